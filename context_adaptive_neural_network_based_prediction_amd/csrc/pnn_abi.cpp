@@ -1,0 +1,866 @@
+// C-ABI layer of libpnn_hip.so (declared in include/pnn_hip.h): contexts, model loading and weight
+// pre-packing, workspace management, and the launch sequences of the FC and convolutional PNNs.
+//
+// Reference behaviour reproduced here (not code): TComPrediction::initTempBuff (model selection,
+// hm_16_15_substitution/source/Lib/TLibCommon/TComPrediction.cpp:108-178), load_graphs
+// (hevc/hm_common/c++/source_common/integration_prediction_neural_network.cpp:29-69), the graph of
+// pnn/components.py:10-261, and predict_by_batch_via_pnn (pnn/batching.py:7-88).
+#include "../../include/pnn_hip.h"
+#include "pnn_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pnn;
+
+namespace {
+
+constexpr int kHidden = 1200;                         // pnn/components.py:130-160
+thread_local std::string g_create_error;
+
+int strides_for(int w, int* st)                       // pnn/PredictionNeuralNetwork.py:126-132
+{
+    switch (w) {
+    case 4: st[0] = 1; st[1] = 1; return 2;
+    case 8: st[0] = 2; st[1] = 1; return 2;
+    case 16: st[0] = 2; st[1] = 1; st[2] = 2; st[3] = 1; return 4;
+    case 32: st[0] = 2; st[1] = 2; st[2] = 1; st[3] = 2; st[4] = 1; return 5;
+    case 64: st[0] = 2; st[1] = 2; st[2] = 2; st[3] = 2; st[4] = 1; return 5;
+    default: return -1;
+    }
+}
+
+int width_index(int w)                                // TComPrediction.cpp:564: log2(w) - 2
+{
+    switch (w) { case 4: return 0; case 8: return 1; case 16: return 2; case 32: return 3; case 64: return 4; default: return -1; }
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct GemmLayer {                                    // one tap-GEMM launch (all classes)
+    TapGemmParams proto{};
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    double k_total = 0;                               // sum over classes of taps * Cin
+    long out_per_block = 0;                           // output floats per block
+};
+struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_bias = nullptr; long out_per_block = 0; };
+struct TConv1Layer { TConv1Params proto{}; float* d_w = nullptr; };
+struct MergerLayer { MergerParams proto{}; float* d_w = nullptr; float* d_bias = nullptr; };
+
+struct Model {
+    int width = 0;
+    bool is_fc = false;
+    long n_params = 0;
+    int n_layers = 0;
+    std::vector<GemmLayer> fc;                        // 4 layers
+    Conv1Layer first[2];                              // branch_above / branch_left conv 0
+    std::vector<GemmLayer> branch[2];                 // conv 1..L-1
+    MergerLayer merger;
+    std::vector<GemmLayer> tconv;                     // tconv 0..L-2
+    TConv1Layer last;
+    int C = 0;                                        // channels at the merger
+    long pmax = 0;                                    // largest intermediate activation (floats / block)
+    std::vector<void*> allocs;
+};
+
+}  // namespace
+
+struct pnn_ctx {
+    int device = 0;
+    float mean = 0.f;
+    hipStream_t stream = nullptr;
+    Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf ws[4];                                     // P0, P1, F0, F1 (FC uses P0, P1)
+    DevBuf stage_in[2], stage_out[2], stage_tbs;
+    long opt_tile_cfg = -1;
+    long opt_max_chunk = 0;
+    size_t ws_cap_bytes = (size_t)8 << 30;
+    std::string err;
+    int stat_gemm_launches = 0, stat_launches = 0;
+    double stat_gemm_flops = 0;
+};
+
+namespace {
+
+int fail(pnn_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail((c), PNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (b.bytes >= bytes) return PNN_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    if (hipMalloc(&b.p, want) != hipSuccess) return fail(c, PNN_E_NOMEM, "hipMalloc(%zu) failed", want);
+    b.bytes = want;
+    return PNN_OK;
+}
+
+int upload(pnn_ctx* c, Model* m, const float* host, size_t n, float** out)
+{
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max(n, (size_t)4) * sizeof(float)) != hipSuccess)
+        return fail(c, PNN_E_NOMEM, "hipMalloc of %zu weight floats failed", n);
+    m->allocs.push_back(d);
+    HIPCHK(c, hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)d;
+    return PNN_OK;
+}
+
+// [K][N] row-major -> [K/16][4][Npad][4] (k = 16*chunk + 4*q + e), zero-padded columns.
+std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad)
+{
+    std::vector<float> out((size_t)K * npad, 0.f);
+    for (long k = 0; k < K; k++) {
+        const long ch = k >> 4; const int q = (k >> 2) & 3, e = k & 3;
+        float* dst = out.data() + (((size_t)ch * 4 + q) * npad) * 4 + e;
+        const float* src = kn.data() + (size_t)k * N;
+        for (int n = 0; n < N; n++) dst[(size_t)n * 4] = src[n];
+    }
+    return out;
+}
+
+int npad_for(int cout) { return ((cout + 15) / 16) * 16 + 128; }
+
+// Fully-connected layer as a one-tap GEMM (pnn/components.py:169-176).
+int build_fc_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int K, int N, int act, GemmLayer* L)
+{
+    if (K % 16) return fail(c, PNN_E_MODEL, "FC input size %d is not a multiple of 16", K);
+    std::vector<float> kn(W, W + (size_t)K * N);
+    const int npad = npad_for(N);
+    std::vector<float> packed = pack_kn(kn, K, N, npad);
+    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
+    if (rc) return rc;
+    std::vector<float> bias(((N + 3) / 4) * 4 + 4, 0.f);
+    std::copy(b, b + N, bias.begin());
+    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
+    if (rc) return rc;
+    TapGemmParams& p = L->proto;
+    p.SH = p.SW = p.IH = p.IW = p.OH = p.OW = 1;
+    p.a = 1; p.os = 1; p.Cin = K; p.Cout = N; p.Npad = npad; p.act = act;
+    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.py[0] = p.px[0] = 0; p.dy[0] = p.dx[0] = 0;
+    L->k_total = K; L->out_per_block = N;
+    return PNN_OK;
+}
+
+// Forward convolution (pnn/tfutils.py:75-139). W is [k][k][Cin][Cout].
+int build_conv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int IH, int IW, int Cin, int Cout, int s,
+                     GemmLayer* L)
+{
+    const int k = 2 * s + 1, OH = (IH + s - 1) / s, OW = (IW + s - 1) / s;
+    const int pad = std::max((OH - 1) * s + k - IH, 0) / 2;
+    if (Cin % 16 || Cout % 4) return fail(c, PNN_E_MODEL, "conv layer %d->%d not MFMA-tileable", Cin, Cout);
+    const long K = (long)k * k * Cin;
+    std::vector<float> kn(W, W + (size_t)K * Cout);
+    const int npad = npad_for(Cout);
+    std::vector<float> packed = pack_kn(kn, K, Cout, npad);
+    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
+    if (rc) return rc;
+    std::vector<float> bias(Cout + 4, 0.f);
+    std::copy(b, b + Cout, bias.begin());
+    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
+    if (rc) return rc;
+    TapGemmParams& p = L->proto;
+    p.SH = OH; p.SW = OW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = s;
+    p.OH = OH; p.OW = OW; p.Cout = Cout; p.os = 1; p.Npad = npad; p.act = 1;
+    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = k * k; p.py[0] = p.px[0] = 0;
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) { p.dy[ky * k + kx] = (int8_t)(ky - pad); p.dx[ky * k + kx] = (int8_t)(kx - pad); }
+    L->k_total = (double)K; L->out_per_block = (long)OH * OW * Cout;
+    return PNN_OK;
+}
+
+// Transposed convolution with Cout >= 4 (Appendix B.3; pnn/tfutils.py:395-462). W is [k][k][Cout][Cin].
+// Gather form: y[oy] takes x[iy] through tap ky iff iy*s + ky - pad == oy (pad = 1 for s = 1, 2).
+int build_tconv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int IH, int IW, int Cin, int Cout, int s,
+                      int act, GemmLayer* L)
+{
+    const int k = 2 * s + 1, OH = IH * s, OW = IW * s;
+    const int pad = std::max((IH - 1) * s + k - OH, 0) / 2;
+    if (Cin % 16 || Cout % 4 || (s != 1 && s != 2)) return fail(c, PNN_E_MODEL, "tconv layer %d->%d not tileable", Cin, Cout);
+    TapGemmParams& p = L->proto;
+    std::vector<float> kn;                           // rows ordered (class, tap, ci)
+    int ntap = 0;
+    p.ncls = s * s;
+    for (int py = 0; py < s; py++)
+        for (int px = 0; px < s; px++) {
+            const int cls = py * s + px;
+            p.tap_begin[cls] = ntap; p.py[cls] = py; p.px[cls] = px;
+            for (int ky = 0; ky < k; ky++) {
+                if ((py + pad - ky) % s) continue;   // C++ % keeps the sign; parity test is sign-safe
+                for (int kx = 0; kx < k; kx++) {
+                    if ((px + pad - kx) % s) continue;
+                    p.dy[ntap] = (int8_t)((py + pad - ky) / s);
+                    p.dx[ntap] = (int8_t)((px + pad - kx) / s);
+                    const float* wt = W + (size_t)(ky * k + kx) * Cout * Cin;
+                    for (int ci = 0; ci < Cin; ci++)
+                        for (int co = 0; co < Cout; co++) kn.push_back(wt[(size_t)co * Cin + ci]);
+                    ntap++;
+                }
+            }
+        }
+    p.tap_begin[p.ncls] = ntap;
+    const long K = (long)ntap * Cin;
+    const int npad = npad_for(Cout);
+    std::vector<float> packed = pack_kn(kn, K, Cout, npad);
+    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
+    if (rc) return rc;
+    std::vector<float> bias(Cout + 4, 0.f);
+    std::copy(b, b + Cout, bias.begin());
+    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
+    if (rc) return rc;
+    p.SH = IH; p.SW = IW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = 1;
+    p.OH = OH; p.OW = OW; p.Cout = Cout; p.os = s; p.Npad = npad; p.act = act;
+    L->k_total = (double)K; L->out_per_block = (long)OH * OW * Cout;
+    return PNN_OK;
+}
+
+void free_model(Model* m)
+{
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n, Model** out)
+{
+    Model* m = new Model();
+    m->width = width; m->is_fc = is_fc != 0; m->n_params = (long)n;
+    const float* p = params;
+    const float* end = params + n;
+    int rc = PNN_OK;
+    auto need = [&](size_t k) { return (size_t)(end - p) >= k; };
+    if (is_fc) {
+        if (width != 4 && width != 8 && width != 16) { free_model(m); return fail(c, PNN_E_MODEL, "no FC architecture for width %d", width); }
+        const int dims[5] = {5 * width * width, kHidden, kHidden, kHidden, width * width};
+        m->fc.resize(4);
+        for (int i = 0; i < 4 && rc == PNN_OK; i++) {
+            const size_t nw = (size_t)dims[i] * dims[i + 1];
+            if (!need(nw + dims[i + 1])) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
+            rc = build_fc_layer(c, m, p, p + nw, dims[i], dims[i + 1], i < 3, &m->fc[i]);
+            p += nw + dims[i + 1];
+        }
+        m->n_layers = 4;
+        m->pmax = kHidden;
+    } else {
+        int st[8];
+        const int L = strides_for(width, st);
+        if (L < 0) { free_model(m); return fail(c, PNN_E_MODEL, "no convolutional architecture for width %d", width); }
+        int C = 32;
+        for (int br = 0; br < 2 && rc == PNN_OK; br++) {
+            int H = br == 0 ? width : 2 * width, Wd = br == 0 ? 3 * width : width, cin = 1, ch = 32;
+            for (int i = 0; i < L && rc == PNN_OK; i++) {
+                const int s = st[i], k = 2 * s + 1;
+                ch *= s;
+                const size_t nw = (size_t)k * k * cin * ch;
+                if (!need(nw + ch)) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
+                const int OH = (H + s - 1) / s, OW = (Wd + s - 1) / s;
+                if (i == 0) {
+                    Conv1Layer& f = m->first[br];
+                    rc = upload(c, m, p, nw, &f.d_w);
+                    if (rc == PNN_OK) {
+                        std::vector<float> bias(ch + 4, 0.f);
+                        std::copy(p + nw, p + nw + ch, bias.begin());
+                        rc = upload(c, m, bias.data(), bias.size(), &f.d_bias);
+                    }
+                    f.proto.IH = H; f.proto.IW = Wd; f.proto.s = s; f.proto.k = k;
+                    f.proto.pad = std::max((OH - 1) * s + k - H, 0) / 2;
+                    f.proto.OH = OH; f.proto.OW = OW; f.proto.Cout = ch;
+                    f.out_per_block = (long)OH * OW * ch;
+                    m->pmax = std::max(m->pmax, f.out_per_block);
+                } else {
+                    m->branch[br].emplace_back();
+                    rc = build_conv_layer(c, m, p, p + nw, H, Wd, cin, ch, s, &m->branch[br].back());
+                    if (rc == PNN_OK) m->pmax = std::max(m->pmax, m->branch[br].back().out_per_block);
+                }
+                p += nw + ch;
+                H = OH; Wd = OW; cin = ch;
+            }
+            if (rc == PNN_OK && ((br == 0 && (H != 4 || Wd != 12)) || (br == 1 && (H != 8 || Wd != 4))))
+                rc = fail(c, PNN_E_MODEL, "branch output is %dx%d, expected 4x12 / 8x4", H, Wd);
+            C = ch;
+        }
+        m->C = C;
+        if (rc == PNN_OK) {                          // channel-wise FC merger: Wm [C][80][16] -> [80][16][C]
+            const size_t nw = (size_t)C * 80 * 16, nb = (size_t)C * 16;
+            if (!need(nw + nb)) rc = fail(c, PNN_E_MODEL, "parameter buffer too short");
+            else {
+                std::vector<float> wp(nw), bp(nb);
+                for (int ch = 0; ch < C; ch++)
+                    for (int pp = 0; pp < 80; pp++)
+                        for (int j = 0; j < 16; j++) wp[((size_t)pp * 16 + j) * C + ch] = p[((size_t)ch * 80 + pp) * 16 + j];
+                for (int ch = 0; ch < C; ch++)
+                    for (int j = 0; j < 16; j++) bp[(size_t)j * C + ch] = p[nw + (size_t)ch * 16 + j];
+                rc = upload(c, m, wp.data(), nw, &m->merger.d_w);
+                if (rc == PNN_OK) rc = upload(c, m, bp.data(), nb, &m->merger.d_bias);
+                m->merger.proto.C = C; m->merger.proto.na = 48; m->merger.proto.nl = 32; m->merger.proto.nout = 16;
+                p += nw + nb;
+                m->pmax = std::max(m->pmax, (long)16 * C);
+            }
+        }
+        int H = 4, ci = C;
+        for (int i = 0; i < L && rc == PNN_OK; i++) { // merger transposed convolutions, reversed strides
+            const int s = st[L - 1 - i], k = 2 * s + 1;
+            const bool last = i == L - 1;
+            const int co = last ? 1 : ci / s;
+            const size_t nw = (size_t)k * k * co * ci;
+            if (!need(nw + co)) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
+            if (last) {
+                rc = upload(c, m, p, nw, &m->last.d_w);   // [k][k][1][Cin] == [k][k][Cin]
+                m->last.proto.IH = H; m->last.proto.IW = H; m->last.proto.Cin = ci; m->last.proto.s = s; m->last.proto.k = k;
+                m->last.proto.pad = std::max((H - 1) * s + k - H * s, 0) / 2;
+                m->last.proto.bias = p[nw];
+            } else {
+                m->tconv.emplace_back();
+                rc = build_tconv_layer(c, m, p, p + nw, H, H, ci, co, s, 1, &m->tconv.back());
+                if (rc == PNN_OK) m->pmax = std::max(m->pmax, m->tconv.back().out_per_block);
+            }
+            p += nw + co;
+            H *= s; ci = co;
+        }
+        if (rc == PNN_OK && H != width) rc = fail(c, PNN_E_MODEL, "merger output width %d != %d", H, width);
+        m->n_layers = 3 * L + 1;
+    }
+    if (rc == PNN_OK && p != end) rc = fail(c, PNN_E_MODEL, "%zu parameters given, architecture needs %zu", n, (size_t)(p - params));
+    if (rc != PNN_OK) { free_model(m); return rc; }
+    *out = m;
+    return PNN_OK;
+}
+
+// Tile choice: fewest "rounds x tile area", with a penalty for small tiles (less operand reuse).
+int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls)
+{
+    if (c->opt_tile_cfg >= 0 && c->opt_tile_cfg < tapgemm_num_cfgs()) return (int)c->opt_tile_cfg;
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < tapgemm_num_cfgs(); i++) {
+        const TileCfg t = tapgemm_cfg(i);
+        const long bm = 64L * t.rt, bn = 16L * t.nt;
+        const long wgs = ((M + bm - 1) / bm) * ((cout + bn - 1) / bn) * ncls;
+        const long slots = 256L * 2;                  // two workgroups per CU share its matrix pipes
+        const long rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * 2.0 * bm * bn * (1.0 + 0.5 / t.nt + 0.15 / t.rt);
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
+int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s)
+{
+    TapGemmParams p = L.proto;
+    p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
+    const long M = nblocks * p.SH * p.SW;
+    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
+    p.M = (int)M;
+    const int cfg = choose_cfg(c, M, p.Cout, p.ncls);
+    HIPCHK(c, launch_tapgemm(p, cfg, s));
+    c->stat_gemm_launches++; c->stat_launches++;
+    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    return PNN_OK;
+}
+
+long chunk_blocks(const pnn_ctx* c, const Model* m)
+{
+    if (c->opt_max_chunk > 0) return c->opt_max_chunk;
+    const double per_block = 4.0 * (m->is_fc ? 2.0 * kHidden : 2.0 * m->pmax + 80.0 * m->C);
+    long n = (long)((double)c->ws_cap_bytes / per_block);
+    return std::max(1L, std::min(n, 1L << 20));
+}
+
+int ensure_ws(pnn_ctx* c, const Model* m, long nb)
+{
+    int rc;
+    if ((rc = dev_reserve(c, c->ws[0], (size_t)nb * m->pmax * 4))) return rc;
+    if ((rc = dev_reserve(c, c->ws[1], (size_t)nb * m->pmax * 4))) return rc;
+    if (!m->is_fc) {
+        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 48 * m->C * 4))) return rc;
+        if ((rc = dev_reserve(c, c->ws[3], (size_t)nb * 32 * m->C * 4))) return rc;
+    }
+    return PNN_OK;
+}
+
+Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
+{
+    const int idx = width_index(width);
+    if (!c) { *rc = PNN_E_ARG; return nullptr; }
+    if (idx < 0 || !c->models[idx]) { *rc = fail(c, PNN_E_MODEL, "no model loaded for width %d", width); return nullptr; }
+    Model* m = c->models[idx];
+    if (want_fc >= 0 && (int)m->is_fc != want_fc) {
+        *rc = fail(c, PNN_E_MODEL, "model for width %d is %s", width, m->is_fc ? "fully-connected" : "convolutional");
+        return nullptr;
+    }
+    *rc = PNN_OK;
+    return m;
+}
+
+int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
+{
+    float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
+    int rc;
+    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
+    if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
+    if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
+    return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
+}
+
+int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, long nb, float* d_out, int32_t* d_dst,
+              hipStream_t s)
+{
+    float* P[2] = {(float*)c->ws[0].p, (float*)c->ws[1].p};
+    float* F[2] = {(float*)c->ws[2].p, (float*)c->ws[3].p};
+    int rc;
+    for (int br = 0; br < 2; br++) {
+        const size_t nl = m->branch[br].size();
+        Conv1Params f = m->first[br].proto;
+        f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
+        f.B = (int)nb;
+        int cur = 0;
+        f.Y = nl == 0 ? F[br] : P[cur];
+        HIPCHK(c, launch_conv_cin1(f, s));
+        c->stat_launches++;
+        for (size_t i = 0; i < nl; i++) {
+            float* dst = (i + 1 == nl) ? F[br] : P[cur ^ 1];
+            if ((rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s))) return rc;
+            cur ^= 1;
+        }
+    }
+    MergerParams mp = m->merger.proto;
+    mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
+    HIPCHK(c, launch_merger(mp, s));
+    c->stat_launches++;
+    int cur = 0;
+    for (size_t i = 0; i < m->tconv.size(); i++) {
+        if ((rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s))) return rc;
+        cur ^= 1;
+    }
+    TConv1Params tp = m->last.proto;
+    tp.X = P[cur]; tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
+    HIPCHK(c, launch_tconv_cout1(tp, s));
+    c->stat_launches++;
+    return PNN_OK;
+}
+
+void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; c->stat_gemm_flops = 0; }
+
+// Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
+int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
+            int32_t* d_dst, hipStream_t s)
+{
+    const int w = m->width;
+    const long chunk = std::min(n, chunk_blocks(c, m));
+    int rc = ensure_ws(c, m, chunk);
+    if (rc) return rc;
+    for (long b0 = 0; b0 < n; b0 += chunk) {
+        const long nb = std::min(chunk, n - b0);
+        float* o = d_out ? d_out + b0 * w * w : nullptr;
+        int32_t* di = d_dst ? d_dst + b0 * w * w : nullptr;
+        rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, nb, o, di, s)
+                      : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
+        if (rc) return rc;
+    }
+    return PNN_OK;
+}
+
+bool read_file(const std::string& path, std::vector<char>* out)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize(sz > 0 ? sz : 0);
+    const size_t got = sz > 0 ? fread(out->data(), 1, sz, f) : 0;
+    fclose(f);
+    return got == (size_t)std::max(sz, 0L);
+}
+
+struct TableEntry { int width, is_pair, channel; std::string path; };
+
+// hevc/hm_common/c++/source_common/tools.cpp:52-111 (+ split_string :127-152): fields split on runs of
+// delimiters, lines made of whitespace only are skipped, keys parsed like std::stoul (leading blanks
+// skipped, trailing text ignored), the path trimmed of surrounding whitespace.
+int parse_table(const char* path, std::vector<TableEntry>* out, std::string* err)
+{
+    std::vector<char> data;
+    if (!path || !read_file(path, &data)) { *err = std::string("The file at \"") + (path ? path : "(null)") + "\" cannot be opened."; return PNN_E_IO; }
+    const std::string text(data.begin(), data.end());
+    size_t pos = 0;
+    const char* ws = " \t\f\v\n\r";
+    while (pos <= text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1;
+        if (line.find_first_not_of(ws) == std::string::npos) { if (eol == text.size()) break; continue; }
+        std::vector<std::string> f;
+        size_t i = 0;
+        while (i <= line.size()) {
+            size_t j = line.find_first_of(",;", i);
+            if (j == std::string::npos) { f.push_back(line.substr(i)); break; }
+            f.push_back(line.substr(i, j - i));
+            i = line.find_first_not_of(",;", j);
+            if (i == std::string::npos) break;
+        }
+        if (f.size() < 4) { *err = "model table line with fewer than 4 fields: " + line; return PNN_E_IO; }
+        TableEntry e;
+        char* endp = nullptr;
+        const char* s0 = f[0].c_str();
+        e.width = (int)strtoul(s0, &endp, 10);
+        if (endp == s0) { *err = "model table: bad width in line: " + line; return PNN_E_IO; }
+        const char* s1 = f[1].c_str();
+        e.is_pair = strtoul(s1, &endp, 10) != 0;
+        if (endp == s1) { *err = "model table: bad is_pair in line: " + line; return PNN_E_IO; }
+        const char* s2 = f[2].c_str();
+        e.channel = (int)strtoul(s2, &endp, 10);
+        if (endp == s2) { *err = "model table: bad channel in line: " + line; return PNN_E_IO; }
+        std::string v = f[3];
+        const size_t a = v.find_first_not_of(ws);
+        const size_t b = v.find_last_not_of(ws);
+        e.path = a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+        out->push_back(e);
+        if (eol == text.size()) break;
+    }
+    return PNN_OK;
+}
+
+struct PnnwHeader { char magic[4]; uint32_t version, width, is_fc; uint64_t n_params, reserved; };
+
+}  // namespace
+
+extern "C" {
+
+int pnn_create_empty(pnn_ctx** out, float mean, int device)
+{
+    if (!out) return fail(nullptr, PNN_E_ARG, "`out` is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PNN_E_HIP, "no HIP device is visible: libpnn_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, PNN_E_ARG, "device %d out of range [0, %d)", device, ndev);
+    pnn_ctx* c = new pnn_ctx();
+    c->device = device; c->mean = mean;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, PNN_E_HIP, "cannot initialise HIP device %d", device);
+    }
+    if (const char* e = getenv("PNN_TILE_CFG")) c->opt_tile_cfg = atol(e);
+    if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
+    *out = c;
+    return PNN_OK;
+}
+
+int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params, size_t n)
+{
+    if (!c || !params) return fail(c, PNN_E_ARG, "NULL argument");
+    const int idx = width_index(width);
+    if (idx < 0) return fail(c, PNN_E_ARG, "width %d is not in {4, 8, 16, 32, 64}", width);
+    HIPCHK(c, hipSetDevice(c->device));
+    Model* m = nullptr;
+    const int rc = build_model(c, width, is_fc, params, n, &m);
+    if (rc) return rc;
+    free_model(c->models[idx]);
+    c->models[idx] = m;
+    return PNN_OK;
+}
+
+int pnn_load_model_file(pnn_ctx* c, const char* path)
+{
+    if (!c || !path) return fail(c, PNN_E_ARG, "NULL argument");
+    std::vector<char> data;
+    if (!read_file(path, &data)) return fail(c, PNN_E_IO, "The model file at \"%s\" cannot be loaded.", path);
+    if (data.size() < sizeof(PnnwHeader)) return fail(c, PNN_E_IO, "%s: truncated header", path);
+    PnnwHeader h;
+    memcpy(&h, data.data(), sizeof h);
+    if (memcmp(h.magic, "PNNW", 4) || h.version != 1) return fail(c, PNN_E_IO, "%s is not a PNNW v1 file", path);
+    if (data.size() != sizeof h + h.n_params * 4) return fail(c, PNN_E_IO, "%s: size does not match its header", path);
+    std::vector<float> params(h.n_params);
+    memcpy(params.data(), data.data() + sizeof h, h.n_params * 4);
+    return pnn_load_model_params(c, (int)h.width, (int)h.is_fc, params.data(), params.size());
+}
+
+int pnn_create(pnn_ctx** out, const char* table_path, int use_pair, float mean, int device)
+{
+    if (!out) return fail(nullptr, PNN_E_ARG, "`out` is NULL");
+    *out = nullptr;
+    std::vector<TableEntry> entries;
+    std::string err;
+    int rc = parse_table(table_path, &entries, &err);
+    if (rc) return fail(nullptr, rc, "%s", err.c_str());
+    bool have_pair = false;
+    for (const TableEntry& e : entries) have_pair |= e.is_pair != 0;
+    const int want_pair = (have_pair && use_pair) ? 1 : 0;      // TComPrediction.cpp:156
+    pnn_ctx* c = nullptr;
+    if ((rc = pnn_create_empty(&c, mean, device))) return rc;
+    std::string dir(table_path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    static const int widths[5] = {4, 8, 16, 32, 64};
+    for (int wi = 0; wi < 5; wi++) {
+        const TableEntry* hit = nullptr;
+        for (const TableEntry& e : entries)
+            if (e.width == widths[wi] && e.is_pair == want_pair && e.channel == 0) hit = &e;   // later lines overwrite (std::map)
+        if (!hit) {
+            rc = fail(nullptr, PNN_E_MODEL, "model table has no (%d, %s, luminance) entry", widths[wi], want_pair ? "pair" : "single");
+            break;
+        }
+        std::string p = hit->path;
+        if (!p.empty() && p[0] != '/') {
+            FILE* f = fopen((dir + "/" + p).c_str(), "rb");
+            if (f) { fclose(f); p = dir + "/" + p; }
+        }
+        rc = pnn_load_model_file(c, p.c_str());
+        if (rc) { g_create_error = c->err; break; }
+        const Model* m = c->models[wi];
+        if (m->width != widths[wi]) { rc = fail(nullptr, PNN_E_MODEL, "%s holds a width-%d model, table says %d", p.c_str(), m->width, widths[wi]); break; }
+    }
+    if (rc) { pnn_destroy(c); return rc; }
+    *out = c;
+    return PNN_OK;
+}
+
+void pnn_destroy(pnn_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Model*& m : c->models) { free_model(m); m = nullptr; }
+    for (DevBuf& b : c->ws) if (b.p) (void)hipFree(b.p);
+    for (DevBuf& b : c->stage_in) if (b.p) (void)hipFree(b.p);
+    for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
+    if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pnn_last_error(const pnn_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+float pnn_mean(const pnn_ctx* c) { return c ? c->mean : 0.f; }
+
+int pnn_model_info(const pnn_ctx* c, int width, int* is_fc, int* n_layers, long* n_params)
+{
+    const int idx = width_index(width);
+    if (!c || idx < 0 || !c->models[idx]) return PNN_E_MODEL;
+    if (is_fc) *is_fc = c->models[idx]->is_fc;
+    if (n_layers) *n_layers = c->models[idx]->n_layers;
+    if (n_params) *n_params = c->models[idx]->n_params;
+    return PNN_OK;
+}
+
+int pnn_set_option(pnn_ctx* c, const char* name, long value)
+{
+    if (!c || !name) return PNN_E_ARG;
+    if (!strcmp(name, "tile_cfg")) c->opt_tile_cfg = value;
+    else if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
+    else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
+    else return fail(c, PNN_E_ARG, "unknown option %s", name);
+    return PNN_OK;
+}
+
+int pnn_last_call_stats(const pnn_ctx* c, int* n_gemm, double* flops, int* n_launches)
+{
+    if (!c) return PNN_E_ARG;
+    if (n_gemm) *n_gemm = c->stat_gemm_launches;
+    if (flops) *flops = c->stat_gemm_flops;
+    if (n_launches) *n_launches = c->stat_launches;
+    return PNN_OK;
+}
+
+// ---- device-resident entry points ----------------------------------------------------------------------
+
+int pnn_predict_fc_device(pnn_ctx* c, int width, const float* d_ctx, int n, float* d_out, void* stream)
+{
+    int rc;
+    Model* m = model_for(c, width, 1, &rc);
+    if (!m) return rc;
+    if (n < 0 || (n > 0 && (!d_ctx || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stats(c);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_net(c, m, d_ctx, 5L * width * width, nullptr, 0, n, d_out, nullptr, s);
+}
+
+int pnn_predict_conv_device(pnn_ctx* c, int width, const float* d_above, const float* d_left, int n, float* d_out, void* stream)
+{
+    int rc;
+    Model* m = model_for(c, width, 0, &rc);
+    if (!m) return rc;
+    if (n < 0 || (n > 0 && (!d_above || !d_left || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stats(c);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_net(c, m, d_above, 3L * width * width, d_left, 2L * width * width, n, d_out, nullptr, s);
+}
+
+int pnn_make_tb_desc(pnn_tb_dev* out, int64_t origin, int32_t stride, const uint8_t* flags, int n_avail, int above_units,
+                     int left_units)
+{
+    if (!out || !flags) { fprintf(stderr, "`out` or `neighbor_flags` is NULL.\n"); return -1; }
+    if (n_avail <= 0) { fprintf(stderr, "`iNumIntraNeighbor` is not strictly positive.\n"); return -1; }   // extraction_context.cpp:42-47
+    if (above_units > 32 || left_units < 0 || above_units < 0) return -1;
+    out->origin = origin; out->stride = stride; out->reserved = 0;
+    if (n_avail == above_units + left_units + 1) {               // extraction_context.cpp:56: dense copy of everything
+        out->above_mask = above_units >= 32 ? 0xffffffffu : ((1u << above_units) - 1u);
+        out->left_units = left_units;
+        return 0;
+    }
+    if (!flags[left_units]) {                                     // extraction_context.cpp:133-139
+        fprintf(stderr, "The neighbouring unit above and on the left side of the current TB is not available.\n");
+        return -1;
+    }
+    uint32_t mask = 0;
+    for (int i = 0; i < above_units; i++) if (flags[left_units + 1 + i]) mask |= 1u << i;
+    int cnt = 0;
+    for (int i = 0; i < left_units; i++) cnt += flags[i] != 0;   // rows compact upwards, extraction_context.cpp:189-205
+    out->above_mask = mask; out->left_units = cnt;
+    return 0;
+}
+
+int pnn_gather_device(pnn_ctx* c, int width, int unit, const void* d_plane, int pel_bytes, const pnn_tb_dev* d_tbs, int n,
+                      float* d_above, long pitch_above, float* d_left, long pitch_left, void* stream)
+{
+    if (!c) return PNN_E_ARG;
+    if (width_index(width) < 0 || (unit != 4 && unit != 2) || n < 0 || (n > 0 && (!d_plane || !d_tbs || !d_above || !d_left)))
+        return fail(c, PNN_E_ARG, "bad gather arguments");
+    if (pel_bytes != 4 && pel_bytes != 1) return fail(c, PNN_E_ARG, "pel_bytes must be 4 (HM Pel) or 1 (uint8)");
+    HIPCHK(c, hipSetDevice(c->device));
+    GatherParams g;
+    g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs); g.N = n; g.w = width;
+    g.unit = unit; g.mean = c->mean; g.above = d_above; g.left = d_left; g.pitch_above = pitch_above; g.pitch_left = pitch_left;
+    HIPCHK(c, launch_gather(g, stream ? (hipStream_t)stream : c->stream));
+    return PNN_OK;
+}
+
+int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_bytes, const pnn_tb_dev* d_tbs, int n,
+                           int32_t* d_dst, float* d_out_f32, void* stream)
+{
+    int rc;
+    Model* m = model_for(c, width, -1, &rc);
+    if (!m) return rc;
+    if (n < 0 || (n > 0 && (!d_plane || !d_tbs || (!d_dst && !d_out_f32)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stats(c);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const long w2 = (long)width * width;
+    const long chunk = std::min((long)n, chunk_blocks(c, m));
+    if ((rc = dev_reserve(c, c->stage_in[0], (size_t)chunk * 5 * w2 * 4))) return rc;
+    float* ctxbuf = (float*)c->stage_in[0].p;
+    for (long b0 = 0; b0 < n; b0 += chunk) {
+        const long nb = std::min(chunk, (long)n - b0);
+        float* ab = ctxbuf;
+        float* lf = m->is_fc ? ctxbuf + 3 * w2 : ctxbuf + nb * 3 * w2;
+        const long pa = m->is_fc ? 5 * w2 : 3 * w2, pl = m->is_fc ? 5 * w2 : 2 * w2;
+        if ((rc = pnn_gather_device(c, width, 4, d_plane, pel_bytes, d_tbs + b0, (int)nb, ab, pa, lf, pl, s))) return rc;
+        c->stat_launches++;
+        if ((rc = run_net(c, m, ab, pa, lf, pl, nb, d_out_f32 ? d_out_f32 + b0 * w2 : nullptr, d_dst ? d_dst + b0 * w2 : nullptr, s)))
+            return rc;
+    }
+    return PNN_OK;
+}
+
+// ---- host-buffer entry points ----------------------------------------------------------------------------
+
+static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst,
+                        int dst_stride)
+{
+    const int w = m->width;
+    const long w2 = (long)w * w;
+    if (n < 0 || (n > 0 && (!above || (!out && !dst)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
+    if (n == 0) return PNN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stats(c);
+    int rc;
+    hipStream_t s = c->stream;
+    const size_t in_a = (size_t)n * (m->is_fc ? 5 : 3) * w2 * 4, in_l = m->is_fc ? 0 : (size_t)n * 2 * w2 * 4;
+    if ((rc = dev_reserve(c, c->stage_in[0], in_a))) return rc;
+    if (in_l && (rc = dev_reserve(c, c->stage_in[1], in_l))) return rc;
+    if ((rc = dev_reserve(c, c->stage_out[0], (size_t)n * w2 * 4))) return rc;
+    if (dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage_in[0].p, above, in_a, hipMemcpyHostToDevice, s));
+    if (in_l) {
+        if (!left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
+        HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
+    }
+    float* d_out = (float*)c->stage_out[0].p;
+    int32_t* d_dst = dst ? (int32_t*)c->stage_out[1].p : nullptr;
+    rc = run_net(c, m, (const float*)c->stage_in[0].p, m->is_fc ? 5 * w2 : 3 * w2, (const float*)c->stage_in[1].p, 2 * w2, n,
+                 d_out, d_dst, s);
+    if (rc) return rc;
+    if (out) HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n * w2 * 4, hipMemcpyDeviceToHost, s));
+    if (dst) {
+        if (dst_stride == w) HIPCHK(c, hipMemcpyAsync(dst, d_dst, (size_t)n * w2 * 4, hipMemcpyDeviceToHost, s));
+        else HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, d_dst, (size_t)w * 4, (size_t)w * 4, (size_t)n * w,
+                                        hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PNN_OK;
+}
+
+int pnn_predict_fc(pnn_ctx* c, int width, const float* context, int n, float* out)
+{
+    int rc;
+    Model* m = model_for(c, width, 1, &rc);
+    if (!m) return rc;
+    if (!out) return fail(c, PNN_E_ARG, "`out` is NULL");
+    return host_predict(c, m, context, nullptr, n, out, nullptr, 0);
+}
+
+int pnn_predict_conv(pnn_ctx* c, int width, const float* above, const float* left, int n, float* out)
+{
+    int rc;
+    Model* m = model_for(c, width, 0, &rc);
+    if (!m) return rc;
+    if (!out) return fail(c, PNN_E_ARG, "`out` is NULL");
+    return host_predict(c, m, above, left, n, out, nullptr, 0);
+}
+
+int pnn_predict_pel(pnn_ctx* c, int width, const float* above, const float* left, int n, int32_t* dst, int dst_stride)
+{
+    int rc;
+    Model* m = model_for(c, width, -1, &rc);
+    if (!m) return rc;
+    if (!dst || dst_stride < width) return fail(c, PNN_E_ARG, "bad destination");
+    if (n > 1 && dst_stride != width) return fail(c, PNN_E_ARG, "strided destination needs n == 1");
+    return host_predict(c, m, above, left, n, nullptr, dst, dst_stride);
+}
+
+int pnn_parse_model_table(const char* path, int* widths, int* is_pair, int* channels, const char** paths, int max_entries)
+{
+    static thread_local std::vector<TableEntry> keep;
+    keep.clear();
+    std::string err;
+    const int rc = parse_table(path, &keep, &err);
+    if (rc) { g_create_error = err; fprintf(stderr, "%s\n", err.c_str()); return rc; }
+    const int n = std::min((int)keep.size(), max_entries);
+    for (int i = 0; i < n; i++) {
+        if (widths) widths[i] = keep[i].width;
+        if (is_pair) is_pair[i] = keep[i].is_pair;
+        if (channels) channels[i] = keep[i].channel;
+        if (paths) paths[i] = keep[i].path.c_str();
+    }
+    return n;
+}
+
+}  // extern "C"

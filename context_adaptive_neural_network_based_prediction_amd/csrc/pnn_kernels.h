@@ -1,0 +1,82 @@
+// Internal launch interface between the C-ABI layer (pnn_abi.cpp) and the gfx950 kernels
+// (pnn_kernels.hip).  Not part of the public boundary -- see include/pnn_hip.h for that.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnn {
+
+constexpr int kMaxTaps = 32;
+constexpr int kMaxClasses = 4;
+
+// One "tap GEMM": Y[pix(m)][n] = act( sum_{t in class} sum_{ci} X[b, i*a+dy[t], j*a+dx[t], ci] * W[t][ci][n] + bias[n] )
+// with m = (b, i, j) over a SH x SW sub-grid per image and the output pixel (i*os+py, j*os+px).
+//   forward conv, stride s : one class, a = s, os = 1, dy = ky - pad_before        
+//   transposed conv, s = 1 : one class, a = 1, os = 1, dy = pad_before - ky         (Appendix B.3)
+//   transposed conv, s = 2 : four output-parity classes, a = 1, os = 2, dy = (py + 1 - ky) / 2
+//   fully-connected layer  : one tap, 1x1 "image", Cin = K                            (components.py:169-176)
+// Weights are pre-packed per 16-deep K chunk as [chunk][q = 4][Npad][4] floats (k = 16*chunk + 4*q + e),
+// the order in which one 16x16x4 f32 MFMA lane group consumes them.
+struct TapGemmParams {
+    const float* X;
+    const float* Wp;
+    const float* bias;
+    float* Y;          // float output (may be null when Yi is set)
+    int32_t* Yi;       // optional fused HM epilogue: (int) round(clamp(v + mean, 0, 255))
+    int M, SH, SW;
+    int IH, IW, Cin, a;
+    int OH, OW, Cout, os;
+    int Npad;
+    int act;
+    float mean;
+    int ncls;
+    int tap_begin[kMaxClasses + 1];
+    int py[kMaxClasses], px[kMaxClasses];
+    int8_t dy[kMaxTaps], dx[kMaxTaps];
+};
+
+// Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
+struct TileCfg { int rt, nt; };
+int tapgemm_num_cfgs();
+TileCfg tapgemm_cfg(int idx);
+hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
+
+// Cin == 1 forward convolution (first layer of each branch): direct VALU kernel.
+struct Conv1Params {
+    const float* X; const float* W; const float* bias; float* Y;
+    int B, IH, IW, s, k, pad, OH, OW, Cout;
+};
+hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
+
+// Cout == 1 transposed convolution (last merger layer), optional fused HM epilogue.
+struct TConv1Params {
+    const float* X; const float* W; /* [k][k][Cin] */ float bias; float* Y; int32_t* Yi;
+    int B, IH, IW, Cin, s, k, pad; float mean;
+};
+hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s);
+
+// Channel-wise fully-connected merger + LeakyReLU (Appendix B.4). Wp is [p = 80][j = 16][C].
+struct MergerParams {
+    const float* A; const float* L; const float* Wp; const float* bias /* [j][C] */; float* Y;
+    int B, C, na, nl, nout;
+};
+hipError_t launch_merger(const MergerParams& p, hipStream_t s);
+
+// L-shaped context gather (extraction_context.cpp:3-208) over a descriptor array.
+struct TbDev {           // mirrors pnn_tb_dev of include/pnn_hip.h
+    int64_t origin;      // element index of the TB's top-left pixel from the plane base
+    int32_t stride;      // row stride in elements
+    uint32_t above_mask; // bit u = above/above-right unit u (left to right) available
+    int32_t left_units;  // number of available left/below-left units, counted from the top
+    int32_t reserved;
+};
+struct GatherParams {
+    const void* plane; int pel_bytes; const TbDev* tbs; int N; int w; int unit; float mean;
+    float* above; float* left; long pitch_above; long pitch_left;
+};
+hipError_t launch_gather(const GatherParams& p, hipStream_t s);
+
+// Stand-alone HM epilogue for float predictions.
+hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, hipStream_t s);
+
+}  // namespace pnn

@@ -1,0 +1,416 @@
+// gfx950 (CDNA4 / MI355X) kernels of the PNN intra-prediction forward pass.
+//
+// Replaces the TensorFlow-1 CPU kernels behind tensorflow::Session::Run in the reference
+// (hm_16_15_substitution/source/Lib/TLibCommon/TComPrediction.cpp:572-579,601-608), i.e. the graph
+// built by pnn/components.py:10-261 + pnn/tfutils.py:8-139,395-462, plus the L-shaped context gather
+// of hevc/hm_common/c++/source_common/extraction_context.cpp:3-208 and the epilogue of
+// TComPrediction.cpp:621-635.
+//
+// All dense contractions (FC layers, convolutions and transposed convolutions with Cin >= 16) run
+// through ONE kernel, tapgemm_kernel: an implicit GEMM over a list of spatial taps on the exact-f32
+// matrix cores (v_mfma_f32_16x16x4_f32, 64-lane wavefronts).  Weights stream global -> LDS once per
+// workgroup in the pre-packed order the MFMA lane groups consume; activations are gathered straight
+// into registers (NHWC keeps a pixel's channels contiguous: 64 B per lane group).
+#include "pnn_kernels.h"
+
+namespace pnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(0.1f * v, v); }   // pnn/tfutils.py:192
+
+// TComPrediction.cpp:632: (int) std::round(max(0, min(255, p + mean))), half away from zero.
+__device__ __forceinline__ int hm_round(float p, float mean)
+{
+    float v = p + mean;
+    v = fminf(v, 255.f);
+    v = fmaxf(v, 0.f);
+    return (int)roundf(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tap GEMM on f32 MFMA.
+//   workgroup = 256 threads = 4 waves; wave w owns rows [16*RT*w, 16*RT*(w+1)) of the BM = 64*RT row
+//   tile and all BN = 16*NT columns; accumulators: RT*NT tiles of 16x16 (4 VGPRs each).
+//   MFMA operand roles: "A" = weights (i = n), "B" = activations (j = m); lane l = (l&15, q = l>>4)
+//   supplies k = 4q + e in step e of a 16-deep chunk, for both operands.  D: lane holds column
+//   m = l&15, rows n = 4q + r  ->  one float4 store of 4 consecutive output channels.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int NT>
+__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
+{
+    constexpr int BM = 64 * RT;
+    constexpr int BN = 16 * NT;
+    constexpr int E = 4 * BN;                       // float4 per staged weight chunk
+    constexpr int NLD = (E + 255) / 256;
+    __shared__ f32x4 Bs[2][E];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM + wave * (16 * RT);
+
+    int pb[RT], pi[RT], pj[RT];
+    bool mv[RT];
+    const int SP = p.SH * p.SW;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int mg = m0 + rt * 16 + l15;
+        mv[rt] = mg < p.M;
+        const int mc = mv[rt] ? mg : 0;
+        const int b = mc / SP;
+        const int r = mc - b * SP;
+        pb[rt] = b;
+        pi[rt] = r / p.SW;
+        pj[rt] = r - pi[rt] * p.SW;
+    }
+
+    const int cpt = p.Cin >> 4;                     // 16-deep chunks per tap
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)t0 * cpt * 4 * p.Npad;
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto load_a = [&](int t, int cc, f32x4 (&dst)[RT]) {
+        const int dy = p.dy[t], dx = p.dx[t];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
+            const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            const float* src = p.X + (((size_t)pb[rt] * p.IH + iy) * p.IW + ix) * p.Cin + (cc << 4) + (q << 2);
+            dst[rt] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto load_b = [&](int chunk, f32x4 (&dst)[NLD]) {
+#pragma unroll
+        for (int r = 0; r < NLD; r++) {
+            const int e = tid + 256 * r;
+            if (E % 256 == 0 || e < E) {
+                const int qq = e / BN, nn = e - qq * BN;
+                dst[r] = Wg[((size_t)chunk * 4 + qq) * p.Npad + n0 + nn];
+            }
+        }
+    };
+    auto store_b = [&](int buf, const f32x4 (&src)[NLD]) {
+#pragma unroll
+        for (int r = 0; r < NLD; r++) {
+            const int e = tid + 256 * r;
+            if (E % 256 == 0 || e < E) Bs[buf][e] = src[r];
+        }
+    };
+
+    f32x4 a_cur[RT], a_nxt[RT], b_stage[NLD];
+    int t = t0, cc = 0;
+    load_a(t, cc, a_cur);
+    load_b(0, b_stage);
+    store_b(0, b_stage);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; c++) {
+        const bool more = c + 1 < nchunks;
+        if (more) {
+            if (++cc == cpt) { cc = 0; ++t; }
+            load_a(t, cc, a_nxt);
+            load_b(c + 1, b_stage);
+        }
+        const int buf = c & 1;
+        f32x4 bf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bf[nt] = Bs[buf][q * BN + nt * 16 + l15];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a_cur[rt][e], acc[rt][nt], 0, 0, 0);
+        if (more) {
+            store_b(buf ^ 1, b_stage);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) a_cur[rt] = a_nxt[rt];
+        }
+        __syncthreads();
+    }
+
+    // Epilogue: bias (+ LeakyReLU), float4 store of channels n .. n+3 of this lane's pixel.
+    const int py = p.py[cls], px = p.px[cls];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        if (!mv[rt]) continue;
+        const int oy = pi[rt] * p.os + py, ox = pj[rt] * p.os + px;
+        const size_t obase = (((size_t)pb[rt] * p.OH + oy) * p.OW + ox) * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int n = n0 + nt * 16 + (q << 2);
+            if (n < p.Cout) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 v = acc[rt][nt] + bv;
+                if (p.act) {
+                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                }
+                if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                if (p.Yi) {
+                    int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                        hm_round(v[3], p.mean));
+                    *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                }
+            }
+        }
+    }
+}
+
+static const TileCfg kCfgs[] = {{2, 8}, {2, 5}, {2, 4}, {2, 2}, {2, 1}, {1, 8}, {1, 5}, {1, 4}, {1, 2}, {1, 1}};
+
+int tapgemm_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
+TileCfg tapgemm_cfg(int idx) { return kCfgs[idx]; }
+
+template <int RT, int NT>
+static hipError_t launch_tg(const TapGemmParams& p, hipStream_t s)
+{
+    dim3 grid((p.M + 64 * RT - 1) / (64 * RT), (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
+    hipLaunchKernelGGL((tapgemm_kernel<RT, NT>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    switch (cfg_idx) {
+    case 0: return launch_tg<2, 8>(p, s);
+    case 1: return launch_tg<2, 5>(p, s);
+    case 2: return launch_tg<2, 4>(p, s);
+    case 3: return launch_tg<2, 2>(p, s);
+    case 4: return launch_tg<2, 1>(p, s);
+    case 5: return launch_tg<1, 8>(p, s);
+    case 6: return launch_tg<1, 5>(p, s);
+    case 7: return launch_tg<1, 4>(p, s);
+    case 8: return launch_tg<1, 2>(p, s);
+    case 9: return launch_tg<1, 1>(p, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 1 forward convolution + bias + LeakyReLU (first layer of each branch; k = 3 or 5).
+// 16 (or 8) lanes share one output pixel, 4 output channels per lane: a wave writes 1 KiB (512 B)
+// of contiguous NHWC output per instruction.  HBM-bound on the output write.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
+{
+    const int CG = p.Cout >> 2;                       // lanes per pixel
+    const int ppb = 256 / CG;                         // pixels per block iteration
+    const int cg = threadIdx.x % CG, psub = threadIdx.x / CG;
+    f32x4 w[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W + (size_t)t * p.Cout + 4 * cg);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
+    const long npix = (long)p.B * p.OH * p.OW;
+    for (long pix = (long)blockIdx.x * ppb + psub; pix < npix; pix += (long)gridDim.x * ppb) {
+        const int ox = (int)(pix % p.OW);
+        const long r = pix / p.OW;
+        const int oy = (int)(r % p.OH);
+        const long b = r / p.OH;
+        const float* xb = p.X + b * p.IH * p.IW;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            const int iy = oy * p.s + ky - p.pad;
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) {
+                const int ix = ox * p.s + kx - p.pad;
+                const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                const float xv = ok ? xb[iy * p.IW + ix] : 0.f;
+                acc += xv * w[ky * K + kx];
+            }
+        }
+        acc += bv;
+        acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
+        *reinterpret_cast<f32x4*>(p.Y + pix * p.Cout + 4 * cg) = acc;
+    }
+}
+
+hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
+{
+    const long npix = (long)p.B * p.OH * p.OW;
+    if (npix <= 0) return hipSuccess;
+    const int ppb = 256 / (p.Cout >> 2);
+    long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 1 transposed convolution + bias (last merger layer, linear), optional HM epilogue.
+// Cin/4 lanes per output pixel, float4 channel slices, shuffle reduction inside the lane group.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
+{
+    const int LP = p.Cin >> 2;                        // lanes per pixel: 8 (Cin 32) or 16 (Cin 64)
+    const int cl = threadIdx.x % LP;
+    const int OH = p.IH * p.s, OW = p.IW * p.s;
+    const long npix = (long)p.B * OH * OW;
+    const long pix = ((long)blockIdx.x * 256 + threadIdx.x) / LP;
+    const bool live = pix < npix;
+    const long pc = live ? pix : 0;
+    const int ox = (int)(pc % OW);
+    const long r = pc / OW;
+    const int oy = (int)(r % OH);
+    const long b = r / OH;
+    float acc = 0.f;
+    for (int ky = 0; ky < p.k; ky++) {
+        const int ny = oy + p.pad - ky;
+        if (ny < 0 || (ny % p.s)) continue;
+        const int iy = ny / p.s;
+        if (iy >= p.IH) continue;
+        for (int kx = 0; kx < p.k; kx++) {
+            const int nx = ox + p.pad - kx;
+            if (nx < 0 || (nx % p.s)) continue;
+            const int ix = nx / p.s;
+            if (ix >= p.IW) continue;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.X + ((b * p.IH + iy) * p.IW + ix) * p.Cin + 4 * cl);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.W + (size_t)(ky * p.k + kx) * p.Cin + 4 * cl);
+            acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+    }
+    for (int off = LP >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (live && cl == 0) {
+        const float v = acc + p.bias;
+        if (p.Y) p.Y[pix] = v;
+        if (p.Yi) p.Yi[pix] = hm_round(v, p.mean);
+    }
+}
+
+hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s)
+{
+    const long npix = (long)p.B * p.IH * p.s * p.IW * p.s;
+    if (npix <= 0) return hipSuccess;
+    const int LP = p.Cin >> 2;
+    if (LP != 8 && LP != 16 && LP != 32) return hipErrorInvalidValue;
+    const long threads = npix * LP;
+    hipLaunchKernelGGL(tconv_cout1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel-wise fully-connected merger + LeakyReLU (pnn/tfutils.py:8-73, components.py:231-237).
+// One thread = one channel c of MB consecutive blocks; loads and stores are coalesced over c.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMergerMB = 4;
+__global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(gid % p.C);
+    const long b0 = (gid / p.C) * kMergerMB;
+    if (b0 >= p.B) return;
+    float acc[kMergerMB][16];
+#pragma unroll
+    for (int m = 0; m < kMergerMB; m++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[m][j] = 0.f;
+    const int nin = p.na + p.nl;
+    for (int pp = 0; pp < nin; pp++) {
+        float xv[kMergerMB];
+#pragma unroll
+        for (int m = 0; m < kMergerMB; m++) {
+            const long b = (b0 + m < p.B) ? b0 + m : b0;
+            xv[m] = (pp < p.na) ? p.A[(b * p.na + pp) * p.C + c] : p.L[(b * p.nl + (pp - p.na)) * p.C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float wv = p.Wp[((size_t)pp * 16 + j) * p.C + c];
+#pragma unroll
+            for (int m = 0; m < kMergerMB; m++) acc[m][j] += xv[m] * wv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float bv = p.bias[(size_t)j * p.C + c];
+#pragma unroll
+        for (int m = 0; m < kMergerMB; m++)
+            if (b0 + m < p.B) p.Y[((b0 + m) * 16 + j) * p.C + c] = leaky(acc[m][j] + bv);
+    }
+}
+
+hipError_t launch_merger(const MergerParams& p, hipStream_t s)
+{
+    if (p.B <= 0) return hipSuccess;
+    if (p.nout != 16) return hipErrorInvalidValue;
+    const long threads = (long)((p.B + kMergerMB - 1) / kMergerMB) * p.C;
+    hipLaunchKernelGGL(merger_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// L-shaped context gather: Pel (int32 or uint8) -> float, minus mean, unavailable units -> 0.
+// Equivalent to extraction_context.cpp:3-208 for every flag pattern: the above portion is masked per
+// unit; the left portion holds the first 4*left_units source rows (the reference advances source and
+// destination only on available units, extraction_context.cpp:189-205).
+// ------------------------------------------------------------------------------------------------
+template <typename Pel>
+__global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
+{
+    const int w = p.w;
+    const int na = 3 * w * w, per = 5 * w * w;
+    const long total = (long)p.N * per;
+    const Pel* plane = reinterpret_cast<const Pel*>(p.plane);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long tb = e / per;
+        const int r = (int)(e - tb * per);
+        const TbDev d = p.tbs[tb];
+        if (r < na) {
+            const int row = r / (3 * w), col = r - row * 3 * w;
+            bool ok = true;
+            if (col >= w) ok = (d.above_mask >> ((col - w) / p.unit)) & 1u;
+            float v = 0.f;
+            if (ok) v = (float)plane[d.origin + (long)(row - w) * d.stride + (col - w)] - p.mean;
+            p.above[tb * p.pitch_above + r] = v;
+        } else {
+            const int rl = r - na;
+            const int row = rl / w, col = rl - row * w;
+            const bool ok = row < d.left_units * p.unit;
+            float v = 0.f;
+            if (ok) v = (float)plane[d.origin + (long)row * d.stride + (col - w)] - p.mean;
+            p.left[tb * p.pitch_left + rl] = v;
+        }
+    }
+}
+
+hipError_t launch_gather(const GatherParams& p, hipStream_t s)
+{
+    const long total = (long)p.N * 5 * p.w * p.w;
+    if (total <= 0) return hipSuccess;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (p.pel_bytes == 1) hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void epilogue_kernel(const float* pred, long n, float mean, int32_t* dst)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dst[i] = hm_round(pred[i], mean);
+}
+
+hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, n, mean, dst);
+    return hipGetLastError();
+}
+
+}  // namespace pnn

@@ -1,0 +1,131 @@
+/*
+ * pnn_hip.h -- C ABI of libpnn_hip.so: the MI355X (gfx950) replacement for the TensorFlow-1
+ * frozen-graph inference that the reference's modified HM-16.15 calls per transform block.
+ *
+ * Boundary replaced (reference file:line):
+ *   - tensor allocation      hevc/hm_common/c++/source_common/integration_prediction_neural_network.cpp:3-27
+ *   - load_graph(s)          integration_prediction_neural_network.cpp:29-69,
+ *                            selection logic hm_16_15_substitution/source/Lib/TLibCommon/TComPrediction.cpp:143-178
+ *   - Session::Run + epilogue TComPrediction.cpp:554-635 (substitution), :550-661 (switch)
+ *   - extract_context_portions hevc/hm_common/c++/source_common/extraction_context.cpp:3-208
+ *   - model table parser      hevc/hm_common/c++/source_common/tools.cpp:52-111
+ *   - Python batched driver   pnn/batching.py:7-88 (through the *_device entry points)
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative PNN_E_* code on
+ * error (pnn_last_error() gives the text); nothing throws across this boundary; the caller owns all
+ * buffers; a context is thread-compatible (one context per thread), which is how the reference uses its
+ * sessions (one TComPrediction object per encoder/decoder).
+ *
+ * Tensors keep the frozen graph's layout: float32, NHWC, mean-subtracted in AND out:
+ *   FC   (w = 4, 8[, 16]) : node_flattened_context [N][5w^2] = [above w x 3w | left 2w x w]  -> [N][w][w]
+ *   conv (w = 4 .. 64)    : node_portion_above [N][w][3w], node_portion_left [N][2w][w]       -> [N][w][w]
+ */
+#ifndef PNN_HIP_H
+#define PNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNN_OK 0
+#define PNN_E_ARG (-1)      /* bad argument (the reference's "return -1") */
+#define PNN_E_IO (-2)       /* file missing / malformed */
+#define PNN_E_MODEL (-3)    /* no model loaded for that width, or wrong kind */
+#define PNN_E_HIP (-4)      /* HIP runtime error */
+#define PNN_E_NOMEM (-5)
+
+typedef struct pnn_ctx pnn_ctx;
+
+/* ---- lifetime / models (replaces create_tensors_* + load_graphs + the mean pickle) ------------------ */
+
+/* Creates a context on HIP device `device` with no model. `mean` is mean_training (117.8952234192841 for
+ * luminance, sets/results/training_set/means/luminance/mean_training.pkl). */
+int pnn_create_empty(pnn_ctx** out, float mean, int device);
+
+/* As TComPrediction::initTempBuff (TComPrediction.cpp:108-178): parses the `width,is_pair,channel,path`
+ * table (delimiters ',' and ';', blank lines ignored, tools.cpp:52-111), picks the `pair` models iff the
+ * table lists them and use_pair != 0 (the caller passes qp >= 32), and loads the five luminance models
+ * (widths 4, 8 fully-connected; 16, 32, 64 convolutional). Paths are `.pnnw` flat weight files (see
+ * INTEGRATION.md); relative paths are resolved against the table's directory, then the working directory. */
+int pnn_create(pnn_ctx** out, const char* model_table_path, int use_pair, float mean, int device);
+
+/* Loads one model from a `.pnnw` file (width and kind come from its header). */
+int pnn_load_model_file(pnn_ctx* ctx, const char* path);
+/* Loads one model from host memory: `params` in the canonical flat order (weights.py:tensor_specs). */
+int pnn_load_model_params(pnn_ctx* ctx, int width, int is_fc, const float* params, size_t n_params);
+
+int pnn_model_info(const pnn_ctx* ctx, int width, int* is_fc, int* n_layers, long* n_params);
+void pnn_destroy(pnn_ctx* ctx);
+const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last error of a failed create */
+float pnn_mean(const pnn_ctx* ctx);
+
+/* Tuning knob: "tile_cfg" (-1 = automatic), "max_chunk" (blocks per pass, 0 = automatic). */
+int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
+
+/* ---- host-buffer entry points (what the HM side binds; synchronous) ---------------------------------- */
+
+/* == Session::Run({{"node_flattened_context", T}}, {"fully_connected/node_output"}) for N stacked inputs. */
+int pnn_predict_fc(pnn_ctx* ctx, int width, const float* context, int n, float* out);
+/* == Session::Run({{"node_portion_above", A}, {"node_portion_left", L}}, {".../node_output"}). */
+int pnn_predict_conv(pnn_ctx* ctx, int width, const float* above, const float* left, int n, float* out);
+/* Either of the above followed by the HM epilogue (TComPrediction.cpp:621-635), written with row stride
+ * `dst_stride` into `dst` for n == 1, or densely [n][w][w] when dst_stride == width. For FC models
+ * `left` is ignored when it equals above + 3w^2 or is NULL (one flattened buffer, TComPattern.cpp:352-353). */
+int pnn_predict_pel(pnn_ctx* ctx, int width, const float* above, const float* left, int n, int32_t* dst,
+                    int dst_stride);
+
+/* == extract_context_portions (extraction_context.cpp:3-208), same argument order and error behaviour
+ * (returns -1 on NULL pointers, n_avail <= 0, unavailable corner unit). Pure host code. */
+int pnn_extract_context(const int32_t* roi_origin, float* above, float* left, const uint8_t* neighbor_flags,
+                        int n_avail, int unit_w, int unit_h, int above_units, int left_units, int tu_w,
+                        int tu_h, int pic_stride, float mean);
+
+/* Parses the model table; returns the number of entries written (<= max_entries) or a negative code.
+ * paths[i] points into an internal buffer valid until the next call on the same thread. */
+int pnn_parse_model_table(const char* path, int* widths, int* is_pair, int* channels, const char** paths,
+                          int max_entries);
+
+/* ---- device-resident entry points (batched path, asynchronous on `stream`) --------------------------- */
+
+/* All pointers are device pointers on the context's device; `stream` is a hipStream_t (NULL = the
+ * context's own stream). Calls only enqueue work; the caller synchronises. */
+int pnn_predict_fc_device(pnn_ctx* ctx, int width, const float* d_context, int n, float* d_out, void* stream);
+int pnn_predict_conv_device(pnn_ctx* ctx, int width, const float* d_above, const float* d_left, int n,
+                            float* d_out, void* stream);
+
+/* One transform block of the batched gather. Build it with pnn_make_tb_desc from HM's neighbour flags. */
+typedef struct {
+    int64_t origin;       /* element index of the TB's top-left pixel from the plane base pointer */
+    int32_t stride;       /* plane row stride in elements */
+    uint32_t above_mask;  /* bit u: above / above-right unit u (left to right) is available */
+    int32_t left_units;   /* number of available left / below-left units, counted from the top */
+    int32_t reserved;
+} pnn_tb_dev;
+
+/* Translates HM's (bNeighborFlags, iNumIntraNeighbor) of TComPattern.cpp:260-280 into a descriptor with
+ * exactly the semantics of extraction_context.cpp:49-205. Returns -1 where the reference returns -1. */
+int pnn_make_tb_desc(pnn_tb_dev* out, int64_t origin, int32_t stride, const uint8_t* neighbor_flags,
+                     int n_avail, int above_units, int left_units);
+
+/* Batched gather only: Pel plane (pel_bytes 4 = HM `Pel`/int32, 1 = uint8 image) -> mean-subtracted,
+ * masked float portions. For FC layouts pass d_left = d_above + 3w^2 and both pitches = 5w^2. */
+int pnn_gather_device(pnn_ctx* ctx, int width, int unit, const void* d_plane, int pel_bytes,
+                      const pnn_tb_dev* d_tbs, int n, float* d_above, long pitch_above, float* d_left,
+                      long pitch_left, void* stream);
+
+/* The whole hot path for n TBs of one width: gather -> net -> (+mean, clamp, round) -> int32 [n][w][w]
+ * (and, when d_out_f32 != NULL, the raw float prediction as the frozen graph returns it). */
+int pnn_predict_tbs_device(pnn_ctx* ctx, int width, const void* d_plane, int pel_bytes, const pnn_tb_dev* d_tbs,
+                           int n, int32_t* d_dst, float* d_out_f32, void* stream);
+
+/* Per-launch accounting of the last *_device call (for bench.py's roofline object): number of tap-GEMM
+ * launches and their algorithmic FLOPs (2 * M * K * N summed, padding excluded). */
+int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_flops, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNN_HIP_H */

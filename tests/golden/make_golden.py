@@ -1,0 +1,155 @@
+"""Generates the committed golden fixtures. Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What it records (data only -- inputs and expected outputs; no reference source text):
+  gather_ref.npz      outputs of the REFERENCE's own extract_context_portions (compiled into oracle/_ref by
+                      oracle/Makefile) on the ramp scenarios of hevc/hm_common/c++/source_test/tests.cpp:248-644
+                      and on seeded random planes / flag patterns (incl. patterns with holes).
+  gather_python.npz   outputs of sets/common.py (imported from /root/reference) for rectangular masks.
+  conv4_single.pnnw, conv8_single.pnnw
+                      the two complete trained checkpoints of the reference (pnn/results/width_target_{4,8}/
+                      convolutional/single/...), variables only, converted to the flat .pnnw format.
+  nets.npz            seeded inputs and outputs of the CPU oracle for every architecture, after the oracle
+                      was checked here against the independent PyTorch formulation (tests/torch_formulation.py),
+                      plus real-weight outputs for conv4 / conv8.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from context_adaptive_neural_network_based_prediction_amd import weights as wts  # noqa: E402
+from oracle import pnn_oracle as O  # noqa: E402
+from tests import util  # noqa: E402
+
+REF = "/root/reference"
+
+
+def ramp_scenarios():
+    """tests.cpp:248-644: decoded[i] = i; (w=4,8: 32x40 plane, TB at column 12, row 10), (w=16: 56x60, (18, 20));
+    flags: all / bottom-most below-left unit(s) missing / right-most above-right unit missing; mean 0."""
+    out = []
+    for w in (4, 8, 16):
+        h, stride, x, y = (32, 40, 12, 10) if w <= 8 else (56, 60, 18, 20)
+        plane = np.arange(h * stride, dtype=np.int32).reshape(h, stride)
+        units = 2 * w // 4
+        f_all = np.ones(2 * units + 1, np.uint8)
+        f_left = f_all.copy()
+        f_left[:1 if w <= 8 else 2] = 0
+        f_right = f_all.copy()
+        f_right[-1] = 0
+        for name, f in (("all", f_all), ("below_left_missing", f_left), ("above_right_missing", f_right)):
+            out.append((w, plane, x, y, f, 0.0, name))
+    return out
+
+
+def gen_gather_ref():
+    assert O.ref_lib() is not None, "oracle/_ref/libref_extract.so was not built"
+    rec = {}
+    k = 0
+    for w, plane, x, y, f, mean, name in ramp_scenarios():
+        rc, a, l = O.extract_context(plane, x, y, w, f, mean, use_ref=True)
+        assert rc == 0
+        rec.update({"c%d_w" % k: w, "c%d_plane" % k: plane, "c%d_xy" % k: np.array([x, y]), "c%d_flags" % k: f,
+                    "c%d_mean" % k: np.float32(mean), "c%d_above" % k: a, "c%d_left" % k: l})
+        k += 1
+    rng = np.random.RandomState(1234)
+    for j in range(64):
+        w = int(rng.choice([4, 8, 16, 32, 64]))
+        plane = util.make_plane(3 * w + 8, 3 * w + 12, seed=5000 + j)
+        xs, ys, flags = util.make_tbs(plane.shape[0], plane.shape[1], w, 1, seed=6000 + j, partial_fraction=0.8,
+                                      holes=bool(j % 3 == 0))
+        rc, a, l = O.extract_context(plane, int(xs[0]), int(ys[0]), w, flags[0], util.MEAN, use_ref=True)
+        assert rc == 0
+        rec.update({"c%d_w" % k: w, "c%d_plane" % k: plane.astype(np.uint8), "c%d_xy" % k: np.array([xs[0], ys[0]]),
+                    "c%d_flags" % k: flags[0], "c%d_mean" % k: np.float32(util.MEAN), "c%d_above" % k: a, "c%d_left" % k: l})
+        k += 1
+    rec["n_cases"] = k
+    np.savez_compressed(os.path.join(HERE, "gather_ref.npz"), **rec)
+    print("gather_ref.npz: %d cases" % k)
+
+
+def gen_gather_python():
+    sys.path.insert(0, REF)
+    import sets.common as sc  # the reference's numpy implementation
+    rng = np.random.RandomState(7)
+    img = rng.randint(0, 256, (2, 96, 96, 1)).astype(np.uint8)
+    rec = {"images": img}
+    k = 0
+    for w in (4, 8, 16):
+        rows = np.array([0, 4, 96 - 3 * w], dtype=np.int32)
+        cols = np.array([8, 0, 96 - 3 * w], dtype=np.int32)
+        for masks in ((0, 0), (w, 0), (0, w), (4, min(8, w))):
+            for is_fc in (True, False):
+                res = sc.extract_context_portions_targets_from_channels_plus_preprocessing(
+                    img, w, rows, cols, util.MEAN, masks, is_fc)
+                rec["k%d_meta" % k] = np.array([w, masks[0], masks[1], int(is_fc)])
+                rec["k%d_rows" % k] = rows
+                rec["k%d_cols" % k] = cols
+                for i, r in enumerate(res):
+                    rec["k%d_out%d" % (k, i)] = r.astype(np.float32)
+                k += 1
+    rec["n_cases"] = k
+    np.savez_compressed(os.path.join(HERE, "gather_python.npz"), **rec)
+    print("gather_python.npz: %d cases" % k)
+
+
+def gen_real_weights():
+    for w in (4, 8):
+        pre = "%s/pnn/results/width_target_%d/convolutional/single/luminance/1_0/masks_tr_random/model_800000.ckpt" % (REF, w)
+        flat = wts.params_from_tf_bundle(pre, w, False)
+        wts.save_pnnw(os.path.join(HERE, "conv%d_single.pnnw" % w), flat, w, False)
+        print("conv%d_single.pnnw: %d params" % (w, flat.size))
+
+
+def gen_nets():
+    from tests import torch_formulation as tf_
+    rec = {}
+    for is_fc, w in [(True, 4), (True, 8), (True, 16), (False, 4), (False, 8), (False, 16), (False, 32), (False, 64)]:
+        seed = 100 + w + (1000 if is_fc else 0)
+        n = 8 if w < 64 else 2
+        params = util.make_params(w, is_fc, seed, out_gain=25.0)
+        above, left = util.make_contexts(w, n, seed + 1)
+        if is_fc:
+            out = O.fc_forward(params, w, util.flatten_fc(above, left))
+            ref = tf_.fc_forward(params, w, util.flatten_fc(above, left))
+        else:
+            out = O.conv_forward(params, w, above, left)
+            ref = tf_.conv_forward(params, w, above, left)
+        err = np.abs(out - ref).max()
+        assert err <= 1e-3, (is_fc, w, err)
+        tag = "%s%d" % ("fc" if is_fc else "conv", w)
+        rec[tag + "_seed"] = seed
+        rec[tag + "_n"] = n
+        rec[tag + "_out"] = out
+        print("%s: oracle vs torch max |delta| = %.2e, out range [%.1f, %.1f]" % (tag, err, out.min(), out.max()))
+    # real weights: 8 smooth natural-like contexts cut from a synthetic plane
+    for w in (4, 8):
+        flat, _, _ = wts.load_pnnw(os.path.join(HERE, "conv%d_single.pnnw" % w))
+        plane = util.make_plane(64, 96, seed=77 + w)
+        xs, ys, flags = util.make_tbs(64, 96, w, 8, seed=88 + w, partial_fraction=0.5)
+        ab = np.zeros((8, w, 3 * w), np.float32)
+        lf = np.zeros((8, 2 * w, w), np.float32)
+        for i in range(8):
+            _, ab[i], lf[i] = O.extract_context(plane, int(xs[i]), int(ys[i]), w, flags[i], util.MEAN)
+        out = O.conv_forward(flat, w, ab, lf)
+        ref = tf_.conv_forward(flat, w, ab, lf)
+        assert np.abs(out - ref).max() <= 1e-3
+        rec["real%d_above" % w] = ab
+        rec["real%d_left" % w] = lf
+        rec["real%d_out" % w] = out
+        print("real conv%d: out range [%.1f, %.1f]" % (w, out.min() + util.MEAN, out.max() + util.MEAN))
+    np.savez_compressed(os.path.join(HERE, "nets.npz"), **rec)
+
+
+if __name__ == "__main__":
+    O.build()
+    gen_gather_ref()
+    gen_gather_python()
+    gen_real_weights()
+    gen_nets()
