@@ -162,7 +162,7 @@ int build_fc_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int K, 
     TapGemmParams& p = L->proto;
     p.SH = p.SW = p.IH = p.IW = p.OH = p.OW = 1;
     p.a = 1; p.os = 1; p.Cin = K; p.Cout = N; p.Npad = npad; p.act = act;
-    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.py[0] = p.px[0] = 0; p.dy[0] = p.dx[0] = 0;
+    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.py[0] = p.px[0] = 0; p.tap[0] = pack_tap(0, 0);
     L->k_total = K; L->out_per_block = N;
     return PNN_OK;
 }
@@ -189,7 +189,7 @@ int build_conv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int I
     p.OH = OH; p.OW = OW; p.Cout = Cout; p.os = 1; p.Npad = npad; p.act = 1;
     p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = k * k; p.py[0] = p.px[0] = 0;
     for (int ky = 0; ky < k; ky++)
-        for (int kx = 0; kx < k; kx++) { p.dy[ky * k + kx] = (int8_t)(ky - pad); p.dx[ky * k + kx] = (int8_t)(kx - pad); }
+        for (int kx = 0; kx < k; kx++) p.tap[ky * k + kx] = pack_tap(ky - pad, kx - pad);
     L->k_total = (double)K; L->out_per_block = (long)OH * OW * Cout;
     return PNN_OK;
 }
@@ -214,8 +214,7 @@ int build_tconv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int 
                 if ((py + pad - ky) % s) continue;   // C++ % keeps the sign; parity test is sign-safe
                 for (int kx = 0; kx < k; kx++) {
                     if ((px + pad - kx) % s) continue;
-                    p.dy[ntap] = (int8_t)((py + pad - ky) / s);
-                    p.dx[ntap] = (int8_t)((px + pad - kx) / s);
+                    p.tap[ntap] = pack_tap((py + pad - ky) / s, (px + pad - kx) / s);
                     const float* wt = W + (size_t)(ky * k + kx) * Cout * Cin;
                     for (int ci = 0; ci < Cin; ci++)
                         for (int co = 0; co < Cout; co++) kn.push_back(wt[(size_t)co * Cin + ci]);
@@ -376,6 +375,9 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     const long M = nblocks * p.SH * p.SW;
     if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
     p.M = (int)M;
+    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
+    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation tensor of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
+    p.x_bytes = (unsigned)xb;
     const int cfg = choose_cfg(c, M, p.Cout, p.ncls);
     HIPCHK(c, launch_tapgemm(p, cfg, s));
     c->stat_gemm_launches++; c->stat_launches++;
@@ -385,9 +387,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
 
 long chunk_blocks(const pnn_ctx* c, const Model* m)
 {
-    if (c->opt_max_chunk > 0) return c->opt_max_chunk;
     const double per_block = 4.0 * (m->is_fc ? 2.0 * kHidden : 2.0 * m->pmax + 80.0 * m->C);
-    long n = (long)((double)c->ws_cap_bytes / per_block);
+    long n = c->opt_max_chunk > 0 ? c->opt_max_chunk : (long)((double)c->ws_cap_bytes / per_block);
+    // every activation tensor of a pass must stay below the 2 GiB bound of a buffer descriptor
+    const double biggest = 4.0 * std::max((double)m->pmax, 5.0 * m->width * m->width);
+    n = std::min(n, (long)(2147483000.0 / biggest));
     return std::max(1L, std::min(n, 1L << 20));
 }
 
@@ -698,7 +702,7 @@ int pnn_predict_fc_device(pnn_ctx* c, int width, const float* d_ctx, int n, floa
     if (n < 0 || (n > 0 && (!d_ctx || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
     reset_stats(c);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     return run_net(c, m, d_ctx, 5L * width * width, nullptr, 0, n, d_out, nullptr, s);
 }
 
@@ -710,7 +714,7 @@ int pnn_predict_conv_device(pnn_ctx* c, int width, const float* d_above, const f
     if (n < 0 || (n > 0 && (!d_above || !d_left || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
     reset_stats(c);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     return run_net(c, m, d_above, 3L * width * width, d_left, 2L * width * width, n, d_out, nullptr, s);
 }
 
@@ -749,7 +753,7 @@ int pnn_gather_device(pnn_ctx* c, int width, int unit, const void* d_plane, int 
     GatherParams g;
     g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs); g.N = n; g.w = width;
     g.unit = unit; g.mean = c->mean; g.above = d_above; g.left = d_left; g.pitch_above = pitch_above; g.pitch_left = pitch_left;
-    HIPCHK(c, launch_gather(g, stream ? (hipStream_t)stream : c->stream));
+    HIPCHK(c, launch_gather(g, (hipStream_t)stream));
     return PNN_OK;
 }
 
@@ -762,7 +766,7 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
     if (n < 0 || (n > 0 && (!d_plane || !d_tbs || (!d_dst && !d_out_f32)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
     reset_stats(c);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     const long w2 = (long)width * width;
     const long chunk = std::min((long)n, chunk_blocks(c, m));
     if ((rc = dev_reserve(c, c->stage_in[0], (size_t)chunk * 5 * w2 * 4))) return rc;

@@ -23,6 +23,7 @@ struct TapGemmParams {
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
     int32_t* Yi;       // optional fused HM epilogue: (int) round(clamp(v + mean, 0, 255))
+    unsigned x_bytes;  // size of X in bytes (< 2^31): bound of the activation buffer descriptor
     int M, SH, SW;
     int IH, IW, Cin, a;
     int OH, OW, Cout, os;
@@ -32,8 +33,9 @@ struct TapGemmParams {
     int ncls;
     int tap_begin[kMaxClasses + 1];
     int py[kMaxClasses], px[kMaxClasses];
-    int8_t dy[kMaxTaps], dx[kMaxTaps];
+    int tap[kMaxTaps];   // (dy << 16) | (dx & 0xffff): one scalar load per tap
 };
+inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
 struct TileCfg { int rt, nt; };

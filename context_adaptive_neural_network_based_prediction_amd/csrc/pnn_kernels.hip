@@ -78,64 +78,103 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto load_a = [&](int t, int cc, f32x4 (&dst)[RT]) {
-        const int dy = p.dy[t], dx = p.dx[t];
+    // Activation loads go through a buffer descriptor: an out-of-image tap (or a row past M) gets an
+    // offset beyond num_records and the hardware returns zeros -- no branch, no select, and therefore no
+    // s_waitcnt inside the loop other than the ones the prefetch distance calls for.  The per-lane byte
+    // offset is computed once per TAP (aoff); the 16-channel chunk inside the tap rides in the scalar
+    // offset, which the range check ignores.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+    unsigned aoff[RT];
+    auto tap_setup = [&](int tp) {                  // tp = (dy << 16) | (dx & 0xffff)
+        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
             const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
             const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-            const float* src = p.X + (((size_t)pb[rt] * p.IH + iy) * p.IW + ix) * p.Cin + (cc << 4) + (q << 2);
-            dst[rt] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const unsigned off = ((unsigned)((pb[rt] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin + (q << 2)) << 2;
+            aoff[rt] = ok ? off : 0x80000000u;
         }
     };
+    auto load_a = [&](int cc, f32x4 (&dst)[RT]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            dst[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt], cc << 6, 0));
+    };
+    const f32x4* bsrc[NLD];                        // this thread's slots of a staged weight chunk
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+        int e = tid + 256 * r;
+        if (E % 256 != 0) e = e < E ? e : E - 1;
+        const int qq = e / BN, nn = e - qq * BN;
+        bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+    }
+    const size_t bstride = (size_t)4 * p.Npad;      // float4 per 16-deep chunk
     auto load_b = [&](int chunk, f32x4 (&dst)[NLD]) {
 #pragma unroll
-        for (int r = 0; r < NLD; r++) {
-            const int e = tid + 256 * r;
-            if (E % 256 == 0 || e < E) {
-                const int qq = e / BN, nn = e - qq * BN;
-                dst[r] = Wg[((size_t)chunk * 4 + qq) * p.Npad + n0 + nn];
-            }
-        }
+        for (int r = 0; r < NLD; r++) dst[r] = bsrc[r][(size_t)chunk * bstride];
     };
     auto store_b = [&](int buf, const f32x4 (&src)[NLD]) {
 #pragma unroll
         for (int r = 0; r < NLD; r++) {
-            const int e = tid + 256 * r;
-            if (E % 256 == 0 || e < E) Bs[buf][e] = src[r];
+            // Threads past the end re-store element E-1 with the value they re-loaded for it: a benign
+            // duplicate instead of an exec-masked store (whose conditional vmcnt wait the compiler would
+            // otherwise have to repeat, conservatively, in front of the next chunk's MFMAs).
+            int e = tid + 256 * r;
+            if (E % 256 != 0) e = e < E ? e : E - 1;
+            Bs[buf][e] = src[r];
         }
     };
 
+    // Two-stage software pipeline, one barrier per 16-deep chunk.  Order inside an iteration (pinned with
+    // sched_barrier, the compiler otherwise sinks the prefetch below the MFMAs):
+    //   LDS fragment reads of chunk c -> issue the global prefetch of chunk c+1 (their address math hides
+    //   the LDS latency) -> first half of the MFMAs -> write the staged weights to the other LDS buffer ->
+    //   second half of the MFMAs (hides the LDS write) -> barrier.
+    // The body has no exec-masked code: the last iteration re-fetches the last chunk instead of testing.
     f32x4 a_cur[RT], a_nxt[RT], b_stage[NLD];
     int t = t0, cc = 0;
-    load_a(t, cc, a_cur);
+    tap_setup(p.tap[t0]);
+    int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];  // the NEXT tap's word, fetched a whole tap early
+    load_a(0, a_cur);
     load_b(0, b_stage);
     store_b(0, b_stage);
     __syncthreads();
-
     for (int c = 0; c < nchunks; c++) {
-        const bool more = c + 1 < nchunks;
-        if (more) {
-            if (++cc == cpt) { cc = 0; ++t; }
-            load_a(t, cc, a_nxt);
-            load_b(c + 1, b_stage);
-        }
         const int buf = c & 1;
         f32x4 bf[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) bf[nt] = Bs[buf][q * BN + nt * 16 + l15];
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = c + 1 < nchunks;
+        if (more && ++cc == cpt) {                  // wave-uniform: next chunk starts the next tap
+            cc = 0;
+            ++t;
+            tap_setup(tp_next);
+            tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
+        }
+        load_a(cc, a_nxt);
+        load_b(more ? c + 1 : c, b_stage);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+        for (int e = 0; e < 2; e++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
                     acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a_cur[rt][e], acc[rt][nt], 0, 0, 0);
-        if (more) {
-            store_b(buf ^ 1, b_stage);
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(buf ^ 1, b_stage);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) a_cur[rt] = a_nxt[rt];
-        }
+        for (int e = 2; e < 4; e++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a_cur[rt][e], acc[rt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) a_cur[rt] = a_nxt[rt];
         __syncthreads();
     }
 

@@ -90,8 +90,8 @@ int pnn_parse_model_table(const char* path, int* widths, int* is_pair, int* chan
 
 /* ---- device-resident entry points (batched path, asynchronous on `stream`) --------------------------- */
 
-/* All pointers are device pointers on the context's device; `stream` is a hipStream_t (NULL = the
- * context's own stream). Calls only enqueue work; the caller synchronises. */
+/* All pointers are device pointers on the context's device; `stream` is a hipStream_t (NULL = HIP's
+ * default stream, as everywhere in HIP). Calls only enqueue work; the caller synchronises. */
 int pnn_predict_fc_device(pnn_ctx* ctx, int width, const float* d_context, int n, float* d_out, void* stream);
 int pnn_predict_conv_device(pnn_ctx* ctx, int width, const float* d_above, const float* d_left, int n,
                             float* d_out, void* stream);
