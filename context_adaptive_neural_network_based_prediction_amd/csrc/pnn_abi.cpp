@@ -144,27 +144,54 @@ std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad
     return out;
 }
 
-int npad_for(int cout) { return ((cout + 15) / 16) * 16 + 128; }
+int npad_for(int cout) { return ((cout + 15) / 16) * 16 + 160; }   // slack >= the widest column tile (BN = 160)
+
+// Common tail of the three layer builders. `kn` holds the [K][Cout] rows ordered (class, tap, ci) and
+// p.tap_begin / p.Cin / p.ncls are set. Every class is zero-padded to a multiple of kChunkPad 16-deep
+// chunks (so that any pipeline stage depth KC <= kChunkPad reads whole stages), packed and uploaded.
+int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const float* b, int Cout, GemmLayer* L)
+{
+    TapGemmParams& p = L->proto;
+    const int cpt = p.Cin / 16;
+    std::vector<float> padded;
+    long chunk = 0;
+    double k_real = 0;
+    for (int cls = 0; cls < p.ncls; cls++) {
+        p.chunk_begin[cls] = (int)chunk;
+        const long rows = (long)(p.tap_begin[cls + 1] - p.tap_begin[cls]) * p.Cin;
+        const long nch = rows / 16, nch_pad = ((nch + kChunkPad - 1) / kChunkPad) * kChunkPad;
+        const float* src = kn.data() + (size_t)p.tap_begin[cls] * p.Cin * Cout;
+        padded.insert(padded.end(), src, src + (size_t)rows * Cout);
+        padded.resize(padded.size() + (size_t)(nch_pad - nch) * 16 * Cout, 0.f);
+        chunk += nch_pad;
+        k_real += (double)rows;
+    }
+    p.chunk_begin[p.ncls] = (int)chunk;
+    (void)cpt;
+    const int npad = npad_for(Cout);
+    std::vector<float> packed = pack_kn(padded, chunk * 16, Cout, npad);
+    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
+    if (rc) return rc;
+    std::vector<float> bias(((Cout + 3) / 4) * 4 + 4, 0.f);
+    std::copy(b, b + Cout, bias.begin());
+    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
+    if (rc) return rc;
+    p.Cout = Cout; p.Npad = npad;
+    L->k_total = k_real;
+    return PNN_OK;
+}
 
 // Fully-connected layer as a one-tap GEMM (pnn/components.py:169-176).
 int build_fc_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int K, int N, int act, GemmLayer* L)
 {
     if (K % 16) return fail(c, PNN_E_MODEL, "FC input size %d is not a multiple of 16", K);
     std::vector<float> kn(W, W + (size_t)K * N);
-    const int npad = npad_for(N);
-    std::vector<float> packed = pack_kn(kn, K, N, npad);
-    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
-    if (rc) return rc;
-    std::vector<float> bias(((N + 3) / 4) * 4 + 4, 0.f);
-    std::copy(b, b + N, bias.begin());
-    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
-    if (rc) return rc;
     TapGemmParams& p = L->proto;
     p.SH = p.SW = p.IH = p.IW = p.OH = p.OW = 1;
-    p.a = 1; p.os = 1; p.Cin = K; p.Cout = N; p.Npad = npad; p.act = act;
+    p.a = 1; p.os = 1; p.Cin = K; p.act = act;
     p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.py[0] = p.px[0] = 0; p.tap[0] = pack_tap(0, 0);
-    L->k_total = K; L->out_per_block = N;
-    return PNN_OK;
+    L->out_per_block = N;
+    return finish_gemm_layer(c, m, kn, b, N, L);
 }
 
 // Forward convolution (pnn/tfutils.py:75-139). W is [k][k][Cin][Cout].
@@ -176,22 +203,14 @@ int build_conv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int I
     if (Cin % 16 || Cout % 4) return fail(c, PNN_E_MODEL, "conv layer %d->%d not MFMA-tileable", Cin, Cout);
     const long K = (long)k * k * Cin;
     std::vector<float> kn(W, W + (size_t)K * Cout);
-    const int npad = npad_for(Cout);
-    std::vector<float> packed = pack_kn(kn, K, Cout, npad);
-    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
-    if (rc) return rc;
-    std::vector<float> bias(Cout + 4, 0.f);
-    std::copy(b, b + Cout, bias.begin());
-    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
-    if (rc) return rc;
     TapGemmParams& p = L->proto;
     p.SH = OH; p.SW = OW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = s;
-    p.OH = OH; p.OW = OW; p.Cout = Cout; p.os = 1; p.Npad = npad; p.act = 1;
+    p.OH = OH; p.OW = OW; p.os = 1; p.act = 1;
     p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = k * k; p.py[0] = p.px[0] = 0;
     for (int ky = 0; ky < k; ky++)
         for (int kx = 0; kx < k; kx++) p.tap[ky * k + kx] = pack_tap(ky - pad, kx - pad);
-    L->k_total = (double)K; L->out_per_block = (long)OH * OW * Cout;
-    return PNN_OK;
+    L->out_per_block = (long)OH * OW * Cout;
+    return finish_gemm_layer(c, m, kn, b, Cout, L);
 }
 
 // Transposed convolution with Cout >= 4 (Appendix B.3; pnn/tfutils.py:395-462). W is [k][k][Cout][Cin].
@@ -223,19 +242,10 @@ int build_tconv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int 
             }
         }
     p.tap_begin[p.ncls] = ntap;
-    const long K = (long)ntap * Cin;
-    const int npad = npad_for(Cout);
-    std::vector<float> packed = pack_kn(kn, K, Cout, npad);
-    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
-    if (rc) return rc;
-    std::vector<float> bias(Cout + 4, 0.f);
-    std::copy(b, b + Cout, bias.begin());
-    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
-    if (rc) return rc;
     p.SH = IH; p.SW = IW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = 1;
-    p.OH = OH; p.OW = OW; p.Cout = Cout; p.os = s; p.Npad = npad; p.act = act;
-    L->k_total = (double)K; L->out_per_block = (long)OH * OW * Cout;
-    return PNN_OK;
+    p.OH = OH; p.OW = OW; p.os = s; p.act = act;
+    L->out_per_block = (long)OH * OW * Cout;
+    return finish_gemm_layer(c, m, kn, b, Cout, L);
 }
 
 void free_model(Model* m)
@@ -350,22 +360,37 @@ int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n,
     return PNN_OK;
 }
 
-// Tile choice: fewest "rounds x tile area", with a penalty for small tiles (less operand reuse).
-int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls)
+// Tile / pipeline choice. Rules distilled from on-device sweeps over every kernel configuration
+// (tools_cfg_sweep.sh; all shapes of the FC-8 and conv-16 nets): once the grid fills the chip every
+// reasonable tile lands within ~3 % (the f32 matrix pipes run at ~1.9 GHz under this load and are
+// ~82 % busy), so the choice only has to (a) avoid column padding, (b) keep >= 2-3 workgroups per CU,
+// and (c) switch to the split-K kernel when M is too small to fill 256 CUs with 64-row tiles.
+int find_cfg(int rt, int nt, int kc, int mf)
 {
-    if (c->opt_tile_cfg >= 0 && c->opt_tile_cfg < tapgemm_num_cfgs()) return (int)c->opt_tile_cfg;
-    int best = 0;
-    double best_cost = 1e300;
     for (int i = 0; i < tapgemm_num_cfgs(); i++) {
         const TileCfg t = tapgemm_cfg(i);
-        const long bm = 64L * t.rt, bn = 16L * t.nt;
-        const long wgs = ((M + bm - 1) / bm) * ((cout + bn - 1) / bn) * ncls;
-        const long slots = 256L * 2;                  // two workgroups per CU share its matrix pipes
-        const long rounds = (wgs + slots - 1) / slots;
-        const double cost = (double)rounds * 2.0 * bm * bn * (1.0 + 0.5 / t.nt + 0.15 / t.rt);
-        if (cost < best_cost) { best_cost = cost; best = i; }
+        if (t.rt == rt && t.nt == nt && t.kc == kc && t.mf == mf) return i;
     }
-    return best;
+    return -1;
+}
+
+int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
+{
+    if (c->opt_tile_cfg >= 0 && c->opt_tile_cfg < tapgemm_num_cfgs()) return (int)c->opt_tile_cfg;
+    const int cpt = cin / 16;
+    const bool one_tap = (k_total == (double)cin);
+    const int kc = (one_tap || cpt % 2 == 0) ? 2 : 1;             // a stage must not straddle two taps
+    int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : ((cout % 128 == 0 && M >= 32768) ? 8 : 4));
+    const long wgs_std = ((M + 63) / 64) * ((cout + 16L * nt - 1) / (16L * nt)) * ncls;
+    if (wgs_std < 192) {                                          // small M: four waves split K instead
+        int nts = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
+        while (nts > 1 && ((M + 15) / 16) * ((cout + 16L * nts - 1) / (16L * nts)) * ncls < 128) nts >>= 1;
+        const int i = find_cfg(0, nts, 1, 16);
+        if (i >= 0) return i;
+    }
+    int i = find_cfg(1, nt, kc, 16);
+    if (i < 0) i = find_cfg(1, nt, 1, 16);
+    return i < 0 ? 0 : i;
 }
 
 int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s)
@@ -378,8 +403,33 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
     if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation tensor of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
     p.x_bytes = (unsigned)xb;
-    const int cfg = choose_cfg(c, M, p.Cout, p.ncls);
-    HIPCHK(c, launch_tapgemm(p, cfg, s));
+    const int cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    static const bool debug = getenv("PNN_DEBUG") != nullptr;
+    if (debug) {
+        const TileCfg t = tapgemm_cfg(cfg);
+        fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls,
+                cfg, t.rt, t.nt, t.kc);
+    }
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch HIP-event timing
+    if (profile) {
+        hipEvent_t e0, e1;
+        HIPCHK(c, hipEventCreate(&e0));
+        HIPCHK(c, hipEventCreate(&e1));
+        HIPCHK(c, hipEventRecord(e0, s));
+        HIPCHK(c, launch_tapgemm(p, cfg, s));
+        HIPCHK(c, hipEventRecord(e1, s));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        const TileCfg t = tapgemm_cfg(cfg);
+        const double fl = 2.0 * (double)M * L.k_total * p.Cout;
+        fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, fl / (ms * 1e-3) / 1e12);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    } else {
+        HIPCHK(c, launch_tapgemm(p, cfg, s));
+    }
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
     return PNN_OK;

@@ -32,13 +32,18 @@ struct TapGemmParams {
     float mean;
     int ncls;
     int tap_begin[kMaxClasses + 1];
+    int chunk_begin[kMaxClasses + 1];   // first packed 16-deep chunk of each class (classes padded to kChunkPad)
     int py[kMaxClasses], px[kMaxClasses];
     int tap[kMaxTaps];   // (dy << 16) | (dx & 0xffff): one scalar load per tap
 };
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
-struct TileCfg { int rt, nt; };
+constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
+struct TileCfg { int rt, nt, kc, mf; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
+int tapgemm32_num_cfgs();
+TileCfg tapgemm32_cfg(int idx);
+hipError_t launch_tapgemm32(const TapGemmParams& p, int idx, hipStream_t s);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);

@@ -12,21 +12,10 @@
 // workgroup in the pre-packed order the MFMA lane groups consume; activations are gathered straight
 // into registers (NHWC keeps a pixel's channels contiguous: 64 B per lane group).
 #include "pnn_kernels.h"
+#include "pnn_device_common.h"
+#include <cstdlib>
 
 namespace pnn {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float leaky(float v) { return fmaxf(0.1f * v, v); }   // pnn/tfutils.py:192
-
-// TComPrediction.cpp:632: (int) std::round(max(0, min(255, p + mean))), half away from zero.
-__device__ __forceinline__ int hm_round(float p, float mean)
-{
-    float v = p + mean;
-    v = fminf(v, 255.f);
-    v = fmaxf(v, 0.f);
-    return (int)roundf(v);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Tap GEMM on f32 MFMA.
@@ -35,15 +24,17 @@ __device__ __forceinline__ int hm_round(float p, float mean)
 //   MFMA operand roles: "A" = weights (i = n), "B" = activations (j = m); lane l = (l&15, q = l>>4)
 //   supplies k = 4q + e in step e of a 16-deep chunk, for both operands.  D: lane holds column
 //   m = l&15, rows n = 4q + r  ->  one float4 store of 4 consecutive output channels.
+//   A pipeline stage is KC chunks (16*KC deep): one barrier per stage, and the global prefetch of
+//   stage s+1 has the whole MFMA time of stage s (KC * RT * NT * 128 cycles) to land.
 // ------------------------------------------------------------------------------------------------
-template <int RT, int NT>
+template <int RT, int NT, int KC>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 {
     constexpr int BM = 64 * RT;
     constexpr int BN = 16 * NT;
     constexpr int E = 4 * BN;                       // float4 per staged weight chunk
     constexpr int NLD = (E + 255) / 256;
-    __shared__ f32x4 Bs[2][E];
+    __shared__ f32x4 Bs[2][KC][E];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,10 +58,11 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
         pj[rt] = r - pi[rt] * p.SW;
     }
 
-    const int cpt = p.Cin >> 4;                     // 16-deep chunks per tap
+    const int cpt = p.Cin >> 4;                     // 16-deep chunks per tap (a multiple of KC, or one tap)
     const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
     const int nchunks = (t1 - t0) * cpt;
-    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)t0 * cpt * 4 * p.Npad;
+    const int nstages = (nchunks + KC - 1) / KC;    // the packed weights are zero-padded to whole stages
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
 
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -95,43 +87,61 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
             aoff[rt] = ok ? off : 0x80000000u;
         }
     };
-    auto load_a = [&](int cc, f32x4 (&dst)[RT]) {
+    auto load_a = [&](int cc, f32x4 (&dst)[KC][RT]) {
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-            dst[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt], cc << 6, 0));
+        for (int j = 0; j < KC; j++) {
+            const int cj = cc + j < cpt ? cc + j : cpt - 1;   // padding chunk: its weights are zero, any finite data will do
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+                dst[j][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt], cj << 6, 0));
+        }
     };
-    const f32x4* bsrc[NLD];                        // this thread's slots of a staged weight chunk
+    const f32x4* bsrc[NLD];                         // this thread's slots of a staged weight chunk
+    int bdst[NLD];
 #pragma unroll
     for (int r = 0; r < NLD; r++) {
+        // Threads past the end re-load / re-store element E-1: a benign duplicate instead of exec-masked
+        // code (whose conditional vmcnt wait the compiler would repeat in front of the next MFMAs).
         int e = tid + 256 * r;
         if (E % 256 != 0) e = e < E ? e : E - 1;
         const int qq = e / BN, nn = e - qq * BN;
         bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+        bdst[r] = e;
     }
     const size_t bstride = (size_t)4 * p.Npad;      // float4 per 16-deep chunk
-    auto load_b = [&](int chunk, f32x4 (&dst)[NLD]) {
+    auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
 #pragma unroll
-        for (int r = 0; r < NLD; r++) dst[r] = bsrc[r][(size_t)chunk * bstride];
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) dst[j][r] = bsrc[r][(size_t)(stage * KC + j) * bstride];
     };
-    auto store_b = [&](int buf, const f32x4 (&src)[NLD]) {
+    auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
 #pragma unroll
-        for (int r = 0; r < NLD; r++) {
-            // Threads past the end re-store element E-1 with the value they re-loaded for it: a benign
-            // duplicate instead of an exec-masked store (whose conditional vmcnt wait the compiler would
-            // otherwise have to repeat, conservatively, in front of the next chunk's MFMAs).
-            int e = tid + 256 * r;
-            if (E % 256 != 0) e = e < E ? e : E - 1;
-            Bs[buf][e] = src[r];
-        }
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) Bs[buf][j][bdst[r]] = src[j][r];
+    };
+    auto read_bf = [&](int buf, int j, f32x4 (&bf)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bf[nt] = Bs[buf][j][q * BN + nt * 16 + l15];
+    };
+    auto mfma_chunk = [&](const f32x4 (&bf)[NT], const f32x4 (&a)[RT], int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; e++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a[rt][e], acc[rt][nt], 0, 0, 0);
     };
 
-    // Two-stage software pipeline, one barrier per 16-deep chunk.  Order inside an iteration (pinned with
-    // sched_barrier, the compiler otherwise sinks the prefetch below the MFMAs):
-    //   LDS fragment reads of chunk c -> issue the global prefetch of chunk c+1 (their address math hides
-    //   the LDS latency) -> first half of the MFMAs -> write the staged weights to the other LDS buffer ->
-    //   second half of the MFMAs (hides the LDS write) -> barrier.
-    // The body has no exec-masked code: the last iteration re-fetches the last chunk instead of testing.
-    f32x4 a_cur[RT], a_nxt[RT], b_stage[NLD];
+    // Two-stage software pipeline.  Order inside an iteration (pinned with sched_barrier, the compiler
+    // otherwise sinks the prefetch below the MFMAs):
+    //   LDS fragment reads of the stage's first chunk -> issue the global prefetch of stage s+1 (its
+    //   address math hides the LDS latency) -> MFMAs of all chunks but half of the last -> write the
+    //   staged weights to the other LDS buffer -> the remaining MFMAs (hide the LDS write) -> barrier.
+    // The body has no exec-masked code: the last iteration re-fetches the last stage instead of testing.
+    f32x4 a_cur[KC][RT], a_nxt[KC][RT], b_stage[KC][NLD];
     int t = t0, cc = 0;
     tap_setup(p.tap[t0]);
     int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];  // the NEXT tap's word, fetched a whole tap early
@@ -139,42 +149,39 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
     load_b(0, b_stage);
     store_b(0, b_stage);
     __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
-        f32x4 bf[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) bf[nt] = Bs[buf][q * BN + nt * 16 + l15];
+    for (int s = 0; s < nstages; s++) {
+        const int buf = s & 1;
+        f32x4 bf0[NT], bf1[NT];
+        read_bf(buf, 0, bf0);
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = c + 1 < nchunks;
-        if (more && ++cc == cpt) {                  // wave-uniform: next chunk starts the next tap
-            cc = 0;
-            ++t;
-            tap_setup(tp_next);
-            tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
+        const bool more = s + 1 < nstages;
+        if (more) {
+            cc += KC;
+            if (cc >= cpt) {                        // wave-uniform: the next stage starts the next tap
+                cc = 0;
+                ++t;
+                tap_setup(tp_next);
+                tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
+            }
         }
         load_a(cc, a_nxt);
-        load_b(more ? c + 1 : c, b_stage);
+        load_b(more ? s + 1 : s, b_stage);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 2; e++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a_cur[rt][e], acc[rt][nt], 0, 0, 0);
+        for (int j = 0; j + 1 < KC; j++) {          // all chunks but the last, fragments double-buffered
+            if (j & 1) { read_bf(buf, j + 1, bf0); mfma_chunk(bf1, a_cur[j], 0, 4); }
+            else       { read_bf(buf, j + 1, bf1); mfma_chunk(bf0, a_cur[j], 0, 4); }
+        }
+        if ((KC - 1) & 1) mfma_chunk(bf1, a_cur[KC - 1], 0, 2); else mfma_chunk(bf0, a_cur[KC - 1], 0, 2);
         __builtin_amdgcn_sched_barrier(0);
         store_b(buf ^ 1, b_stage);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 2; e < 4; e++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][e], a_cur[rt][e], acc[rt][nt], 0, 0, 0);
+        if ((KC - 1) & 1) mfma_chunk(bf1, a_cur[KC - 1], 2, 4); else mfma_chunk(bf0, a_cur[KC - 1], 2, 4);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) a_cur[rt] = a_nxt[rt];
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) a_cur[j][rt] = a_nxt[j][rt];
         __syncthreads();
     }
 
@@ -205,35 +212,159 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
     }
 }
 
-static const TileCfg kCfgs[] = {{2, 8}, {2, 5}, {2, 4}, {2, 2}, {2, 1}, {1, 8}, {1, 5}, {1, 4}, {1, 2}, {1, 1}};
+// ------------------------------------------------------------------------------------------------
+// Tap GEMM for SMALL M (last FC layer, batch-1 calls from inside HM): the four waves of a workgroup
+// share one 16-row x 16*NT-column tile and split K between them (wave w takes chunks w, w+4, ...).
+// Nothing is shared before the end, so weights and activations stream straight into registers -- no
+// LDS staging, no barrier in the loop -- and one LDS reduction combines the four partial tiles.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams p)
+{
+    constexpr int BN = 16 * NT;
+    __shared__ f32x4 red[4][NT][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int mg = blockIdx.x * 16 + l15;
+    const bool mv = mg < p.M;
+    const int SP = p.SH * p.SW;
+    const int mc = mv ? mg : 0;
+    const int pb = mc / SP;
+    const int rr = mc - pb * SP;
+    const int pi = rr / p.SW, pj = rr - pi * p.SW;
 
-int tapgemm_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
-TileCfg tapgemm_cfg(int idx) { return kCfgs[idx]; }
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad
+                                   + (size_t)q * p.Npad + n0 + l15;
+    const size_t bstride = (size_t)4 * p.Npad;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
 
-template <int RT, int NT>
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    unsigned aoff = 0x80000000u;
+    auto tap_setup = [&](int t) {
+        const int tp = p.tap[t];
+        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+        const int iy = pi * p.a + dy, ix = pj * p.a + dx;
+        const bool ok = mv && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const unsigned off = ((unsigned)((pb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin + (q << 2)) << 2;
+        aoff = ok ? off : 0x80000000u;
+    };
+    auto load_chunk = [&](int chunk, int cc, f32x4& a, f32x4 (&b)[NT]) {
+        a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff, cc << 6, 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b[nt] = Wg[(size_t)chunk * bstride + nt * 16];
+    };
+
+    if (wave < nchunks) {                           // wave-uniform
+        int c = wave;
+        int t = t0 + c / cpt, cc = c - (c / cpt) * cpt;
+        tap_setup(t);
+        f32x4 a_cur, a_nxt, b_cur[NT], b_nxt[NT];
+        load_chunk(c, cc, a_cur, b_cur);
+        for (; c < nchunks; c += 4) {
+            const bool more = c + 4 < nchunks;
+            if (more) {
+                cc += 4;
+                if (cc >= cpt) {                    // next chunk of this wave lies in a later tap
+                    while (cc >= cpt) { cc -= cpt; ++t; }
+                    tap_setup(t);
+                }
+            }
+            load_chunk(more ? c + 4 : c, cc, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[nt][e], a_cur[e], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b_cur[nt] = b_nxt[nt];
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt];
+    __syncthreads();
+
+    if (!mv) return;
+    const int oy = pi * p.os + p.py[cls], ox = pj * p.os + p.px[cls];
+    const size_t obase = (((size_t)pb * p.OH + oy) * p.OW + ox) * p.Cout;
+    for (int nt = wave; nt < NT; nt += 4) {
+        const int n = n0 + nt * 16 + (q << 2);
+        if (n < p.Cout) {
+            f32x4 v = (red[0][nt][lane] + red[1][nt][lane]) + (red[2][nt][lane] + red[3][nt][lane]);
+            v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act) {
+                v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+            }
+            if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+            if (p.Yi) {
+                int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                    hm_round(v[3], p.mean));
+                *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+            }
+        }
+    }
+}
+
+// {rt, nt, kc}: rt = 0 marks the split-K kernel (one 16-row tile shared by the four waves).
+#define PNN_TG_CFGS(X) \
+    X(2, 8, 1) X(2, 5, 1) X(2, 4, 1) X(2, 2, 1) X(2, 1, 1) X(1, 8, 1) X(1, 5, 1) X(1, 4, 1) X(1, 2, 1) X(1, 1, 1) \
+    X(2, 8, 2) X(2, 5, 2) X(2, 4, 2) X(2, 2, 2) X(1, 8, 2) X(1, 5, 2) X(1, 4, 2) X(1, 2, 2)                   \
+    X(2, 5, 4) X(2, 4, 4) X(1, 5, 4) X(1, 4, 4)
+#define PNN_SK_CFGS(X) X(5) X(4) X(2) X(1)
+
+static const TileCfg kCfgs[] = {
+#define X(rt, nt, kc) {rt, nt, kc, 16},
+    PNN_TG_CFGS(X)
+#undef X
+#define X(nt) {0, nt, 1, 16},
+    PNN_SK_CFGS(X)
+#undef X
+};
+
+static int n16() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
+int tapgemm_num_cfgs() { return n16() + tapgemm32_num_cfgs(); }
+TileCfg tapgemm_cfg(int idx) { return idx < n16() ? kCfgs[idx] : tapgemm32_cfg(idx - n16()); }
+
+template <int RT, int NT, int KC>
 static hipError_t launch_tg(const TapGemmParams& p, hipStream_t s)
 {
     dim3 grid((p.M + 64 * RT - 1) / (64 * RT), (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
-    hipLaunchKernelGGL((tapgemm_kernel<RT, NT>), grid, dim3(256), 0, s, p);
+    static const int lds_pad = getenv("PNN_LDS_PAD") ? atoi(getenv("PNN_LDS_PAD")) : 0;   // experiment: cap workgroups per CU
+    hipLaunchKernelGGL((tapgemm_kernel<RT, NT, KC>), grid, dim3(256), lds_pad, s, p);
+    return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_sk(const TapGemmParams& p, hipStream_t s)
+{
+    dim3 grid((p.M + 15) / 16, (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
+    hipLaunchKernelGGL((tapgemm_splitk_kernel<NT>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s)
 {
     if (p.M <= 0) return hipSuccess;
-    switch (cfg_idx) {
-    case 0: return launch_tg<2, 8>(p, s);
-    case 1: return launch_tg<2, 5>(p, s);
-    case 2: return launch_tg<2, 4>(p, s);
-    case 3: return launch_tg<2, 2>(p, s);
-    case 4: return launch_tg<2, 1>(p, s);
-    case 5: return launch_tg<1, 8>(p, s);
-    case 6: return launch_tg<1, 5>(p, s);
-    case 7: return launch_tg<1, 4>(p, s);
-    case 8: return launch_tg<1, 2>(p, s);
-    case 9: return launch_tg<1, 1>(p, s);
-    default: return hipErrorInvalidValue;
-    }
+    if (cfg_idx >= n16()) return launch_tapgemm32(p, cfg_idx - n16(), s);
+    int i = 0;
+#define X(rt, nt, kc) if (cfg_idx == i++) return launch_tg<rt, nt, kc>(p, s);
+    PNN_TG_CFGS(X)
+#undef X
+#define X(nt) if (cfg_idx == i++) return launch_sk<nt>(p, s);
+    PNN_SK_CFGS(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------
