@@ -84,6 +84,7 @@ struct pnn_ctx {
     DevBuf stage_in[2], stage_out[2], stage_tbs;
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
+    long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
@@ -382,7 +383,7 @@ int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_t
     const int kc = (one_tap || cpt % 2 == 0) ? 2 : 1;             // a stage must not straddle two taps
     int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : ((cout % 128 == 0 && M >= 32768) ? 8 : 4));
     const long wgs_std = ((M + 63) / 64) * ((cout + 16L * nt - 1) / (16L * nt)) * ncls;
-    if (wgs_std < 192) {                                          // small M: four waves split K instead
+    if (wgs_std < 192 && !c->opt_canonical) {                     // small M: four waves split K instead
         int nts = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
         while (nts > 1 && ((M + 15) / 16) * ((cout + 16L * nts - 1) / (16L * nts)) * ncls < 128) nts >>= 1;
         const int i = find_cfg(0, nts, 1, 16);
@@ -728,6 +729,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     if (!c || !name) return PNN_E_ARG;
     if (!strcmp(name, "tile_cfg")) c->opt_tile_cfg = value;
     else if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
+    else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
     return PNN_OK;

@@ -62,7 +62,11 @@ void pnn_destroy(pnn_ctx* ctx);
 const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last error of a failed create */
 float pnn_mean(const pnn_ctx* ctx);
 
-/* Tuning knob: "tile_cfg" (-1 = automatic), "max_chunk" (blocks per pass, 0 = automatic). */
+/* Options: "tile_cfg" (-1 = automatic), "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb",
+ * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
+ * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
+ * pair needs; 0 (default) lets small batches use the faster split-K kernel, whose float result can differ in
+ * the last bits, i.e. by one LSB on an exact .5 tie). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 
 /* ---- host-buffer entry points (what the HM side binds; synchronous) ---------------------------------- */

@@ -59,8 +59,8 @@ def gen_gather_ref():
                     "c%d_mean" % k: np.float32(mean), "c%d_above" % k: a, "c%d_left" % k: l})
         k += 1
     rng = np.random.RandomState(1234)
-    for j in range(64):
-        w = int(rng.choice([4, 8, 16, 32, 64]))
+    for j in range(40):
+        w = int(rng.choice([4, 8, 16, 32, 64], p=[0.3, 0.3, 0.25, 0.1, 0.05]))
         plane = util.make_plane(3 * w + 8, 3 * w + 12, seed=5000 + j)
         xs, ys, flags = util.make_tbs(plane.shape[0], plane.shape[1], w, 1, seed=6000 + j, partial_fraction=0.8,
                                       holes=bool(j % 3 == 0))
@@ -113,7 +113,7 @@ def gen_nets():
     for is_fc, w in [(True, 4), (True, 8), (True, 16), (False, 4), (False, 8), (False, 16), (False, 32), (False, 64)]:
         seed = 100 + w + (1000 if is_fc else 0)
         n = 8 if w < 64 else 2
-        params = util.make_params(w, is_fc, seed, out_gain=25.0)
+        params = util.make_params(w, is_fc, seed, out_gain=util.out_gain(w, is_fc))
         above, left = util.make_contexts(w, n, seed + 1)
         if is_fc:
             out = O.fc_forward(params, w, util.flatten_fc(above, left))

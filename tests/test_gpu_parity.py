@@ -32,7 +32,7 @@ def _check_pel(got, want):
 
 @pytest.mark.parametrize("w,n", [(4, 1), (4, 257), (8, 1), (8, 64), (8, 1000), (16, 33)])
 def test_fc_matches_oracle(pnn, oracle, w, n):
-    params = util.make_params(w, True, seed=10 + w, out_gain=60.0)
+    params = util.make_params(w, True, seed=10 + w, out_gain=util.out_gain(w, True))
     above, left = util.make_contexts(w, n, seed=w * 1000 + n)
     ctx = util.flatten_fc(above, left)
     net = pnn.PredictionNeuralNetwork(n, w, True, params=params)
@@ -47,7 +47,7 @@ def test_fc_matches_oracle(pnn, oracle, w, n):
 
 @pytest.mark.parametrize("w,n", [(4, 1), (4, 130), (8, 1), (8, 77), (16, 1), (16, 40), (32, 5), (64, 2)])
 def test_conv_matches_oracle(pnn, oracle, w, n):
-    params = util.make_params(w, False, seed=20 + w, out_gain=40.0)
+    params = util.make_params(w, False, seed=20 + w, out_gain=util.out_gain(w, False))
     above, left = util.make_contexts(w, n, seed=w * 1000 + n + 1)
     net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
     got = net.predict(above[..., None], left[..., None])
@@ -98,7 +98,7 @@ def test_fused_tbs_matches_oracle(pnn, oracle, w, is_fc, n):
     import torch
     from context_adaptive_neural_network_based_prediction_amd import _lib
     L = _lib.lib()
-    params = util.make_params(w, is_fc, seed=30 + w, out_gain=30.0)
+    params = util.make_params(w, is_fc, seed=30 + w, out_gain=util.out_gain(w, is_fc))
     plane = util.make_plane(256, 384, seed=100 + w, pad=8)
     xs, ys, flags = util.make_tbs(256, 384, w, n, seed=w + 11)
     net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
@@ -111,3 +111,202 @@ def test_fused_tbs_matches_oracle(pnn, oracle, w, is_fc, n):
     torch.cuda.synchronize()
     want = oracle.predict_tbs(params, w, is_fc, plane, xs, ys, flags, util.MEAN)
     _check_pel(d_dst.cpu().numpy(), want)
+
+
+# ---- committed golden fixtures through the HIP path ----------------------------------------------------------
+import os  # noqa: E402
+
+from context_adaptive_neural_network_based_prediction_amd import weights as wts  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("is_fc,w", [(True, 4), (True, 8), (True, 16), (False, 4), (False, 8), (False, 16), (False, 32),
+                                     (False, 64)])
+def test_golden_nets(pnn, is_fc, w):
+    g = np.load(os.path.join(GOLD, "nets.npz"))
+    tag = "%s%d" % ("fc" if is_fc else "conv", w)
+    seed, n = int(g[tag + "_seed"]), int(g[tag + "_n"])
+    params = util.make_params(w, is_fc, seed, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, seed + 1)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    got = net.predict(util.flatten_fc(above, left)) if is_fc else net.predict(above, left)
+    np.testing.assert_allclose(got[..., 0], g[tag + "_out"], rtol=0, atol=FLOAT_ATOL)
+
+
+@pytest.mark.parametrize("w", [4, 8])
+def test_real_checkpoints_on_gpu(pnn, oracle, w):
+    """The reference's two trained models (converted from its TF checkpoints) through the HIP path."""
+    g = np.load(os.path.join(GOLD, "nets.npz"))
+    net = pnn.PredictionNeuralNetwork(8, w, False, path_to_model=os.path.join(GOLD, "conv%d_single.pnnw" % w))
+    got = net.predict(g["real%d_above" % w], g["real%d_left" % w])
+    np.testing.assert_allclose(got[..., 0], g["real%d_out" % w], rtol=0, atol=FLOAT_ATOL)
+    _check_pel(net.predict_pel(g["real%d_above" % w], g["real%d_left" % w]), oracle.epilogue(g["real%d_out" % w], util.MEAN))
+    img = np.tile(np.linspace(60, 180, 3 * w)[None, :], (3 * w, 1))
+    img[:, w + 1] = 230                                             # SURVEY.md Appendix A anchor
+    pred = net.predict_pel((img[None, 0:w, :] - util.MEAN).astype(np.float32), (img[None, w:3 * w, 0:w] - util.MEAN).astype(np.float32))[0]
+    assert (pred.argmax(axis=1) == 1).all()
+    if w == 4:
+        assert np.abs(pred - np.array([[102, 225, 126, 131], [105, 228, 132, 136], [100, 225, 131, 137], [112, 213, 133, 140]])).max() <= 1
+
+
+def test_python_gather_twin(pnn):
+    """context.extract_context_portions_targets_from_channels_plus_preprocessing == sets/common.py outputs."""
+    from context_adaptive_neural_network_based_prediction_amd import context
+    g = np.load(os.path.join(GOLD, "gather_python.npz"))
+    img = g["images"]
+    net = pnn.PredictionNeuralNetwork(1, 4, True, params=util.make_params(4, True, 1))
+    for k in range(int(g["n_cases"])):
+        w, mw, mh, is_fc = [int(v) for v in g["k%d_meta" % k]]
+        res = context.extract_context_portions_targets_from_channels_plus_preprocessing(
+            img, w, g["k%d_rows" % k], g["k%d_cols" % k], util.MEAN, (mw, mh), bool(is_fc), predictor=net)
+        assert len(res) == (2 if is_fc else 3)
+        for i, r in enumerate(res):
+            assert r.shape == g["k%d_out%d" % (k, i)].shape and np.array_equal(r, g["k%d_out%d" % (k, i)]), (k, i)
+    with pytest.raises(ValueError):
+        context.extract_context_portions_targets_from_channels_plus_preprocessing(
+            img, 8, np.array([0]), np.array([0]), util.MEAN, (6, 0), True, predictor=net)
+    with pytest.raises(TypeError):
+        context.extract_context_portions_targets_from_channels_plus_preprocessing(
+            img.astype(np.float32), 8, np.array([0]), np.array([0]), util.MEAN, (0, 0), True, predictor=net)
+
+
+def test_predict_by_batch_via_pnn(pnn, oracle):
+    """pnn/batching.py semantics: N = 6, batch 2 (test_pnn.py:451-506): identical inputs give identical outputs and
+    the result does not depend on the batch size."""
+    w = 8
+    params = util.make_params(w, True, 7, out_gain=util.out_gain(w, True))
+    above, left = util.make_contexts(w, 2, 8)
+    ctx = util.flatten_fc(above, left)
+    ctx = np.concatenate([ctx[:1], np.repeat(ctx[1:2], 5, axis=0)], axis=0)
+    net = pnn.PredictionNeuralNetwork(2, w, True, params=params)
+    out2 = pnn.predict_by_batch_via_pnn((ctx,), None, net, 2)
+    out6 = pnn.predict_by_batch_via_pnn((ctx,), None, net, 6)
+    assert out2.shape == (6, w, w, 1) and out2.dtype == np.float32
+    assert np.array_equal(out2, out6)
+    assert all(np.array_equal(out2[i], out2[1]) for i in range(2, 6)) and not np.array_equal(out2[0], out2[1])
+    np.testing.assert_allclose(out2[..., 0], oracle.fc_forward(params, w, ctx), rtol=0, atol=FLOAT_ATOL)
+    wc = 16
+    pc = util.make_params(wc, False, 9, out_gain=util.out_gain(wc, False))
+    a, l = util.make_contexts(wc, 4, 10)
+    netc = pnn.PredictionNeuralNetwork(2, wc, False, params=pc)
+    outc = pnn.predict_by_batch_via_pnn((a[..., None], l[..., None]), None, netc, 2)
+    np.testing.assert_allclose(outc[..., 0], oracle.conv_forward(pc, wc, a, l), rtol=0, atol=FLOAT_ATOL)
+
+
+def test_model_table_create_and_hm_call_sequence(pnn, oracle, tmp_path):
+    """pnn_create from a `width,is_pair,channel,path` table (TComPrediction.cpp:143-178), then exactly what HM does per
+    TB: host gather into the per-width tensor, one Run, epilogue into a strided Pel block (TComPrediction.cpp:554-635)."""
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    entries = []
+    params = {}
+    for pair in (0, 1):
+        for w in (4, 8, 16, 32, 64):
+            is_fc = w <= 8
+            flat = wts.init_params(w, is_fc, seed=100 * pair + w, bias_std=0.05)
+            if w == 8 or w == 16:
+                flat = util.make_params(w, is_fc, seed=100 * pair + w, out_gain=util.out_gain(w, is_fc))
+            params[(w, pair)] = flat
+            name = "w%d_%s.pnnw" % (w, "pair" if pair else "single")
+            wts.save_pnnw(str(tmp_path / name), flat, w, is_fc)
+            entries.append((w, pair, 0, name))                       # relative to the table's directory
+    table = wts.write_model_table(str(tmp_path / "table.txt"), entries)
+    for use_pair in (0, 1):
+        ctx = ctypes.c_void_p()
+        rc = L.pnn_create(ctypes.byref(ctx), table.encode(), use_pair, ctypes.c_float(util.MEAN), 0)
+        assert rc == 0, L.pnn_last_error(None)
+        fc, nl, npar = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+        assert L.pnn_model_info(ctx, 8, ctypes.byref(fc), ctypes.byref(nl), ctypes.byref(npar)) == 0
+        assert (fc.value, nl.value, npar.value) == (1, 4, 3344464)
+        assert L.pnn_model_info(ctx, 16, ctypes.byref(fc), ctypes.byref(nl), ctypes.byref(npar)) == 0
+        assert (fc.value, nl.value, npar.value) == (0, 13, 1339073)
+        for w in (8, 16):
+            plane = util.make_plane(96, 128, seed=w, pad=8)
+            xs, ys, flags = util.make_tbs(96, 128, w, 1, seed=w + use_pair, partial_fraction=1.0)
+            units = 2 * w // 4
+            buf = np.zeros(5 * w * w, np.float32)                    # one tensor for w <= 8, left at +3w^2 (TComPattern.cpp:352-353)
+            above, left = buf[:3 * w * w], buf[3 * w * w:]
+            origin = ctypes.cast(plane.ctypes.data + 4 * (int(ys[0]) * plane.shape[1] + int(xs[0])), _lib.i32p)
+            assert L.pnn_extract_context(origin, above.ctypes.data_as(_lib.f32p), left.ctypes.data_as(_lib.f32p),
+                                         flags[0].ctypes.data_as(_lib.u8p), int(flags[0].sum()), 4, 4, units, units, w, w,
+                                         plane.shape[1], ctypes.c_float(util.MEAN)) == 0
+            stride = 64
+            dst = np.full((w, stride), -7, np.int32)
+            rc = L.pnn_predict_pel(ctx, w, above.ctypes.data_as(_lib.f32p), left.ctypes.data_as(_lib.f32p), 1,
+                                   dst.ctypes.data_as(_lib.i32p), stride)
+            assert rc == 0, L.pnn_last_error(ctx)
+            want = oracle.predict_tbs(params[(w, use_pair)], w, w <= 8, plane, xs, ys, flags, util.MEAN)[0]
+            _check_pel(dst[:, :w], want)
+            assert (dst[:, w:] == -7).all()                          # nothing written outside the block
+        # wrong kind / missing width are errors, not fallbacks
+        out = np.zeros((1, 8, 8), np.float32)
+        assert L.pnn_predict_conv(ctx, 8, out.ctypes.data_as(_lib.f32p), out.ctypes.data_as(_lib.f32p), 1,
+                                  out.ctypes.data_as(_lib.f32p)) == -3
+        L.pnn_destroy(ctx)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("4,0,0,w4_single.pnnw\n")
+    ctx = ctypes.c_void_p()
+    assert L.pnn_create(ctypes.byref(ctx), str(bad).encode(), 0, ctypes.c_float(util.MEAN), 0) == -3   # 8..64 missing
+
+
+def test_torch_device_path_and_empty_batch(pnn, oracle):
+    import torch
+    w = 16
+    params = util.make_params(w, False, 11, out_gain=util.out_gain(w, False))
+    a, l = util.make_contexts(w, 9, 12)
+    net = pnn.PredictionNeuralNetwork(9, w, False, params=params)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                       # a non-default stream: the library must follow it
+        out = net.predict(torch.from_numpy(a).cuda()[..., None], torch.from_numpy(l).cuda()[..., None])
+    s.synchronize()
+    assert out.is_cuda and out.shape == (9, w, w, 1)
+    np.testing.assert_allclose(out.cpu().numpy()[..., 0], oracle.conv_forward(params, w, a, l), rtol=0, atol=FLOAT_ATOL)
+    assert net.predict(a[:0, ..., None], l[:0, ..., None]).shape == (0, w, w, 1)
+    with pytest.raises(ValueError):
+        net.predict(a)                                               # conv nets take two inputs
+
+
+# ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------
+@pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
+def test_full_size_properties(pnn, oracle, w, is_fc, n):
+    """configs[1] / configs[2] at full size: (1) a prediction does not depend on its batch position or on the batch
+    it travels in (chunked vs whole, permuted), (2) a random 64-block sample equals the oracle, (3) duplicated
+    inputs give identical outputs, (4) the fused gather+net+epilogue entry equals gather -> net -> epilogue."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, is_fc, 21, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 22)
+    above[n // 2] = above[3]
+    left[n // 2] = left[3]
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    full = run(above, left)
+    perm = np.random.RandomState(0).permutation(n)
+    assert np.array_equal(run(above[perm], left[perm]), full[perm])
+    net.set_option("max_chunk", 300)                                 # ragged chunks: 300, 300, ..., remainder
+    np.testing.assert_allclose(run(above, left), full, rtol=0, atol=FLOAT_ATOL)   # small passes may pick the split-K kernel
+    net.set_option("canonical_order", 1)                             # ... unless one summation order is requested:
+    canon = run(above, left)
+    net.set_option("max_chunk", 0)
+    assert np.array_equal(run(above, left), canon)                   # then chunking / batch size change nothing, bit for bit
+    assert np.array_equal(run(above[5:6], left[5:6])[0], canon[5])   # ... down to a batch of one
+    net.set_option("canonical_order", 0)
+    assert np.array_equal(full[n // 2], full[3])
+    idx = np.random.RandomState(1).choice(n, 64, replace=False)
+    want = oracle.fc_forward(params, w, util.flatten_fc(above[idx], left[idx])) if is_fc else oracle.conv_forward(params, w, above[idx], left[idx])
+    np.testing.assert_allclose(full[idx, ..., 0], want, rtol=0, atol=FLOAT_ATOL)
+    plane = util.make_plane(544, 960, seed=5, pad=32)
+    xs, ys, flags = util.make_tbs(544, 960, w, n, seed=6)
+    d_plane = torch.from_numpy(plane).cuda()
+    d_tbs = torch.from_numpy(_device_tbs(pnn, xs, ys, flags, plane.shape[1], w)).cuda()
+    d_dst = torch.empty((n, w, w), dtype=torch.int32, device="cuda")
+    d_f32 = torch.empty((n, w, w), dtype=torch.float32, device="cuda")
+    assert L.pnn_predict_tbs_device(net.ctx, w, d_plane.data_ptr(), 4, d_tbs.data_ptr(), n, d_dst.data_ptr(), d_f32.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert got.min() >= 0 and got.max() <= 255 and got.min() == 0 and got.max() == 255
+    assert np.array_equal(got, oracle.epilogue(d_f32.cpu().numpy(), util.MEAN))   # epilogue fused == epilogue applied after
+    sample = idx[:32]
+    _check_pel(got[sample], oracle.predict_tbs(params, w, is_fc, plane, xs[sample], ys[sample], flags[sample], util.MEAN))

@@ -5,6 +5,15 @@ from context_adaptive_neural_network_based_prediction_amd import weights as wts
 
 MEAN = wts.MEAN_TRAINING_LUMINANCE
 
+# Last-layer gains that make seeded random nets sweep (and overshoot) the 0..255 range, so that parity tests
+# exercise both clamps of the HM epilogue; found by running the oracle once per architecture.
+OUT_GAIN = {("fc", 4): 60.0, ("fc", 8): 30.0, ("fc", 16): 15.0,
+            ("conv", 4): 600.0, ("conv", 8): 300.0, ("conv", 16): 2000.0, ("conv", 32): 8000.0, ("conv", 64): 12000.0}
+
+
+def out_gain(w, is_fc):
+    return OUT_GAIN[("fc" if is_fc else "conv", w)]
+
 
 def make_params(w, is_fc, seed, out_gain=1.0, bias_std=0.05):
     """Reference-initialiser statistics (weights.init_params); `out_gain` scales the last layer's weights so
