@@ -167,22 +167,29 @@ def main():
 
     for _ in range(3):
         net_only()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(5, min(args.steps, 50))
     torch.cuda.synchronize()
-    ev0.record(stream)
+    net.set_option("time_launches", 1)             # HIP events around every tap-GEMM launch, on the launch stream
     for _ in range(reps):
         net_only()
-    ev1.record(stream)
     torch.cuda.synchronize()
-    net_ms = ev0.elapsed_time(ev1) / reps
+    net.set_option("time_launches", 0)
     nstats = net.last_call_stats()
-    other_launches = nstats["launches"] - nstats["gemm_launches"]
-    gemm_flops_per_launch = nstats["gemm_flops"] / max(nstats["gemm_launches"], 1)
-    # For FC nets the region holds only tap-GEMM launches; for conv nets the few non-GEMM launches
-    # (Cin=1 conv, merger, Cout=1 tconv) are inside the region too, which makes `achieved` conservative.
-    avg_launch_s = net_ms * 1e-3 / max(nstats["gemm_launches"], 1)
+    n_std, us_std, fl_std = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    n_sk, us_sk, fl_sk = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    L.pnn_launch_times(net.ctx, 0, ctypes.byref(n_std), ctypes.byref(us_std), ctypes.byref(fl_std))
+    L.pnn_launch_times(net.ctx, 1, ctypes.byref(n_sk), ctypes.byref(us_sk), ctypes.byref(fl_sk))
+    # Dominant kernel = tapgemm_kernel (the LDS-staged MFMA tap GEMM); the small-M split-K kernel is listed beside it.
+    gemm_flops_per_launch = fl_std.value / max(n_std.value, 1)
+    avg_launch_s = us_std.value * 1e-6 / max(n_std.value, 1)
     achieved_tflops = gemm_flops_per_launch / avg_launch_s / 1e12
+    other_launches = nstats["launches"] - nstats["gemm_launches"]
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # PMC pass results (FETCH_SIZE x2 + WRITE_SIZE, per launch)
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get(args.workload)
+        if rec and batch == default_batch:
+            traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
 
     # ---- CPU baseline: the oracle (a port; TF1 cannot be installed) on this box's host cores --------------
     cpu = None
@@ -221,11 +228,13 @@ def main():
                        "parallelism": "independent blocks sharded over ranks, no data-path collective"},
             "launches_per_step": stats["launches"],
             "max_abs_lsb_vs_oracle": parity,
-            "roofline": {"bound": "mfma", "kernel": "tapgemm_kernel (f32 MFMA 16x16x4)", "achieved": achieved_tflops,
+            "roofline": {"bound": "mfma", "kernel": "tapgemm_kernel (f32 MFMA, LDS-staged weights)", "achieved": achieved_tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "flops_per_launch": gemm_flops_per_launch,
-                         "avg_launch_us": avg_launch_s * 1e6, "gemm_launches_per_pass": nstats["gemm_launches"],
-                         "other_launches_in_region": other_launches,
+                         "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": gemm_flops_per_launch,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_std.value,
+                         "gemm_launches_per_pass": nstats["gemm_launches"], "non_gemm_launches_per_pass": other_launches,
+                         "splitk_kernel": {"launches_timed": n_sk.value, "avg_launch_us": us_sk.value / max(n_sk.value, 1),
+                                           "tflops": fl_sk.value / max(us_sk.value, 1e-9) / 1e6},
                          "algorithmic_flops_per_block": flops_per_block(width, is_fc)},
             "cpu_baseline": cpu,
         }

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pnn_gather_device": (ci, [vp, ci, ci, vp, ci, vp, ci, vp, ctypes.c_long, vp, ctypes.c_long, vp]),
     "pnn_predict_tbs_device": (ci, [vp, ci, vp, ci, vp, ci, vp, vp, vp]),
     "pnn_last_call_stats": (ci, [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci)]),
+    "pnn_launch_times": (ci, [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

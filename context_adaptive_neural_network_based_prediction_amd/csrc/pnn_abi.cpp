@@ -85,6 +85,9 @@ struct pnn_ctx {
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
+    long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
+    struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
+    std::vector<LaunchRec> launch_recs;
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
@@ -411,23 +414,28 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls,
                 cfg, t.rt, t.nt, t.kc);
     }
-    static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch HIP-event timing
-    if (profile) {
-        hipEvent_t e0, e1;
-        HIPCHK(c, hipEventCreate(&e0));
-        HIPCHK(c, hipEventCreate(&e1));
-        HIPCHK(c, hipEventRecord(e0, s));
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch timing, synchronous
+    if (profile || c->opt_time_launches) {
+        pnn_ctx::LaunchRec r;
+        HIPCHK(c, hipEventCreate(&r.e0));
+        HIPCHK(c, hipEventCreate(&r.e1));
+        r.kind = tapgemm_cfg(cfg).rt == 0 ? 1 : 0;
+        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
+        HIPCHK(c, hipEventRecord(r.e0, s));
         HIPCHK(c, launch_tapgemm(p, cfg, s));
-        HIPCHK(c, hipEventRecord(e1, s));
-        HIPCHK(c, hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        const TileCfg t = tapgemm_cfg(cfg);
-        const double fl = 2.0 * (double)M * L.k_total * p.Cout;
-        fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
-                p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, fl / (ms * 1e-3) / 1e12);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        HIPCHK(c, hipEventRecord(r.e1, s));
+        if (profile) {
+            HIPCHK(c, hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+            const TileCfg t = tapgemm_cfg(cfg);
+            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        } else {
+            c->launch_recs.push_back(r);
+        }
     } else {
         HIPCHK(c, launch_tapgemm(p, cfg, s));
     }
@@ -730,6 +738,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     if (!strcmp(name, "tile_cfg")) c->opt_tile_cfg = value;
     else if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
     else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
+    else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
     return PNN_OK;
@@ -741,6 +750,28 @@ int pnn_last_call_stats(const pnn_ctx* c, int* n_gemm, double* flops, int* n_lau
     if (n_gemm) *n_gemm = c->stat_gemm_launches;
     if (flops) *flops = c->stat_gemm_flops;
     if (n_launches) *n_launches = c->stat_launches;
+    return PNN_OK;
+}
+
+int pnn_launch_times(pnn_ctx* c, int kind, int* n_launches, double* total_us, double* total_flops)
+{
+    if (!c) return PNN_E_ARG;
+    int n = 0;
+    double us = 0, fl = 0;
+    std::vector<pnn_ctx::LaunchRec> keep;
+    for (pnn_ctx::LaunchRec& r : c->launch_recs) {
+        if (r.kind != kind) { keep.push_back(r); continue; }
+        HIPCHK(c, hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+        us += ms * 1e3; fl += r.flops; n++;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    c->launch_recs.swap(keep);
+    if (n_launches) *n_launches = n;
+    if (total_us) *total_us = us;
+    if (total_flops) *total_flops = fl;
     return PNN_OK;
 }
 

@@ -129,6 +129,12 @@ int pnn_predict_tbs_device(pnn_ctx* ctx, int width, const void* d_plane, int pel
  * launches and their algorithmic FLOPs (2 * M * K * N summed, padding excluded). */
 int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_flops, int* n_launches);
 
+/* With pnn_set_option(ctx, "time_launches", 1) every tap-GEMM launch is bracketed by HIP events on its launch
+ * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_kernel / tapgemm32_kernel,
+ * 1 = tapgemm_splitk_kernel), the number of launches since the last call, their summed duration and their
+ * summed algorithmic FLOPs. */
+int pnn_launch_times(pnn_ctx* ctx, int kind, int* n_launches, double* total_us, double* total_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the per-round profile evidence on the GPU box into gpurun_out/profiles_<round>/ :
+#   rocprofv3 --kernel-trace --stats of the default bench command (FC 8x8) and of conv16, plus PMC passes
+#   (separate runs, --pmc only) for MFMA utilisation, LDS conflicts and HBM traffic.
+export TMPDIR=/tmp
+r=${1:-r01}
+out=gpurun_out/profiles_$r
+mkdir -p $out
+for wl in fc8 conv16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > $out/${wl}_trace.log 2>&1
+  python3 tools_trace_summary.py $out/${wl}_trace > $out/${wl}_kernel_summary.txt
+  cp $out/${wl}_trace/*/*_kernel_stats.csv $out/${wl}_kernel_stats.csv
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
+             "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > $out/${wl}_pmc_p$i.log 2>&1
+  done
+  python3 tools_pmc_summary.py $wl > $out/${wl}_pmc_summary.txt
+  rm -rf $out/${wl}_trace
+done
+python3 bench.py --steps 100 --warmup 10 > $out/bench_fc8.json 2> $out/bench_fc8.err
+python3 bench.py --workload conv16 --steps 50 --warmup 5 > $out/bench_conv16.json 2> $out/bench_conv16.err
+ls -la $out
