@@ -59,6 +59,7 @@ hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 struct TConv1Params {
     const float* X; const float* W; /* [k][k][Cin] */ float bias; float* Y; int32_t* Yi;
     int B, IH, IW, Cin, s, k, pad; float mean;
+    int ni;   // images per workgroup (set by the launcher)
 };
 hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s);
 

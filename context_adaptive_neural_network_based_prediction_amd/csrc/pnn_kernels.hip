@@ -367,220 +367,4 @@ hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Cin == 1 forward convolution + bias + LeakyReLU (first layer of each branch; k = 3 or 5).
-// 16 (or 8) lanes share one output pixel, 4 output channels per lane: a wave writes 1 KiB (512 B)
-// of contiguous NHWC output per instruction.  HBM-bound on the output write.
-// ------------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
-{
-    const int CG = p.Cout >> 2;                       // lanes per pixel
-    const int ppb = 256 / CG;                         // pixels per block iteration
-    const int cg = threadIdx.x % CG, psub = threadIdx.x / CG;
-    f32x4 w[K * K];
-#pragma unroll
-    for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W + (size_t)t * p.Cout + 4 * cg);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
-    const long npix = (long)p.B * p.OH * p.OW;
-    for (long pix = (long)blockIdx.x * ppb + psub; pix < npix; pix += (long)gridDim.x * ppb) {
-        const int ox = (int)(pix % p.OW);
-        const long r = pix / p.OW;
-        const int oy = (int)(r % p.OH);
-        const long b = r / p.OH;
-        const float* xb = p.X + b * p.IH * p.IW;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < K; ky++) {
-            const int iy = oy * p.s + ky - p.pad;
-#pragma unroll
-            for (int kx = 0; kx < K; kx++) {
-                const int ix = ox * p.s + kx - p.pad;
-                const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-                const float xv = ok ? xb[iy * p.IW + ix] : 0.f;
-                acc += xv * w[ky * K + kx];
-            }
-        }
-        acc += bv;
-        acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-        *reinterpret_cast<f32x4*>(p.Y + pix * p.Cout + 4 * cg) = acc;
-    }
-}
-
-hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
-{
-    const long npix = (long)p.B * p.OH * p.OW;
-    if (npix <= 0) return hipSuccess;
-    const int ppb = 256 / (p.Cout >> 2);
-    long blocks = (npix + ppb - 1) / ppb;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Cout == 1 transposed convolution + bias (last merger layer, linear), optional HM epilogue.
-// Cin/4 lanes per output pixel, float4 channel slices, shuffle reduction inside the lane group.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
-{
-    const int LP = p.Cin >> 2;                        // lanes per pixel: 8 (Cin 32) or 16 (Cin 64)
-    const int cl = threadIdx.x % LP;
-    const int OH = p.IH * p.s, OW = p.IW * p.s;
-    const long npix = (long)p.B * OH * OW;
-    const long pix = ((long)blockIdx.x * 256 + threadIdx.x) / LP;
-    const bool live = pix < npix;
-    const long pc = live ? pix : 0;
-    const int ox = (int)(pc % OW);
-    const long r = pc / OW;
-    const int oy = (int)(r % OH);
-    const long b = r / OH;
-    float acc = 0.f;
-    for (int ky = 0; ky < p.k; ky++) {
-        const int ny = oy + p.pad - ky;
-        if (ny < 0 || (ny % p.s)) continue;
-        const int iy = ny / p.s;
-        if (iy >= p.IH) continue;
-        for (int kx = 0; kx < p.k; kx++) {
-            const int nx = ox + p.pad - kx;
-            if (nx < 0 || (nx % p.s)) continue;
-            const int ix = nx / p.s;
-            if (ix >= p.IW) continue;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.X + ((b * p.IH + iy) * p.IW + ix) * p.Cin + 4 * cl);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.W + (size_t)(ky * p.k + kx) * p.Cin + 4 * cl);
-            acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
-        }
-    }
-    for (int off = LP >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (live && cl == 0) {
-        const float v = acc + p.bias;
-        if (p.Y) p.Y[pix] = v;
-        if (p.Yi) p.Yi[pix] = hm_round(v, p.mean);
-    }
-}
-
-hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s)
-{
-    const long npix = (long)p.B * p.IH * p.s * p.IW * p.s;
-    if (npix <= 0) return hipSuccess;
-    const int LP = p.Cin >> 2;
-    if (LP != 8 && LP != 16 && LP != 32) return hipErrorInvalidValue;
-    const long threads = npix * LP;
-    hipLaunchKernelGGL(tconv_cout1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Channel-wise fully-connected merger + LeakyReLU (pnn/tfutils.py:8-73, components.py:231-237).
-// One thread = one channel c of MB consecutive blocks; loads and stores are coalesced over c.
-// ------------------------------------------------------------------------------------------------
-constexpr int kMergerMB = 4;
-__global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
-{
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int c = (int)(gid % p.C);
-    const long b0 = (gid / p.C) * kMergerMB;
-    if (b0 >= p.B) return;
-    float acc[kMergerMB][16];
-#pragma unroll
-    for (int m = 0; m < kMergerMB; m++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) acc[m][j] = 0.f;
-    const int nin = p.na + p.nl;
-    for (int pp = 0; pp < nin; pp++) {
-        float xv[kMergerMB];
-#pragma unroll
-        for (int m = 0; m < kMergerMB; m++) {
-            const long b = (b0 + m < p.B) ? b0 + m : b0;
-            xv[m] = (pp < p.na) ? p.A[(b * p.na + pp) * p.C + c] : p.L[(b * p.nl + (pp - p.na)) * p.C + c];
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float wv = p.Wp[((size_t)pp * 16 + j) * p.C + c];
-#pragma unroll
-            for (int m = 0; m < kMergerMB; m++) acc[m][j] += xv[m] * wv;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float bv = p.bias[(size_t)j * p.C + c];
-#pragma unroll
-        for (int m = 0; m < kMergerMB; m++)
-            if (b0 + m < p.B) p.Y[((b0 + m) * 16 + j) * p.C + c] = leaky(acc[m][j] + bv);
-    }
-}
-
-hipError_t launch_merger(const MergerParams& p, hipStream_t s)
-{
-    if (p.B <= 0) return hipSuccess;
-    if (p.nout != 16) return hipErrorInvalidValue;
-    const long threads = (long)((p.B + kMergerMB - 1) / kMergerMB) * p.C;
-    hipLaunchKernelGGL(merger_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// L-shaped context gather: Pel (int32 or uint8) -> float, minus mean, unavailable units -> 0.
-// Equivalent to extraction_context.cpp:3-208 for every flag pattern: the above portion is masked per
-// unit; the left portion holds the first 4*left_units source rows (the reference advances source and
-// destination only on available units, extraction_context.cpp:189-205).
-// ------------------------------------------------------------------------------------------------
-template <typename Pel>
-__global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
-{
-    const int w = p.w;
-    const int na = 3 * w * w, per = 5 * w * w;
-    const long total = (long)p.N * per;
-    const Pel* plane = reinterpret_cast<const Pel*>(p.plane);
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long tb = e / per;
-        const int r = (int)(e - tb * per);
-        const TbDev d = p.tbs[tb];
-        if (r < na) {
-            const int row = r / (3 * w), col = r - row * 3 * w;
-            bool ok = true;
-            if (col >= w) ok = (d.above_mask >> ((col - w) / p.unit)) & 1u;
-            float v = 0.f;
-            if (ok) v = (float)plane[d.origin + (long)(row - w) * d.stride + (col - w)] - p.mean;
-            p.above[tb * p.pitch_above + r] = v;
-        } else {
-            const int rl = r - na;
-            const int row = rl / w, col = rl - row * w;
-            const bool ok = row < d.left_units * p.unit;
-            float v = 0.f;
-            if (ok) v = (float)plane[d.origin + (long)row * d.stride + (col - w)] - p.mean;
-            p.left[tb * p.pitch_left + rl] = v;
-        }
-    }
-}
-
-hipError_t launch_gather(const GatherParams& p, hipStream_t s)
-{
-    const long total = (long)p.N * 5 * p.w * p.w;
-    if (total <= 0) return hipSuccess;
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (p.pel_bytes == 1) hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void epilogue_kernel(const float* pred, long n, float mean, int32_t* dst)
-{
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        dst[i] = hm_round(pred[i], mean);
-}
-
-hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, hipStream_t s)
-{
-    if (n <= 0) return hipSuccess;
-    long blocks = (n + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, n, mean, dst);
-    return hipGetLastError();
-}
-
 }  // namespace pnn

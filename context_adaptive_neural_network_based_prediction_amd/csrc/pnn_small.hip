@@ -1,0 +1,288 @@
+// The non-GEMM kernels of the PNN forward pass (gfx950): the L-shaped context gather, the Cin = 1 first
+// convolution of each branch, the channel-wise fully-connected merger, the Cout = 1 last transposed
+// convolution (with the HM epilogue fused) and the stand-alone epilogue.  All are bandwidth-side work: the
+// designs below stage what is re-read in LDS so that global memory sees each activation once.
+//
+// Reference semantics: extraction_context.cpp:3-208 (gather), pnn/tfutils.py:75-139 (conv, SAME),
+// pnn/tfutils.py:8-73 + components.py:231-237 (merger), pnn/tfutils.py:395-462 (transposed conv, SAME),
+// TComPrediction.cpp:621-635 (epilogue).
+#include "pnn_kernels.h"
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 1 forward convolution + bias + LeakyReLU (k = 3, stride 1 or k = 5, stride 2).
+// One workgroup per image: the zero-padded input plane sits in LDS (SAME padding becomes plain indexing),
+// each lane keeps its 4 output channels' k*k weights in registers, Cout/4 lanes share a pixel so a wave
+// stores 1 KiB (Cout 64) of contiguous NHWC output per instruction.  HBM-bound on the output write.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int PH = (p.OH - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
+    const long b = blockIdx.x;
+    const float* xb = p.X + b * p.IH * p.IW;
+    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+        const int r = idx / PW, c = idx - r * PW;
+        const int iy = r - p.pad, ix = c - p.pad;
+        xs[idx] = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
+    }
+    const int CG = p.Cout >> 2;                       // lanes per pixel (8 or 16)
+    const int cg = threadIdx.x % CG, psub = threadIdx.x / CG, ppi = 256 / CG;
+    f32x4 w[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W + (size_t)t * p.Cout + 4 * cg);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
+    __syncthreads();
+    const int npix = p.OH * p.OW;
+    float* yb = p.Y + b * npix * p.Cout;
+    for (int pix = psub; pix < npix; pix += ppi) {
+        const int oy = pix / p.OW, ox = pix - oy * p.OW;
+        const float* xr = xs + (oy * p.s) * PW + ox * p.s;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
+        acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
+        *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
+    }
+}
+
+hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
+{
+    if (p.B <= 0) return hipSuccess;
+    const size_t lds = (size_t)((p.OH - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
+    if (lds > 64 * 1024 || (p.Cout != 32 && p.Cout != 64)) return hipErrorInvalidValue;
+    if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3(p.B), dim3(256), lds, s, p);
+    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3(p.B), dim3(256), lds, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 1 transposed convolution + bias (last merger layer, linear), optional HM epilogue.
+// One workgroup per 16x16 output tile of one image.  The input tile (with halo, zeros outside the image)
+// is staged in LDS channel-chunk-major -- [Cin/4][pixel] float4 -- so that the 64 lanes of a wave, which
+// read 64 different pixels at the same channel chunk, hit consecutive 16-byte slots.  For stride 2 each
+// wave owns one output-parity class (py, px): its tap set is wave-uniform, so the weights are scalar
+// loads and there is no divergence.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) f32x4 xt[];       // [image in WG][Cin/4][TI*TI]
+    const int s = p.s, K = p.k;
+    const int OH = p.IH * s, OW = p.IW * s;
+    const int TO = OH < 16 ? OH : 16;                 // output tile edge (square images: OH == OW)
+    const int tiles_x = (OW + TO - 1) / TO;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int oy0 = ty * TO, ox0 = tx * TO;
+    // input rows/cols that can reach this output tile: iy in [floor((oy0 + pad - (K-1)) / s), (oy0 + TO-1 + pad) / s]
+    const int lo_y = oy0 + p.pad - (K - 1), lo_x = ox0 + p.pad - (K - 1);
+    const int iy0 = lo_y >= 0 ? lo_y / s : -((-lo_y + s - 1) / s);
+    const int ix0 = lo_x >= 0 ? lo_x / s : -((-lo_x + s - 1) / s);
+    const int TI = (oy0 + TO - 1 + p.pad) / s - iy0 + 1;
+    const int NP = TI * TI, C4 = p.Cin >> 2;
+    const int NI = p.ni;                              // images per workgroup (small outputs share a workgroup)
+    const long bbase = (long)blockIdx.x * NI;
+    for (int idx = threadIdx.x; idx < NI * NP * C4; idx += 256) {
+        const int li = idx / (NP * C4), r0 = idx - li * NP * C4;
+        const int pix = r0 / C4, c4 = r0 - pix * C4;
+        const int r = pix / TI, c = pix - r * TI;
+        const int iy = iy0 + r, ix = ix0 + c;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bbase + li < p.B && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+            v = *reinterpret_cast<const f32x4*>(p.X + (((bbase + li) * p.IH + iy) * p.IW + ix) * p.Cin + 4 * c4);
+        xt[(li * C4 + c4) * NP + pix] = v;
+    }
+    __syncthreads();
+
+    // Thread -> (image, output pixel).  Stride 2: wave = parity class (py, px), lanes = NI images x (TO/2)^2
+    // pixels of that class, so the tap set is wave-uniform.  Stride 1: plain row-major pixels, every tap valid.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int li, oy, ox, py, px;
+    bool live;
+    if (s == 2) {
+        const int SG = TO >> 1, SGP = SG * SG;
+        py = wave >> 1; px = wave & 1;
+        li = lane / SGP;
+        const int sub = lane - li * SGP;
+        oy = oy0 + 2 * (sub / SG) + py; ox = ox0 + 2 * (sub % SG) + px;
+        live = li < NI;
+    } else {
+        const int PT = TO * TO;
+        py = 0; px = 0;
+        li = threadIdx.x / PT;
+        const int sub = threadIdx.x - li * PT;
+        oy = oy0 + sub / TO; ox = ox0 + sub % TO;
+        live = li < NI;
+    }
+    if (!live) li = 0;
+    float acc = 0.f;
+    for (int ky = 0; ky < K; ky++) {
+        if ((py + p.pad - ky) % s) continue;          // wave-uniform: parity class (s = 2) or always taken (s = 1)
+        const int ry = (oy + p.pad - ky) / s - iy0;   // exact division for this class; inside the staged tile
+        for (int kx = 0; kx < K; kx++) {
+            if ((px + p.pad - kx) % s) continue;
+            const int rx = (ox + p.pad - kx) / s - ix0;
+            const f32x4* xp = xt + (size_t)li * C4 * NP + ry * TI + rx;
+            const f32x4* wp = reinterpret_cast<const f32x4*>(p.W + (size_t)(ky * K + kx) * p.Cin);   // uniform -> scalar loads
+            for (int c4 = 0; c4 < C4; c4++) {
+                const f32x4 xv = xp[c4 * NP], wv = wp[c4];
+                acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+            }
+        }
+    }
+    if (live && bbase + li < p.B && oy < OH && ox < OW) {
+        const float v = acc + p.bias;
+        const size_t o = ((size_t)(bbase + li) * OH + oy) * OW + ox;
+        if (p.Y) p.Y[o] = v;
+        if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
+    }
+}
+
+hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)
+{
+    TConv1Params p = pin;
+    if (p.B <= 0) return hipSuccess;
+    if ((p.s != 1 && p.s != 2) || p.Cin % 4 || p.IH != p.IW) return hipErrorInvalidValue;
+    const int OH = p.IH * p.s;
+    const int TO = OH < 16 ? OH : 16;
+    if (p.s == 2 && (TO & 1)) return hipErrorInvalidValue;
+    const int lo = p.pad - (p.k - 1);
+    const int i0 = lo >= 0 ? lo / p.s : -((-lo + p.s - 1) / p.s);
+    const int TI = (TO - 1 + p.pad) / p.s - i0 + 1;
+    const size_t per_img = (size_t)TI * TI * p.Cin * sizeof(float);
+    int ni = p.s == 2 ? 64 / ((TO / 2) * (TO / 2)) : 256 / (TO * TO);
+    while (ni > 1 && ni * per_img > 60 * 1024) ni >>= 1;
+    if (ni < 1 || per_img > 64 * 1024) return hipErrorInvalidValue;
+    p.ni = ni;
+    const int tiles = ((OH + TO - 1) / TO) * ((OH + TO - 1) / TO);
+    dim3 grid((p.B + ni - 1) / ni, tiles);
+    hipLaunchKernelGGL(tconv_cout1_kernel, grid, dim3(256), ni * per_img, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel-wise fully-connected merger + LeakyReLU.  Per channel c: out[b][j][c] = leaky(sum_p v[b][p][c] *
+// W[c][p][j] + bias[c][j]) with v = [above 4x12 | left 8x4] (80 values).  Thread = (channel c, 4 outputs j,
+// MB blocks); lanes run over c, the innermost NHWC index, so every load and store is coalesced; W is
+// pre-arranged as [p][j][c].
+// ------------------------------------------------------------------------------------------------
+constexpr int kMergerMB = 2;
+__global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(gid % p.C);
+    const long r = gid / p.C;
+    const int jq = (int)(r & 3);
+    const long b0 = (r >> 2) * kMergerMB;
+    if (b0 >= p.B) return;
+    float acc[kMergerMB][4];
+#pragma unroll
+    for (int m = 0; m < kMergerMB; m++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[m][j] = 0.f;
+    long brow[kMergerMB];
+#pragma unroll
+    for (int m = 0; m < kMergerMB; m++) brow[m] = (b0 + m < p.B) ? b0 + m : b0;
+    // two plain loops (above part, then left part) instead of a per-iteration select between the sources
+    auto part = [&](const float* src, int np, int pbase) {
+#pragma unroll 8
+        for (int pp = 0; pp < np; pp++) {
+            float xv[kMergerMB];
+#pragma unroll
+            for (int m = 0; m < kMergerMB; m++) xv[m] = src[(brow[m] * np + pp) * p.C + c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float wv = p.Wp[((size_t)(pbase + pp) * 16 + 4 * jq + j) * p.C + c];
+#pragma unroll
+                for (int m = 0; m < kMergerMB; m++) acc[m][j] += xv[m] * wv;
+            }
+        }
+    };
+    part(p.A, p.na, 0);
+    part(p.L, p.nl, p.na);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float bv = p.bias[(size_t)(4 * jq + j) * p.C + c];
+#pragma unroll
+        for (int m = 0; m < kMergerMB; m++)
+            if (b0 + m < p.B) p.Y[((b0 + m) * 16 + 4 * jq + j) * p.C + c] = leaky(acc[m][j] + bv);
+    }
+}
+
+hipError_t launch_merger(const MergerParams& p, hipStream_t s)
+{
+    if (p.B <= 0) return hipSuccess;
+    if (p.nout != 16) return hipErrorInvalidValue;
+    const long threads = (long)((p.B + kMergerMB - 1) / kMergerMB) * 4 * p.C;
+    hipLaunchKernelGGL(merger_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// L-shaped context gather: Pel (int32 or uint8) -> float, minus mean, unavailable units -> 0.
+// Equivalent to extraction_context.cpp:3-208 for every flag pattern: the above portion is masked per
+// unit; the left portion holds the first 4*left_units source rows (the reference advances source and
+// destination only on available units, extraction_context.cpp:189-205).
+// ------------------------------------------------------------------------------------------------
+template <typename Pel>
+__global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
+{
+    const int w = p.w;
+    const int na = 3 * w * w, per = 5 * w * w;
+    const long total = (long)p.N * per;
+    const Pel* plane = reinterpret_cast<const Pel*>(p.plane);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long tb = e / per;
+        const int r = (int)(e - tb * per);
+        const TbDev d = p.tbs[tb];
+        if (r < na) {
+            const int row = r / (3 * w), col = r - row * 3 * w;
+            bool ok = true;
+            if (col >= w) ok = (d.above_mask >> ((col - w) / p.unit)) & 1u;
+            float v = 0.f;
+            if (ok) v = (float)plane[d.origin + (long)(row - w) * d.stride + (col - w)] - p.mean;
+            p.above[tb * p.pitch_above + r] = v;
+        } else {
+            const int rl = r - na;
+            const int row = rl / w, col = rl - row * w;
+            const bool ok = row < d.left_units * p.unit;
+            float v = 0.f;
+            if (ok) v = (float)plane[d.origin + (long)row * d.stride + (col - w)] - p.mean;
+            p.left[tb * p.pitch_left + rl] = v;
+        }
+    }
+}
+
+hipError_t launch_gather(const GatherParams& p, hipStream_t s)
+{
+    const long total = (long)p.N * 5 * p.w * p.w;
+    if (total <= 0) return hipSuccess;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (p.pel_bytes == 1) hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void epilogue_kernel(const float* pred, long n, float mean, int32_t* dst)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dst[i] = hm_round(pred[i], mean);
+}
+
+hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, n, mean, dst);
+    return hipGetLastError();
+}
+
+}  // namespace pnn
