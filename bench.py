@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32)
+DEFAULT_PRECISION = "1"           # library default (pnn_set_option "precision"); PNN_PRECISION overrides
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 
 WORKLOADS = {                      # name -> (width, is_fc, default batch per GPU, BASELINE.json config)
     "fc4": (4, True, 4096, "4x4 fully-connected PNN"),
@@ -92,6 +94,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    precision_name = ("f32 (3 x f16 MFMA split products, f32 accumulate)" if os.environ.get("PNN_PRECISION", DEFAULT_PRECISION) == "1"
+                      else "f32")
     width, is_fc, default_batch, cfg_name = WORKLOADS[args.workload]
     batch = args.batch or default_batch
     L = _lib.lib()
@@ -175,14 +179,20 @@ def main():
     torch.cuda.synchronize()
     net.set_option("time_launches", 0)
     nstats = net.last_call_stats()
-    n_std, us_std, fl_std = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-    n_sk, us_sk, fl_sk = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-    L.pnn_launch_times(net.ctx, 0, ctypes.byref(n_std), ctypes.byref(us_std), ctypes.byref(fl_std))
-    L.pnn_launch_times(net.ctx, 1, ctypes.byref(n_sk), ctypes.byref(us_sk), ctypes.byref(fl_sk))
-    # Dominant kernel = tapgemm_kernel (the LDS-staged MFMA tap GEMM); the small-M split-K kernel is listed beside it.
-    gemm_flops_per_launch = fl_std.value / max(n_std.value, 1)
-    avg_launch_s = us_std.value * 1e-6 / max(n_std.value, 1)
+    kinds = {}
+    for kind, name in ((0, "tapgemm_kernel (exact f32 MFMA 16x16x4, LDS-staged weights)"),
+                       (1, "tapgemm_splitk_kernel (f32 MFMA, small M)"),
+                       (2, "tapgemm_sp_kernel (f32-class split products on 3 x f16 MFMA 32x32x16, LDS-staged operands)")):
+        n_k, us_k, fl_k = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        L.pnn_launch_times(net.ctx, kind, ctypes.byref(n_k), ctypes.byref(us_k), ctypes.byref(fl_k))
+        kinds[kind] = {"kernel": name, "launches_timed": n_k.value, "total_us": us_k.value, "flops": fl_k.value}
+    dom = max(kinds, key=lambda k: kinds[k]["total_us"])          # dominant kernel of this workload
+    gemm_flops_per_launch = kinds[dom]["flops"] / max(kinds[dom]["launches_timed"], 1)
+    avg_launch_s = kinds[dom]["total_us"] * 1e-6 / max(kinds[dom]["launches_timed"], 1)
     achieved_tflops = gemm_flops_per_launch / avg_launch_s / 1e12
+    # peak: exact-f32 MFMA 157.3 TFLOP/s; the split-precision kernel issues three f16 MFMAs (2.5 PFLOP/s dense) per
+    # algorithmic product, so its roof in algorithmic FLOPs is 2500 / 3.
+    peak_tflops = PEAK_F32_MFMA_TFLOPS if dom != 2 else PEAK_F16_MFMA_TFLOPS / 3.0
     other_launches = nstats["launches"] - nstats["gemm_launches"]
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # PMC pass results (FETCH_SIZE x2 + WRITE_SIZE, per launch)
@@ -220,7 +230,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": precision_name,
             "data": "synthetic",
             "config": {"workload": cfg_name, "width": width, "arch": "fully_connected" if is_fc else "convolutional",
                        "batch_per_gpu": batch, "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
@@ -228,13 +238,18 @@ def main():
                        "parallelism": "independent blocks sharded over ranks, no data-path collective"},
             "launches_per_step": stats["launches"],
             "max_abs_lsb_vs_oracle": parity,
-            "roofline": {"bound": "mfma", "kernel": "tapgemm_kernel (f32 MFMA, LDS-staged weights)", "achieved": achieved_tflops,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": kinds[dom]["kernel"], "achieved": achieved_tflops,
+                         "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
                          "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": gemm_flops_per_launch,
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_std.value,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": kinds[dom]["launches_timed"],
+                         "peak_note": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if dom == 2
+                                       else "f32 dense MFMA peak at 2.4 GHz"),
+                         "frac_of_f32_mfma_peak": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
                          "gemm_launches_per_pass": nstats["gemm_launches"], "non_gemm_launches_per_pass": other_launches,
-                         "splitk_kernel": {"launches_timed": n_sk.value, "avg_launch_us": us_sk.value / max(n_sk.value, 1),
-                                           "tflops": fl_sk.value / max(us_sk.value, 1e-9) / 1e6},
+                         "other_gemm_kernels": [{"kernel": v["kernel"], "launches_timed": v["launches_timed"],
+                                                 "avg_launch_us": v["total_us"] / max(v["launches_timed"], 1),
+                                                 "tflops": v["flops"] / max(v["total_us"], 1e-9) / 1e6}
+                                                for k, v in kinds.items() if k != dom and v["launches_timed"]],
                          "algorithmic_flops_per_block": flops_per_block(width, is_fc)},
             "cpu_baseline": cpu,
         }

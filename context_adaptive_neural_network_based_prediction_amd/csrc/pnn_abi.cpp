@@ -49,6 +49,8 @@ struct DevBuf {
 struct GemmLayer {                                    // one tap-GEMM launch (all classes)
     TapGemmParams proto{};
     float* d_w = nullptr;
+    float* d_w_sp = nullptr;                          // split-precision pack: f16 hi/lo, pre-scaled by 2^sp_shift
+    float sp_inv_scale = 1.f;
     float* d_bias = nullptr;
     double k_total = 0;                               // sum over classes of taps * Cin
     long out_per_block = 0;                           // output floats per block
@@ -85,6 +87,8 @@ struct pnn_ctx {
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
+    long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
+    long opt_sp_cfg = -1;
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
     struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
     std::vector<LaunchRec> launch_recs;
@@ -148,6 +152,25 @@ std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad
     return out;
 }
 
+// Split-precision pack: [K/16][hl = hi/lo][h = k-half][Npad][8 x f16] with w * scale = hi + lo.
+std::vector<float> pack_kn_split(const std::vector<float>& kn, long K, int N, int npad, float scale)
+{
+    std::vector<float> out((size_t)K * npad, 0.f);              // same byte count as the f32 pack
+    _Float16* o = reinterpret_cast<_Float16*>(out.data());
+    for (long k = 0; k < K; k++) {
+        const long ch = k >> 4; const int h = (k >> 3) & 1, j = k & 7;
+        const float* src = kn.data() + (size_t)k * N;
+        for (int n = 0; n < N; n++) {
+            const float w = src[n] * scale;
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            o[((((size_t)ch * 2 + 0) * 2 + h) * npad + n) * 8 + j] = hi;
+            o[((((size_t)ch * 2 + 1) * 2 + h) * npad + n) * 8 + j] = lo;
+        }
+    }
+    return out;
+}
+
 int npad_for(int cout) { return ((cout + 15) / 16) * 16 + 160; }   // slack >= the widest column tile (BN = 160)
 
 // Common tail of the three layer builders. `kn` holds the [K][Cout] rows ordered (class, tap, ci) and
@@ -176,6 +199,18 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
     std::vector<float> packed = pack_kn(padded, chunk * 16, Cout, npad);
     int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
     if (rc) return rc;
+    {   // split-precision copy: scale so that max |w| lands in [2^12, 2^13) (hi and lo halves both f16-normal)
+        float wmax = 0.f;
+        for (float v : padded) wmax = std::max(wmax, std::fabs(v));
+        int shift = 0;
+        if (wmax > 0.f) { int e; std::frexp(wmax, &e); shift = 13 - e; }
+        shift = std::max(-8, std::min(shift, 24));
+        const float scale = std::ldexp(1.f, shift);
+        L->sp_inv_scale = std::ldexp(1.f, -shift);
+        std::vector<float> sp = pack_kn_split(padded, chunk * 16, Cout, npad, scale);
+        rc = upload(c, m, sp.data(), sp.size(), &L->d_w_sp);
+        if (rc) return rc;
+    }
     std::vector<float> bias(((Cout + 3) / 4) * 4 + 4, 0.f);
     std::copy(b, b + Cout, bias.begin());
     rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
@@ -444,6 +479,81 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     return PNN_OK;
 }
 
+// Split-precision launch (3 x f16 MFMA): activations as two f16 planes, outputs f32 and/or two f16 planes.
+int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
+{
+    const int cpt = cin / 16;
+    const bool one_tap = (k_total == (double)cin);
+    if (c->opt_sp_cfg >= 0 && c->opt_sp_cfg < tapgemm_sp_num_cfgs()) {
+        const TileCfg t = tapgemm_sp_cfg((int)c->opt_sp_cfg);
+        if (one_tap || cpt % t.kc == 0) return (int)c->opt_sp_cfg;
+    }
+    int best = -1;
+    double best_cost = 1e300;
+    for (int i = 0; i < tapgemm_sp_num_cfgs(); i++) {
+        const TileCfg t = tapgemm_sp_cfg(i);
+        if (!one_tap && cpt % t.kc) continue;
+        const long bm = 128L * t.rt, bn = 32L * t.nt;
+        const long tm = (M + bm - 1) / bm, tn = (cout + bn - 1) / bn;
+        const double wgs = (double)tm * tn * ncls;
+        // calibrated on device sweeps (tools/sp_check.py, tools/sp_prof.py): time ~ padded work x (1 + 2/NT) (operand
+        // traffic per MFMA), mild tail quantisation, RT = 2 and KC = 4 lose a resident workgroup, KC = 1 adds barriers
+        const double per_cu = wgs / 256.0;
+        const double fill = 1.0 + 0.3 * std::max(0.0, 1.5 - per_cu);              // under-filled chip: no co-resident workgroup
+        const double pad = (double)(tm * bm) * (tn * bn) / ((double)M * cout);
+        const double reuse = 1.0 + 2.0 / t.nt;
+        const double shape = (t.rt == 2 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
+        const double cost = fill * pad * reuse * shape;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best < 0 ? 0 : best;
+}
+
+int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
+                long nblocks, hipStream_t s)
+{
+    TapGemmParams p = L.proto;
+    p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp; p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
+    p.mean = c->mean; p.out_scale = L.sp_inv_scale;
+    const long M = nblocks * p.SH * p.SW;
+    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
+    p.M = (int)M;
+    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
+    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation plane of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
+    p.x_bytes = (unsigned)xb;
+    const int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    static const bool debug = getenv("PNN_DEBUG") != nullptr;
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;
+    const TileCfg t = tapgemm_sp_cfg(cfg);
+    if (debug) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc);
+    if (profile || c->opt_time_launches) {
+        pnn_ctx::LaunchRec r;
+        HIPCHK(c, hipEventCreate(&r.e0));
+        HIPCHK(c, hipEventCreate(&r.e1));
+        r.kind = 2;
+        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
+        HIPCHK(c, hipEventRecord(r.e0, s));
+        HIPCHK(c, launch_tapgemm_sp(p, cfg, s));
+        HIPCHK(c, hipEventRecord(r.e1, s));
+        if (profile) {
+            HIPCHK(c, hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        } else {
+            c->launch_recs.push_back(r);
+        }
+    } else {
+        HIPCHK(c, launch_tapgemm_sp(p, cfg, s));
+    }
+    c->stat_gemm_launches++; c->stat_launches++;
+    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    return PNN_OK;
+}
+
 long chunk_blocks(const pnn_ctx* c, const Model* m)
 {
     const double per_block = 4.0 * (m->is_fc ? 2.0 * kHidden : 2.0 * m->pmax + 80.0 * m->C);
@@ -459,7 +569,9 @@ int ensure_ws(pnn_ctx* c, const Model* m, long nb)
     int rc;
     if ((rc = dev_reserve(c, c->ws[0], (size_t)nb * m->pmax * 4))) return rc;
     if ((rc = dev_reserve(c, c->ws[1], (size_t)nb * m->pmax * 4))) return rc;
-    if (!m->is_fc) {
+    if (m->is_fc) {
+        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 5 * m->width * m->width * 4))) return rc;   // split-precision input planes
+    } else {
         if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 48 * m->C * 4))) return rc;
         if ((rc = dev_reserve(c, c->ws[3], (size_t)nb * 32 * m->C * 4))) return rc;
     }
@@ -484,6 +596,17 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, long nb, float* d_out, int
 {
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
     int rc;
+    if (c->opt_precision == 1) {
+        // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32)
+        const long nin = nb * 5L * m->width * m->width;
+        void* S = c->ws[2].p;
+        HIPCHK(c, launch_split(d_ctx, nin, S, nullptr, s));
+        c->stat_launches++;
+        if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
+        if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
+        if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
+        return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
+    }
     if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
     if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
     if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
@@ -495,6 +618,9 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
 {
     float* P[2] = {(float*)c->ws[0].p, (float*)c->ws[1].p};
     float* F[2] = {(float*)c->ws[2].p, (float*)c->ws[3].p};
+    // Split-precision mode: tensors between two tap GEMMs travel in the split f16 layout (same byte count as f32);
+    // tensors consumed by the merger / the last transposed convolution stay f32.
+    const bool sp = c->opt_precision == 1;
     int rc;
     for (int br = 0; br < 2; br++) {
         const size_t nl = m->branch[br].size();
@@ -503,21 +629,30 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         f.B = (int)nb;
         int cur = 0;
         f.Y = nl == 0 ? F[br] : P[cur];
+        f.split = (sp && nl > 0) ? 1 : 0;
         HIPCHK(c, launch_conv_cin1(f, s));
         c->stat_launches++;
         for (size_t i = 0; i < nl; i++) {
-            float* dst = (i + 1 == nl) ? F[br] : P[cur ^ 1];
-            if ((rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s))) return rc;
+            const bool last = i + 1 == nl;
+            float* dst = last ? F[br] : P[cur ^ 1];
+            if (sp) rc = run_gemm_sp(c, m->branch[br][i], P[cur], nullptr, last ? dst : nullptr, last ? nullptr : dst, nullptr, nullptr, nb, s);
+            else rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s);
+            if (rc) return rc;
             cur ^= 1;
         }
     }
+    const size_t nt = m->tconv.size();
     MergerParams mp = m->merger.proto;
     mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
+    mp.split = (sp && nt > 0) ? 1 : 0;
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;
     int cur = 0;
-    for (size_t i = 0; i < m->tconv.size(); i++) {
-        if ((rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s))) return rc;
+    for (size_t i = 0; i < nt; i++) {
+        const bool last = i + 1 == nt;
+        if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, last ? P[cur ^ 1] : nullptr, last ? nullptr : P[cur ^ 1], nullptr, nullptr, nb, s);
+        else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s);
+        if (rc) return rc;
         cur ^= 1;
     }
     TConv1Params tp = m->last.proto;
@@ -632,6 +767,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     }
     if (const char* e = getenv("PNN_TILE_CFG")) c->opt_tile_cfg = atol(e);
     if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
+    if (const char* e = getenv("PNN_PRECISION")) c->opt_precision = atol(e);
     *out = c;
     return PNN_OK;
 }
@@ -739,6 +875,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
     else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
     else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
+    else if (!strcmp(name, "precision")) c->opt_precision = value;
+    else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
     return PNN_OK;

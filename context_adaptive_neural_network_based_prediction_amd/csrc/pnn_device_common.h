@@ -17,4 +17,25 @@ __device__ __forceinline__ int hm_round(float p, float mean)
     return (int)roundf(v);
 }
 
+// Split activation layout of the split-precision GEMM: element (pixel, channel n) of a [pixels][C] tensor lives at
+// f16 index 2*pixel*C + (n/16)*32 + n%16 (hi) and +16 (lo); x = hi + lo with hi = (f16) x, lo = (f16)(x - hi).
+__device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, int n, f32x4 v)
+{
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+    _Float16* dst = reinterpret_cast<_Float16*>(base) + 2 * pixel_times_c + (n >> 4) * 32 + (n & 15);
+    *reinterpret_cast<h4*>(dst) = hi;
+    *reinterpret_cast<h4*>(dst + 16) = lo;
+}
+
+__device__ __forceinline__ void store_split1(void* base, size_t pixel_times_c, int n, float v)
+{
+    const _Float16 hi = (_Float16)v;
+    _Float16* dst = reinterpret_cast<_Float16*>(base) + 2 * pixel_times_c + (n >> 4) * 32 + (n & 15);
+    dst[0] = hi;
+    dst[16] = (_Float16)(v - (float)hi);
+}
+
 }  // namespace pnn

@@ -1,0 +1,287 @@
+// Split-precision tap GEMM: f32-class accuracy on the f16 matrix cores (v_mfma_f32_32x32x16_f16).
+//
+// Every f32 operand x is carried as two halves, x = hi + lo with hi = (f16) x and lo = (f16)(x - hi), i.e. 22
+// mantissa bits; a product a*w is formed as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (each f16 x f16 product is exact in
+// the MFMA's f32 accumulator; only the ~2^-22 lo*lo term is dropped).  Three f16 MFMAs (3 x 32 cycles for a
+// 32x32x16 block) replace eight f32 MFMAs (8 x 64 cycles): 5.3x fewer matrix-pipe cycles for the same result
+// within float rounding.  Weights are pre-scaled by a per-layer power of two so that their lo halves stay in the
+// f16 normal range; the scale is undone exactly in the epilogue.
+//
+// Same contract as tapgemm_kernel (TapGemmParams): FC layers, convolutions, transposed convolutions of
+// pnn/components.py:10-261.  Activations arrive as two f16 planes [pixel][Cin] (X = hi, Xlo = lo), written that way
+// by the producing layer's epilogue (Yhi) or by split_kernel for network inputs.
+//
+//   workgroup = 256 threads = 4 waves; wave w owns rows [32*RT*w, 32*RT*(w+1)) and all BN = 32*NT columns.
+//   MFMA roles: "A" = weights (i = n), "B" = activations (j = m); lane l = (l&31, h = l>>5) supplies k = 8h + j.
+//   Packed weights per 16-deep chunk: [hl = hi/lo][h][Npad][8 x f16] = four planes of Npad x 16 bytes -- the same
+//   plane geometry as the f32 kernels' [q = 4][Npad][4 x f32], so staging and LDS addressing are shared.
+#include "pnn_kernels.h"
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int RT, int NT, int KC>
+__global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
+{
+    constexpr int BM = 128 * RT;
+    constexpr int BN = 32 * NT;
+    constexpr int E = 4 * BN;                       // 16-byte slots per staged weight chunk
+    constexpr int NLD = (E + 255) / 256;
+    constexpr int PPR = KC * 4;                     // 16-byte pieces per activation row and stage (64 B per chunk)
+    constexpr int APITCH = PPR + 1;                 // LDS row pitch in 16-byte slots: +1 keeps b128 reads conflict-free
+    constexpr int NLA = BM * PPR / 256;             // activation pieces per thread and stage
+    __shared__ f32x4 Bs[2][KC][E];
+    __shared__ f32x4 As[2][BM * APITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int mblk = blockIdx.x * BM;
+    const int SP = p.SH * p.SW;
+
+    // Rows this THREAD stages (full 64*KC-byte runs per row: PPR consecutive lanes share a row).
+    int lb[NLA], li[NLA], lj[NLA];
+    bool lv[NLA];
+    const int lpiece = tid % PPR;
+#pragma unroll
+    for (int r = 0; r < NLA; r++) {
+        const int mg = mblk + (tid + 256 * r) / PPR;
+        lv[r] = mg < p.M;
+        const int mc = lv[r] ? mg : 0;
+        const int b = mc / SP;
+        const int q = mc - b * SP;
+        lb[r] = b;
+        li[r] = q / p.SW;
+        lj[r] = q - li[r] * p.SW;
+    }
+
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const int nstages = (nchunks + KC - 1) / KC;
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
+
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
+
+    // Activations: [pixel][Cin/16][hi 16 x f16 | lo 16 x f16] -- 64 B per 16-deep chunk, so a stage is one
+    // contiguous 64*KC-byte run per row.  Out-of-image taps / rows past M read zeros (descriptor range check).
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+    unsigned aoff[NLA];
+    auto tap_setup = [&](int tp) {
+        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+        for (int r = 0; r < NLA; r++) {
+            const int iy = li[r] * p.a + dy, ix = lj[r] * p.a + dx;
+            const bool ok = lv[r] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            const unsigned off = (((unsigned)((lb[r] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) + (lpiece << 4);
+            aoff[r] = ok ? off : 0x80000000u;
+        }
+    };
+    auto load_a = [&](int cc, f32x4 (&dst)[NLA]) {
+        // the tail stage of a single-tap layer may run past the last chunk: those pieces multiply zero weights,
+        // clamp them onto the last valid chunk so they stay finite.
+        int sc = cc;
+        if (cc + (lpiece >> 2) >= cpt) sc = cpt - 1 - (lpiece >> 2);
+#pragma unroll
+        for (int r = 0; r < NLA; r++)
+            dst[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[r] + (unsigned)(sc << 6), 0, 0));
+    };
+    auto store_a = [&](int buf, const f32x4 (&src)[NLA]) {
+#pragma unroll
+        for (int r = 0; r < NLA; r++) As[buf][((tid + 256 * r) / PPR) * APITCH + lpiece] = src[r];
+    };
+    const f32x4* bsrc[NLD];
+    int bdst[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+        int e = tid + 256 * r;
+        if (E % 256 != 0) e = e < E ? e : E - 1;
+        const int qq = e / BN, nn = e - qq * BN;
+        bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+        bdst[r] = e;
+    }
+    const size_t bstride = (size_t)4 * p.Npad;
+    auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
+#pragma unroll
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) dst[j][r] = bsrc[r][(size_t)(stage * KC + j) * bstride];
+    };
+    auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
+#pragma unroll
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) Bs[buf][j][bdst[r]] = src[j][r];
+    };
+    auto read_frags = [&](int buf, int j, f32x4 (&wf)[NT][2], f32x4 (&af)[RT][2]) {   // [..][0] = hi, [..][1] = lo
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            wf[nt][0] = Bs[buf][j][(0 + h) * BN + nt * 32 + l31];
+            wf[nt][1] = Bs[buf][j][(2 + h) * BN + nt * 32 + l31];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int row = wave * (32 * RT) + rt * 32 + l31;
+            af[rt][0] = As[buf][row * APITCH + j * 4 + 0 + h];
+            af[rt][1] = As[buf][row * APITCH + j * 4 + 2 + h];
+        }
+    };
+    auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2], int part) {
+        // part 0: hi*hi;  part 1: the two cross terms
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const f16x8 whi = __builtin_bit_cast(f16x8, wf[nt][0]), wlo = __builtin_bit_cast(f16x8, wf[nt][1]);
+                const f16x8 ahi = __builtin_bit_cast(f16x8, a[rt][0]), alo = __builtin_bit_cast(f16x8, a[rt][1]);
+                if (part == 0) {
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[rt][nt], 0, 0, 0);
+                } else {
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[rt][nt], 0, 0, 0);
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc[rt][nt], 0, 0, 0);
+                }
+            }
+    };
+
+    // Two-stage pipeline, one barrier per KC chunks: both operands travel global -> registers -> LDS in full
+    // cache lines; MFMA fragments are read from LDS (double-buffered in registers across chunks).
+    // (Fetching two stages ahead through a second register set was measured 30-50 % SLOWER: the extra 32 VGPRs
+    // cost a resident workgroup per CU, which hides more latency than the deeper prefetch does.)
+    f32x4 a_stage[NLA], b_stage[KC][NLD];
+    int t = t0, cc = 0;
+    tap_setup(p.tap[t0]);
+    int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
+    load_a(0, a_stage);
+    load_b(0, b_stage);
+    store_a(0, a_stage);
+    store_b(0, b_stage);
+    __syncthreads();
+    for (int s = 0; s < nstages; s++) {
+        const int buf = s & 1;
+        f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
+        read_frags(buf, 0, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = s + 1 < nstages;
+        if (more) {
+            cc += KC;
+            if (cc >= cpt) {
+                cc = 0;
+                ++t;
+                tap_setup(tp_next);
+                tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
+            }
+        }
+        load_a(cc, a_stage);
+        load_b(more ? s + 1 : s, b_stage);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j + 1 < KC; j++) {
+            if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); }
+            else       { read_frags(buf, j + 1, wf1, af1); mfma_chunk(wf0, af0, 0); mfma_chunk(wf0, af0, 1); }
+        }
+        if ((KC - 1) & 1) { mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); } else { mfma_chunk(wf0, af0, 0); mfma_chunk(wf0, af0, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(buf ^ 1, a_stage);                   // after ALL of the stage's MFMAs: the loads get the whole stage to land
+        store_b(buf ^ 1, b_stage);
+        __syncthreads();
+    }
+
+    // Epilogue: undo the weight scale, bias (+ LeakyReLU); f32 and/or split-f16 outputs (and the HM epilogue).
+    const int py = p.py[cls], px = p.px[cls];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int mg = mblk + wave * (32 * RT) + rt * 32 + l31;
+        if (mg >= p.M) continue;
+        const int pbq = mg / SP;
+        const int rq = mg - pbq * SP;
+        const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+        const int oy = piq * p.os + py, ox = pjq * p.os + px;
+        const size_t opix = ((size_t)pbq * p.OH + oy) * p.OW + ox;
+        const size_t obase = opix * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + nt * 32 + 8 * g + 4 * h;
+                if (n < p.Cout) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
+                    if (p.act) {
+                        v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    }
+                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                    if (p.Yhi) store_split4(p.Yhi, obase, n, v);   // split output for the next split-precision layer
+                    if (p.Yi) {
+                        int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                            hm_round(v[3], p.mean));
+                        *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                    }
+                }
+            }
+    }
+}
+
+#define PNN_SP_CFGS(X) X(1, 4, 2) X(1, 4, 4) X(1, 2, 2) X(1, 2, 4) X(2, 2, 2) X(2, 4, 2) X(1, 4, 1) X(1, 3, 2) X(1, 5, 2) X(2, 2, 1)
+
+static const TileCfg kCfgsSp[] = {
+#define X(rt, nt, kc) {rt, nt, kc, 316},            // mf 316: "3 x f16 32x32x16"
+    PNN_SP_CFGS(X)
+#undef X
+};
+
+int tapgemm_sp_num_cfgs() { return (int)(sizeof(kCfgsSp) / sizeof(kCfgsSp[0])); }
+TileCfg tapgemm_sp_cfg(int idx) { return kCfgsSp[idx]; }
+
+template <int RT, int NT, int KC>
+static hipError_t launch_sp(const TapGemmParams& p, hipStream_t s)
+{
+    dim3 grid((p.M + 128 * RT - 1) / (128 * RT), (p.Cout + 32 * NT - 1) / (32 * NT), p.ncls);
+    hipLaunchKernelGGL((tapgemm_sp_kernel<RT, NT, KC>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    int i = 0;
+#define X(rt, nt, kc) if (idx == i++) return launch_sp<rt, nt, kc>(p, s);
+    PNN_SP_CFGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+// f32 [rows][C] -> split activations [rows][C/16][hi 16 x f16 | lo 16 x f16] for network inputs (C % 16 == 0).
+__global__ __launch_bounds__(256) void split_kernel(const float* x, long n, _Float16* out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        const _Float16 hv = (_Float16)v;
+        _Float16* d = out + 2 * (i & ~15L) + (i & 15);
+        d[0] = hv;
+        d[16] = (_Float16)(v - (float)hv);
+    }
+}
+
+hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s)
+{
+    (void)lo;
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, (_Float16*)hi);
+    return hipGetLastError();
+}
+
+}  // namespace pnn

@@ -18,11 +18,15 @@ constexpr int kMaxClasses = 4;
 // Weights are pre-packed per 16-deep K chunk as [chunk][q = 4][Npad][4] floats (k = 16*chunk + 4*q + e),
 // the order in which one 16x16x4 f32 MFMA lane group consumes them.
 struct TapGemmParams {
-    const float* X;
+    const float* X;    // f32 activations, or the hi f16 plane for the split-precision kernel
+    const void* Xlo;   // lo f16 plane (split-precision kernel only)
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
     int32_t* Yi;       // optional fused HM epilogue: (int) round(clamp(v + mean, 0, 255))
+    void* Yhi;         // optional split-f16 output planes (split-precision kernel only)
+    void* Ylo;
+    float out_scale;   // split-precision kernel: exact power of two undoing the weight pre-scale
     unsigned x_bytes;  // size of X in bytes (< 2^31): bound of the activation buffer descriptor
     int M, SH, SW;
     int IH, IW, Cin, a;
@@ -44,6 +48,10 @@ struct TileCfg { int rt, nt, kc, mf; };   // mf: MFMA shape, 16 (16x16x4, BM = 6
 int tapgemm32_num_cfgs();
 TileCfg tapgemm32_cfg(int idx);
 hipError_t launch_tapgemm32(const TapGemmParams& p, int idx, hipStream_t s);
+int tapgemm_sp_num_cfgs();
+TileCfg tapgemm_sp_cfg(int idx);
+hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s);   // 3 x f16 MFMA, f32-class accuracy
+hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
@@ -52,6 +60,7 @@ hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
 struct Conv1Params {
     const float* X; const float* W; const float* bias; float* Y;
     int B, IH, IW, s, k, pad, OH, OW, Cout;
+    int split;   // 1: write Y as split activations [pixel][Cout/16][hi 16 x f16 | lo 16 x f16] for the split-precision GEMM
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 
@@ -67,6 +76,7 @@ hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s);
 struct MergerParams {
     const float* A; const float* L; const float* Wp; const float* bias /* [j][C] */; float* Y;
     int B, C, na, nl, nout;
+    int split;   // 1: write Y in the split f16 activation layout
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);
 

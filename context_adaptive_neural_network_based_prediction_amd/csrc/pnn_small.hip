@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
 #pragma unroll
             for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
         acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-        *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
+        if (p.split) store_split4(p.Y, ((size_t)b * npix + pix) * p.Cout, 4 * cg, acc);
+        else *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
     }
 }
 
@@ -210,7 +211,11 @@ __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
         const float bv = p.bias[(size_t)(4 * jq + j) * p.C + c];
 #pragma unroll
         for (int m = 0; m < kMergerMB; m++)
-            if (b0 + m < p.B) p.Y[((b0 + m) * 16 + 4 * jq + j) * p.C + c] = leaky(acc[m][j] + bv);
+            if (b0 + m < p.B) {
+                const float v = leaky(acc[m][j] + bv);
+                if (p.split) store_split1(p.Y, ((size_t)(b0 + m) * 16 + 4 * jq + j) * p.C, c, v);
+                else p.Y[((b0 + m) * 16 + 4 * jq + j) * p.C + c] = v;
+            }
     }
 }
 

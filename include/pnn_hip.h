@@ -62,7 +62,9 @@ void pnn_destroy(pnn_ctx* ctx);
 const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last error of a failed create */
 float pnn_mean(const pnn_ctx* ctx);
 
-/* Options: "tile_cfg" (-1 = automatic), "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb",
+/* Options: "precision" (1, default: tap GEMMs form every f32 product from three f16 MFMAs on hi/lo operand halves --
+ * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice),
+ * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
  * pair needs; 0 (default) lets small batches use the faster split-K kernel, whose float result can differ in

@@ -24,6 +24,14 @@ def pnn():
     return P
 
 
+@pytest.fixture(autouse=True, params=["f32", "split_f16"])
+def precision(request, monkeypatch):
+    """Every test runs on both arithmetic paths of the tap GEMMs: exact-f32 MFMA and the 3 x f16 split-product MFMA
+    (f32-class accuracy); the tolerances are the same for both."""
+    monkeypatch.setenv("PNN_PRECISION", "0" if request.param == "f32" else "1")
+    return request.param
+
+
 def _check_pel(got, want):
     diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
     assert diff.max() <= 1, "max |delta| = %d LSB" % diff.max()
