@@ -499,7 +499,7 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
         // calibrated on device sweeps (tools/sp_check.py, tools/sp_prof.py): time ~ padded work x (1 + 2/NT) (operand
         // traffic per MFMA), mild tail quantisation, RT = 2 and KC = 4 lose a resident workgroup, KC = 1 adds barriers
         const double per_cu = wgs / 256.0;
-        const double fill = 1.0 + 0.3 * std::max(0.0, 1.5 - per_cu);              // under-filled chip: no co-resident workgroup
+        const double fill = 1.0 + 0.4 * std::max(0.0, 1.5 - per_cu);              // under-filled chip: no co-resident workgroup
         const double pad = (double)(tm * bm) * (tn * bn) / ((double)M * cout);
         const double reuse = 1.0 + 2.0 / t.nt;
         const double shape = (t.rt == 2 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
@@ -592,16 +592,19 @@ Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
     return m;
 }
 
-int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
+int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
 {
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
     int rc;
     if (c->opt_precision == 1) {
         // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32)
         const long nin = nb * 5L * m->width * m->width;
-        void* S = c->ws[2].p;
-        HIPCHK(c, launch_split(d_ctx, nin, S, nullptr, s));
-        c->stat_launches++;
+        const void* S = d_ctx;                        // already in the split layout when the gather wrote it
+        if (!ctx_is_split) {
+            HIPCHK(c, launch_split(d_ctx, nin, c->ws[2].p, nullptr, s));
+            c->stat_launches++;
+            S = c->ws[2].p;
+        }
         if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
@@ -666,7 +669,7 @@ void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; 
 
 // Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
 int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
-            int32_t* d_dst, hipStream_t s)
+            int32_t* d_dst, hipStream_t s, bool ctx_is_split = false)
 {
     const int w = m->width;
     const long chunk = std::min(n, chunk_blocks(c, m));
@@ -676,7 +679,7 @@ int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d
         const long nb = std::min(chunk, n - b0);
         float* o = d_out ? d_out + b0 * w * w : nullptr;
         int32_t* di = d_dst ? d_dst + b0 * w * w : nullptr;
-        rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, nb, o, di, s)
+        rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, ctx_is_split, nb, o, di, s)
                       : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
         if (rc) return rc;
     }
@@ -974,6 +977,7 @@ int pnn_gather_device(pnn_ctx* c, int width, int unit, const void* d_plane, int 
     GatherParams g;
     g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs); g.N = n; g.w = width;
     g.unit = unit; g.mean = c->mean; g.above = d_above; g.left = d_left; g.pitch_above = pitch_above; g.pitch_left = pitch_left;
+    g.split = 0;
     HIPCHK(c, launch_gather(g, (hipStream_t)stream));
     return PNN_OK;
 }
@@ -997,9 +1001,14 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
         float* ab = ctxbuf;
         float* lf = m->is_fc ? ctxbuf + 3 * w2 : ctxbuf + nb * 3 * w2;
         const long pa = m->is_fc ? 5 * w2 : 3 * w2, pl = m->is_fc ? 5 * w2 : 2 * w2;
-        if ((rc = pnn_gather_device(c, width, 4, d_plane, pel_bytes, d_tbs + b0, (int)nb, ab, pa, lf, pl, s))) return rc;
+        const bool split_ctx = m->is_fc && c->opt_precision == 1;   // the FC chain starts on the split-precision GEMM
+        GatherParams g;
+        g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs + b0); g.N = (int)nb; g.w = width;
+        g.unit = 4; g.mean = c->mean; g.above = ab; g.left = lf; g.pitch_above = pa; g.pitch_left = pl; g.split = split_ctx ? 1 : 0;
+        HIPCHK(c, launch_gather(g, s));
         c->stat_launches++;
-        if ((rc = run_net(c, m, ab, pa, lf, pl, nb, d_out_f32 ? d_out_f32 + b0 * w2 : nullptr, d_dst ? d_dst + b0 * w2 : nullptr, s)))
+        if ((rc = run_net(c, m, ab, pa, lf, pl, nb, d_out_f32 ? d_out_f32 + b0 * w2 : nullptr, d_dst ? d_dst + b0 * w2 : nullptr, s,
+                          split_ctx)))
             return rc;
     }
     return PNN_OK;

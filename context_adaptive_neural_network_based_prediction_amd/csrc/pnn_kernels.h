@@ -91,6 +91,7 @@ struct TbDev {           // mirrors pnn_tb_dev of include/pnn_hip.h
 struct GatherParams {
     const void* plane; int pel_bytes; const TbDev* tbs; int N; int w; int unit; float mean;
     float* above; float* left; long pitch_above; long pitch_left;
+    int split;   // 1 (FC layout only, one [5w^2] row per TB): write the split f16 activation layout instead of f32
 };
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);
 

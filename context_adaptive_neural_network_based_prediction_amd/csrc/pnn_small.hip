@@ -251,14 +251,16 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
             if (col >= w) ok = (d.above_mask >> ((col - w) / p.unit)) & 1u;
             float v = 0.f;
             if (ok) v = (float)plane[d.origin + (long)(row - w) * d.stride + (col - w)] - p.mean;
-            p.above[tb * p.pitch_above + r] = v;
+            if (p.split) store_split1(p.above, (size_t)tb * per, r, v);
+            else p.above[tb * p.pitch_above + r] = v;
         } else {
             const int rl = r - na;
             const int row = rl / w, col = rl - row * w;
             const bool ok = row < d.left_units * p.unit;
             float v = 0.f;
             if (ok) v = (float)plane[d.origin + (long)row * d.stride + (col - w)] - p.mean;
-            p.left[tb * p.pitch_left + rl] = v;
+            if (p.split) store_split1(p.above, (size_t)tb * per, r, v);          // FC row: left part follows the above part
+            else p.left[tb * p.pitch_left + rl] = v;
         }
     }
 }
