@@ -493,7 +493,7 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
     for (int i = 0; i < tapgemm_sp_num_cfgs(); i++) {
         const TileCfg t = tapgemm_sp_cfg(i);
         if (!one_tap && cpt % t.kc) continue;
-        const long bm = 128L * t.rt, bn = 32L * t.nt;
+        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
         const long tm = (M + bm - 1) / bm, tn = (cout + bn - 1) / bn;
         const double wgs = (double)tm * tn * ncls;
         // calibrated on device sweeps (tools/sp_check.py, tools/sp_prof.py): time ~ padded work x (1 + 2/NT) (operand
@@ -501,8 +501,8 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
         const double per_cu = wgs / 256.0;
         const double fill = 1.0 + 0.4 * std::max(0.0, 1.5 - per_cu);              // under-filled chip: no co-resident workgroup
         const double pad = (double)(tm * bm) * (tn * bn) / ((double)M * cout);
-        const double reuse = 1.0 + 2.0 / t.nt;
-        const double shape = (t.rt == 2 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
+        const double reuse = 1.0 + 2.0 / (t.nt * (4 / t.wm));
+        const double shape = (t.rt * t.wm >= 8 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
         const double cost = fill * pad * reuse * shape;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }

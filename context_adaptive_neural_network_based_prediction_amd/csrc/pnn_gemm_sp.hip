@@ -11,7 +11,8 @@
 // pnn/components.py:10-261.  Activations arrive as two f16 planes [pixel][Cin] (X = hi, Xlo = lo), written that way
 // by the producing layer's epilogue (Yhi) or by split_kernel for network inputs.
 //
-//   workgroup = 256 threads = 4 waves; wave w owns rows [32*RT*w, 32*RT*(w+1)) and all BN = 32*NT columns.
+//   workgroup = 256 threads = 4 waves arranged WM x WN; a wave owns a (32*RT) x (32*NT) tile of the
+//   (32*RT*WM) x (32*NT*WN) workgroup tile.
 //   MFMA roles: "A" = weights (i = n), "B" = activations (j = m); lane l = (l&31, h = l>>5) supplies k = 8h + j.
 //   Packed weights per 16-deep chunk: [hl = hi/lo][h][Npad][8 x f16] = four planes of Npad x 16 bytes -- the same
 //   plane geometry as the f32 kernels' [q = 4][Npad][4 x f32], so staging and LDS addressing are shared.
@@ -24,11 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int RT, int NT, int KC>
+template <int RT, int NT, int KC, int WM>
 __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
 {
-    constexpr int BM = 128 * RT;
-    constexpr int BN = 32 * NT;
+    constexpr int WN = 4 / WM;                      // waves along N (WM x WN = 4 waves)
+    constexpr int BM = 32 * RT * WM;
+    constexpr int BN = 32 * NT * WN;
     constexpr int E = 4 * BN;                       // 16-byte slots per staged weight chunk
     constexpr int NLD = (E + 255) / 256;
     constexpr int PPR = KC * 4;                     // 16-byte pieces per activation row and stage (64 B per chunk)
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int cls = blockIdx.z;
     const int n0 = blockIdx.y * BN;
@@ -128,12 +131,12 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     auto read_frags = [&](int buf, int j, f32x4 (&wf)[NT][2], f32x4 (&af)[RT][2]) {   // [..][0] = hi, [..][1] = lo
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            wf[nt][0] = Bs[buf][j][(0 + h) * BN + nt * 32 + l31];
-            wf[nt][1] = Bs[buf][j][(2 + h) * BN + nt * 32 + l31];
+            wf[nt][0] = Bs[buf][j][(0 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
+            wf[nt][1] = Bs[buf][j][(2 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
         }
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-            const int row = wave * (32 * RT) + rt * 32 + l31;
+            const int row = wm * (32 * RT) + rt * 32 + l31;
             af[rt][0] = As[buf][row * APITCH + j * 4 + 0 + h];
             af[rt][1] = As[buf][row * APITCH + j * 4 + 2 + h];
         }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     const int py = p.py[cls], px = p.px[cls];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
-        const int mg = mblk + wave * (32 * RT) + rt * 32 + l31;
+        const int mg = mblk + wm * (32 * RT) + rt * 32 + l31;
         if (mg >= p.M) continue;
         const int pbq = mg / SP;
         const int rq = mg - pbq * SP;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int n = n0 + nt * 32 + 8 * g + 4 * h;
+                const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
                 if (n < p.Cout) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
                     f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
@@ -233,10 +236,13 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     }
 }
 
-#define PNN_SP_CFGS(X) X(1, 4, 2) X(1, 4, 4) X(1, 2, 2) X(1, 2, 4) X(2, 2, 2) X(2, 4, 2) X(1, 4, 1) X(1, 3, 2) X(1, 5, 2) X(2, 2, 1)
+// X(rt, nt, kc, wm)
+#define PNN_SP_CFGS(X) \
+    X(1, 4, 2, 4) X(1, 4, 4, 4) X(1, 2, 2, 4) X(1, 2, 4, 4) X(2, 2, 2, 4) X(2, 4, 2, 4) X(1, 4, 1, 4) X(1, 3, 2, 4) X(1, 5, 2, 4) \
+    X(2, 2, 1, 4) X(2, 2, 2, 2) X(2, 1, 2, 2) X(1, 2, 2, 2) X(2, 2, 4, 2) X(2, 3, 2, 2) X(1, 1, 2, 2)
 
 static const TileCfg kCfgsSp[] = {
-#define X(rt, nt, kc) {rt, nt, kc, 316},            // mf 316: "3 x f16 32x32x16"
+#define X(rt, nt, kc, wm) {rt, nt, kc, 316, wm},     // mf 316: "3 x f16 32x32x16"
     PNN_SP_CFGS(X)
 #undef X
 };
@@ -244,11 +250,12 @@ static const TileCfg kCfgsSp[] = {
 int tapgemm_sp_num_cfgs() { return (int)(sizeof(kCfgsSp) / sizeof(kCfgsSp[0])); }
 TileCfg tapgemm_sp_cfg(int idx) { return kCfgsSp[idx]; }
 
-template <int RT, int NT, int KC>
+template <int RT, int NT, int KC, int WM>
 static hipError_t launch_sp(const TapGemmParams& p, hipStream_t s)
 {
-    dim3 grid((p.M + 128 * RT - 1) / (128 * RT), (p.Cout + 32 * NT - 1) / (32 * NT), p.ncls);
-    hipLaunchKernelGGL((tapgemm_sp_kernel<RT, NT, KC>), grid, dim3(256), 0, s, p);
+    constexpr int BM = 32 * RT * WM, BN = 32 * NT * (4 / WM);
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
+    hipLaunchKernelGGL((tapgemm_sp_kernel<RT, NT, KC, WM>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -256,7 +263,7 @@ hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s)
 {
     if (p.M <= 0) return hipSuccess;
     int i = 0;
-#define X(rt, nt, kc) if (idx == i++) return launch_sp<rt, nt, kc>(p, s);
+#define X(rt, nt, kc, wm) if (idx == i++) return launch_sp<rt, nt, kc, wm>(p, s);
     PNN_SP_CFGS(X)
 #undef X
     return hipErrorInvalidValue;

@@ -44,7 +44,7 @@ inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsi
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
 constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
-struct TileCfg { int rt, nt, kc, mf; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
+struct TileCfg { int rt, nt, kc, mf, wm = 4; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
 int tapgemm32_num_cfgs();
 TileCfg tapgemm32_cfg(int idx);
 hipError_t launch_tapgemm32(const TapGemmParams& p, int idx, hipStream_t s);

@@ -16,7 +16,7 @@ d_in = torch.from_numpy(ctx).cuda(); d_out = torch.empty((n, w, w), device="cuda
 sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for prec in (0, 1):
     net.set_option("precision", prec)
-    cfgs = [-1] if prec == 0 else [-1] + list(range(10))
+    cfgs = [-1] if prec == 0 else [-1] + [0, 2, 7, 8, 10, 11, 12, 13, 14, 15]
     for cfg in cfgs:
         if prec: net.set_option("sp_cfg", cfg)
         rc = L.pnn_predict_fc_device(net.ctx, w, d_in.data_ptr(), n, d_out.data_ptr(), sp)
