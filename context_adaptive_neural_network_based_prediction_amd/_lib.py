@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnn_hip.so")
+LIB_PATH = os.environ.get("PNN_LIB_PATH") or os.path.join(_HERE, "libpnn_hip.so")   # override: diagnostic builds
 
 f32p = ctypes.POINTER(ctypes.c_float)
 i32p = ctypes.POINTER(ctypes.c_int32)

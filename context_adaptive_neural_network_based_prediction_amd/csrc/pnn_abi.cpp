@@ -513,7 +513,12 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
                 long nblocks, hipStream_t s)
 {
     TapGemmParams p = L.proto;
-    p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp; p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
+    p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp;
+    static const bool diag = getenv("PNN_SP_DIAG") != nullptr;   // diagnostic library only: phase stamps of every workgroup
+    if (diag) {
+        if (dev_reserve(c, c->stage_tbs, (size_t)64 << 20)) return PNN_E_NOMEM;
+        p.Xlo = c->stage_tbs.p;
+    } p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
     p.mean = c->mean; p.out_scale = L.sp_inv_scale;
     const long M = nblocks * p.SH * p.SW;
     if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
@@ -548,6 +553,19 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         }
     } else {
         HIPCHK(c, launch_tapgemm_sp(p, cfg, s));
+    }
+    if (diag) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        const TileCfg tt = tapgemm_sp_cfg(cfg);
+        const long bm = 32L * tt.rt * tt.wm, bn = 32L * tt.nt * (4 / tt.wm);
+        const size_t nwg = (size_t)((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
+        std::vector<unsigned long long> h(4 * nwg);
+        HIPCHK(c, hipMemcpy(h.data(), c->stage_tbs.p, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < nwg; i++) for (int k = 0; k < 4; k++) sum[k] += (double)h[4 * i + k];
+        const double stages = std::ceil(L.k_total / 16.0 / p.ncls / tt.kc);
+        fprintf(stderr, "[pnn-diag] M=%ld K=%.0f N=%d cfg {%d,%d,%d,wm%d}: per stage (cycles, wave 0 mean over %zu WGs): issue %.0f  mfma %.0f  store %.0f  barrier %.0f\n",
+                M, L.k_total, p.Cout, tt.rt, tt.nt, tt.kc, tt.wm, nwg, sum[0] / nwg / stages, sum[1] / nwg / stages, sum[2] / nwg / stages, sum[3] / nwg / stages);
     }
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;

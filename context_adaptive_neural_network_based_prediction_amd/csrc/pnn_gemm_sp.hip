@@ -162,6 +162,24 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     // cache lines; MFMA fragments are read from LDS (double-buffered in registers across chunks).
     // (Fetching two stages ahead through a second register set was measured 30-50 % SLOWER: the extra 32 VGPRs
     // cost a resident workgroup per CU, which hides more latency than the deeper prefetch does.)
+#ifdef PNN_SP_DIAG
+    // Diagnostic build only (`make diag`, tools/sp_prof.py): per-phase cycle sums of wave 0 of every workgroup, written
+    // to the buffer passed in p.Xlo.  Findings on FC 1200x1200 (tile 128x128, 768 MFMA cycles per stage): ~740 cycles
+    // to issue the eight 1-KiB loads of a stage (the CU's 64 B/clk vector-memory path, shared by 8 waves), ~870 in the
+    // MFMA block, ~460 waiting for the loads + LDS stores, ~140 at the barrier.  Interleaving the loads with the MFMAs
+    // only moves the stall (in-order issue), prefetching two stages ahead costs a resident workgroup: both measured.
+    unsigned long long dg_t = 0, dg_issue = 0, dg_mfma = 0, dg_store = 0, dg_bar = 0;
+#define DG_STAMP(acc)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long now_;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory");       \
+        acc += now_ - dg_t; dg_t = now_;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define DG_STAMP(acc) do {} while (0)
+#endif
     f32x4 a_stage[NLA], b_stage[KC][NLD];
     int t = t0, cc = 0;
     tap_setup(p.tap[t0]);
@@ -171,6 +189,9 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     store_a(0, a_stage);
     store_b(0, b_stage);
     __syncthreads();
+#ifdef PNN_SP_DIAG
+    { unsigned long long d0_ = 0; DG_STAMP(d0_); (void)d0_; }
+#endif
     for (int s = 0; s < nstages; s++) {
         const int buf = s & 1;
         f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
         load_a(cc, a_stage);
         load_b(more ? s + 1 : s, b_stage);
         __builtin_amdgcn_sched_barrier(0);
+        DG_STAMP(dg_issue);
 #pragma unroll
         for (int j = 0; j + 1 < KC; j++) {
             if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); }
@@ -196,10 +218,19 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
         }
         if ((KC - 1) & 1) { mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); } else { mfma_chunk(wf0, af0, 0); mfma_chunk(wf0, af0, 1); }
         __builtin_amdgcn_sched_barrier(0);
+        DG_STAMP(dg_mfma);
         store_a(buf ^ 1, a_stage);                   // after ALL of the stage's MFMAs: the loads get the whole stage to land
         store_b(buf ^ 1, b_stage);
+        DG_STAMP(dg_store);
         __syncthreads();
+        DG_STAMP(dg_bar);
     }
+#ifdef PNN_SP_DIAG
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        d[0] = dg_issue; d[1] = dg_mfma; d[2] = dg_store; d[3] = dg_bar;
+    }
+#endif
 
     // Epilogue: undo the weight scale, bias (+ LeakyReLU); f32 and/or split-f16 outputs (and the HM epilogue).
     const int py = p.py[cls], px = p.px[cls];
