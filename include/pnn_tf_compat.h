@@ -1,0 +1,218 @@
+// pnn_tf_compat.h -- header-only look-alike of the TensorFlow C++ API subset that the reference's HM side uses
+// (SURVEY.md Appendix C), implemented on the C ABI of pnn_hip.h.  With `-I<repo>/include/tf_compat` in front
+// of the include path, the reference's hevc/hm_common/c++/source_common/integration_prediction_neural_network.{h,cpp}
+// and the PNN branch of TComPrediction.cpp / TComPattern.cpp compile unchanged and run on libpnn_hip.so:
+//
+//   tensorflow::Tensor(DT_FLOAT, {1, 80}).flat<float>().data() / .dims() / .shape().dim_size(i)
+//   tensorflow::GraphDef + ReadBinaryProto(Env::Default(), path, &graph_def)   -> remembers the model path
+//   tensorflow::NewSession(SessionOptions()) ; session->Create(graph_def)      -> loads the model (.pnnw)
+//   session->Run({{"node_flattened_context", T}}, {"fully_connected/node_output"}, {}, &out)
+//   session->Run({{"node_portion_above", A}, {"node_portion_left", L}}, {".../node_output"}, {}, &out)
+//   tensorflow::Status (.ok(), Status::OK(), operator<<), errors::NotFound(...), LOG(ERROR), tensorflow::string
+//
+// Reference call sites: integration_prediction_neural_network.cpp:3-69, TComPrediction.cpp:564-622,
+// TComPattern.cpp:344-360.  Paths listed in the model table must point at `.pnnw` files.
+#ifndef PNN_TF_COMPAT_H
+#define PNN_TF_COMPAT_H
+
+#include "pnn_hip.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <initializer_list>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace tensorflow {
+
+typedef std::string string;
+typedef long long int64;
+
+enum DataType { DT_INVALID = 0, DT_FLOAT = 1 };
+
+class Status {
+public:
+    Status() : ok_(true) {}
+    Status(bool ok, const std::string& msg) : ok_(ok), msg_(msg) {}
+    static Status OK() { return Status(); }
+    bool ok() const { return ok_; }
+    const std::string& error_message() const { return msg_; }
+    std::string ToString() const { return ok_ ? "OK" : msg_; }
+private:
+    bool ok_;
+    std::string msg_;
+};
+inline std::ostream& operator<<(std::ostream& os, const Status& s) { return os << s.ToString(); }
+
+namespace errors {
+inline void pnn_append(std::ostringstream&) {}
+template <typename T, typename... Rest>
+inline void pnn_append(std::ostringstream& os, const T& v, const Rest&... rest) { os << v; pnn_append(os, rest...); }
+template <typename... Args>
+inline Status NotFound(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Not found: " + os.str()); }
+template <typename... Args>
+inline Status InvalidArgument(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Invalid argument: " + os.str()); }
+template <typename... Args>
+inline Status Internal(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Internal: " + os.str()); }
+}  // namespace errors
+
+class TensorShape {
+public:
+    TensorShape() {}
+    TensorShape(std::initializer_list<int64> d) : dims_(d) {}
+    explicit TensorShape(const std::vector<int64>& d) : dims_(d) {}
+    int dims() const { return (int)dims_.size(); }
+    int64 dim_size(int i) const { return dims_.at(i); }
+    int64 num_elements() const { int64 n = 1; for (int64 d : dims_) n *= d; return n; }
+private:
+    std::vector<int64> dims_;
+};
+
+class Tensor {
+public:
+    Tensor() : dtype_(DT_INVALID) {}
+    Tensor(DataType dt, const TensorShape& shape) : dtype_(dt), shape_(shape), buf_(new std::vector<float>((size_t)shape.num_elements(), 0.f)) {}
+    template <typename T>
+    struct Flat {
+        T* ptr; int64 n;
+        T* data() const { return ptr; }
+        int64 size() const { return n; }
+        T& operator()(int64 i) const { return ptr[i]; }
+    };
+    template <typename T> Flat<T> flat() { return Flat<T>{buf_ ? buf_->data() : nullptr, shape_.num_elements()}; }
+    template <typename T> Flat<const T> flat() const { return Flat<const T>{buf_ ? buf_->data() : nullptr, shape_.num_elements()}; }
+    int dims() const { return shape_.dims(); }
+    const TensorShape& shape() const { return shape_; }
+    int64 dim_size(int i) const { return shape_.dim_size(i); }
+    int64 NumElements() const { return shape_.num_elements(); }
+    DataType dtype() const { return dtype_; }
+private:
+    DataType dtype_;
+    TensorShape shape_;
+    std::shared_ptr<std::vector<float> > buf_;     // copies share the buffer, as TF tensors do
+};
+
+class Env {
+public:
+    static Env* Default() { static Env e; return &e; }
+};
+
+// The "graph" is the path of the model file; Session::Create loads it.
+class GraphDef {
+public:
+    std::string pnn_model_path;
+};
+
+inline Status ReadBinaryProto(Env*, const std::string& path, GraphDef* graph_def)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return errors::NotFound(path, "; No such file or directory");
+    std::fclose(f);
+    graph_def->pnn_model_path = path;
+    return Status::OK();
+}
+
+struct SessionOptions {
+    int pnn_device = 0;          // HIP device index
+    float pnn_mean = 0.f;        // only used by the fused Pel entry points; the float Run() path never adds the mean
+};
+
+class Session {
+public:
+    virtual ~Session() {}
+    virtual Status Create(const GraphDef& graph) = 0;
+    virtual Status Run(const std::vector<std::pair<string, Tensor> >& inputs, const std::vector<string>& output_tensor_names,
+                       const std::vector<string>& target_node_names, std::vector<Tensor>* outputs) = 0;
+    virtual Status Close() { return Status::OK(); }
+};
+
+class PnnSession : public Session {
+public:
+    explicit PnnSession(const SessionOptions& o) : opts_(o), ctx_(nullptr), width_(0), is_fc_(0) {}
+    ~PnnSession() override { if (ctx_) pnn_destroy(ctx_); }
+    pnn_ctx* pnn_context() const { return ctx_; }
+
+    Status Create(const GraphDef& graph) override
+    {
+        if (ctx_) { pnn_destroy(ctx_); ctx_ = nullptr; }
+        int rc = pnn_create_empty(&ctx_, opts_.pnn_mean, opts_.pnn_device);
+        if (rc != PNN_OK) return errors::Internal(pnn_last_error(nullptr));
+        rc = pnn_load_model_file(ctx_, graph.pnn_model_path.c_str());
+        if (rc != PNN_OK) return errors::InvalidArgument(pnn_last_error(ctx_));
+        for (int w = 4; w <= 64; w *= 2) {
+            int fc = 0;
+            if (pnn_model_info(ctx_, w, &fc, nullptr, nullptr) == PNN_OK) { width_ = w; is_fc_ = fc; }
+        }
+        return width_ ? Status::OK() : errors::Internal("no model in ", graph.pnn_model_path);
+    }
+
+    Status Run(const std::vector<std::pair<string, Tensor> >& inputs, const std::vector<string>& output_tensor_names,
+               const std::vector<string>&, std::vector<Tensor>* outputs) override
+    {
+        if (!ctx_) return errors::Internal("Session::Run before Session::Create");
+        if (!outputs || output_tensor_names.size() != 1) return errors::InvalidArgument("exactly one fetch is supported");
+        const Tensor* ctx = nullptr; const Tensor* above = nullptr; const Tensor* left = nullptr;
+        for (const auto& kv : inputs) {
+            if (kv.first == "node_flattened_context" || kv.first == "node_flattened_context:0") ctx = &kv.second;
+            else if (kv.first == "node_portion_above" || kv.first == "node_portion_above:0") above = &kv.second;
+            else if (kv.first == "node_portion_left" || kv.first == "node_portion_left:0") left = &kv.second;
+            else return errors::NotFound("feed ", kv.first, " is not a placeholder of the PNN graph");
+        }
+        const string& fetch = output_tensor_names[0];
+        const int w = width_;
+        int rc;
+        if (is_fc_) {
+            if (!ctx || fetch.find("fully_connected/node_output") != 0) return errors::NotFound("FetchOutputs node ", fetch, ": not found");
+            if (ctx->NumElements() % (5 * w * w)) return errors::InvalidArgument("node_flattened_context must be [N, ", 5 * w * w, "]");
+            const int n = (int)(ctx->NumElements() / (5 * w * w));
+            Tensor out(DT_FLOAT, TensorShape({n, w, w, 1}));
+            rc = pnn_predict_fc(ctx_, w, ctx->flat<float>().data(), n, out.flat<float>().data());
+            if (rc != PNN_OK) return errors::Internal(pnn_last_error(ctx_));
+            outputs->assign(1, out);
+        } else {
+            if (!above || !left || fetch.find("convolutional/merger/transpose_convolution_") != 0)
+                return errors::NotFound("FetchOutputs node ", fetch, ": not found");
+            if (above->NumElements() % (3 * w * w) || left->NumElements() / (2 * w * w) != above->NumElements() / (3 * w * w))
+                return errors::InvalidArgument("node_portion_above / node_portion_left have the wrong shape for width ", w);
+            const int n = (int)(above->NumElements() / (3 * w * w));
+            Tensor out(DT_FLOAT, TensorShape({n, w, w, 1}));
+            rc = pnn_predict_conv(ctx_, w, above->flat<float>().data(), left->flat<float>().data(), n, out.flat<float>().data());
+            if (rc != PNN_OK) return errors::Internal(pnn_last_error(ctx_));
+            outputs->assign(1, out);
+        }
+        return Status::OK();
+    }
+
+private:
+    SessionOptions opts_;
+    pnn_ctx* ctx_;
+    int width_, is_fc_;
+};
+
+inline Session* NewSession(const SessionOptions& options) { return new PnnSession(options); }
+
+// LOG(ERROR) << ...  (tensorflow/core/platform/logging.h)
+class PnnLogLine {
+public:
+    explicit PnnLogLine(const char* sev) { os_ << sev << " "; }
+    ~PnnLogLine() { std::cerr << os_.str() << std::endl; }
+    template <typename T> PnnLogLine& operator<<(const T& v) { os_ << v; return *this; }
+private:
+    std::ostringstream os_;
+};
+
+}  // namespace tensorflow
+
+#ifndef LOG
+#define PNN_LOG_INFO ::tensorflow::PnnLogLine("I")
+#define PNN_LOG_WARNING ::tensorflow::PnnLogLine("W")
+#define PNN_LOG_ERROR ::tensorflow::PnnLogLine("E")
+#define PNN_LOG_FATAL ::tensorflow::PnnLogLine("F")
+#define LOG(severity) PNN_LOG_##severity
+#endif
+
+#endif  // PNN_TF_COMPAT_H

@@ -1,0 +1,3 @@
+// Shadow of <tensorflow/core/lib/strings/stringprintf.h> for the HM drop-in: everything the reference needs from TensorFlow lives in
+// pnn_tf_compat.h (see its header comment).
+#include "pnn_tf_compat.h"   // needs -I<repo>/include next to -I<repo>/include/tf_compat

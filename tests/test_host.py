@@ -245,3 +245,19 @@ def test_two_rank_sharding_gloo(tmp_path, oracle):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
+
+
+def test_tf_compat_headers_compile(tmp_path):
+    """include/pnn_tf_compat.h + the shadow tree include/tf_compat/tensorflow/core/...: (1) the reference's own TF glue
+    (integration_prediction_neural_network.cpp: create_tensors_*, load_graph(s)) compiles UNCHANGED against them when
+    the reference checkout is present; (2) the call-site sample program compiles and links against libpnn_hip.so."""
+    inc = ["-I" + os.path.join(ROOT, "include", "tf_compat"), "-I" + os.path.join(ROOT, "include")]
+    ref = "/root/reference/hevc/hm_common/c++/source_common"
+    if os.path.exists(os.path.join(ref, "integration_prediction_neural_network.cpp")):
+        subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall"] + inc + ["-I" + ref,
+                              os.path.join(ref, "integration_prediction_neural_network.cpp")])
+    exe = str(tmp_path / "hm_sample")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall"] + inc + [os.path.join(ROOT, "tests", "hm_callsite_sample.cpp"), "-o", exe,
+                           "-L" + libdir, "-lpnn_hip", "-Wl,-rpath," + libdir])
+    assert os.path.exists(exe)
