@@ -210,6 +210,88 @@ def params_from_tf_bundle(prefix, width, is_fc):
     return np.concatenate(chunks)
 
 
+# ---------------------------------------------------------------------------------------------
+# Frozen GraphDef reader: the `graph_output.pbtxt` files written by the
+# reference's freezing_graph_pnn.py:131-143 are BINARY GraphDefs whose weights are Const nodes
+# named like the variables of Appendix B.7.  No TensorFlow needed.
+# ---------------------------------------------------------------------------------------------
+def read_frozen_graph_consts(path):
+    """{node_name: float32 ndarray} for every float Const node of a binary GraphDef."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    consts = {}
+    for field, wt, node in _proto_fields(buf):
+        if field != 1 or wt != 2:                       # GraphDef.node
+            continue
+        name, op, tensor = None, None, None
+        for f2, w2, v2 in _proto_fields(node):
+            if f2 == 1: name = v2.decode()
+            elif f2 == 2: op = v2.decode()
+            elif f2 == 5:                               # NodeDef.attr map entry {key = 1, value = 2 (AttrValue)}
+                key, val = None, None
+                for f3, _, v3 in _proto_fields(v2):
+                    if f3 == 1: key = v3.decode()
+                    elif f3 == 2: val = v3
+                if key == "value" and val is not None:
+                    for f4, w4, v4 in _proto_fields(val):
+                        if f4 == 8 and w4 == 2: tensor = v4   # AttrValue.tensor (TensorProto)
+        if op != "Const" or tensor is None:
+            continue
+        dtype, shape, content, float_vals = 0, [], None, []
+        for f5, w5, v5 in _proto_fields(tensor):
+            if f5 == 1: dtype = v5
+            elif f5 == 2:
+                for f6, _, dim in _proto_fields(v5):
+                    if f6 == 2:
+                        sz = 0
+                        for f7, _, v7 in _proto_fields(dim):
+                            if f7 == 1: sz = v7
+                        shape.append(sz)
+            elif f5 == 4: content = v5
+            elif f5 == 5:                               # float_val: packed (wire type 2) or single fixed32 (wire type 5)
+                float_vals += list(np.frombuffer(v5, dtype="<f4")) if w5 in (2, 5) else []
+        if dtype != 1:
+            continue
+        n = int(np.prod(shape)) if shape else 1
+        if content is not None and len(content) == 4 * n:
+            arr = np.frombuffer(content, dtype="<f4").copy()
+        elif len(float_vals) == n:
+            arr = np.array(float_vals, np.float32)
+        elif len(float_vals) == 1:                      # TF stores a constant-filled tensor as one value
+            arr = np.full(n, float_vals[0], np.float32)
+        else:
+            continue
+        consts[name] = arr.reshape(shape)
+    return consts
+
+
+def params_from_frozen_graph(path, width, is_fc):
+    """Flat canonical parameters from a frozen graph written by the reference's freezing_graph_pnn.py."""
+    t = read_frozen_graph_consts(path)
+    chunks = []
+    for name, shape, _ in tensor_specs(width, is_fc):
+        if name not in t:
+            raise KeyError("%s: no Const node named %s" % (path, name))
+        if tuple(t[name].shape) != tuple(shape):
+            raise ValueError("%s: shape %s, expected %s" % (name, t[name].shape, shape))
+        chunks.append(t[name].astype(np.float32).ravel())
+    return np.concatenate(chunks)
+
+
+def convert_model(src, dst, width, is_fc):
+    """Any supported source (frozen GraphDef `.pbtxt`/`.pb`, TF V2 checkpoint prefix, `.pnnw`) -> `.pnnw`."""
+    if src.endswith(".pnnw"):
+        flat, w, fc = load_pnnw(src)
+        if (w, fc) != (width, bool(is_fc)):
+            raise ValueError("%s holds a width-%d %s model" % (src, w, "FC" if fc else "conv"))
+    elif os.path.exists(src + ".index"):
+        flat = params_from_tf_bundle(src, width, is_fc)
+    else:
+        flat = params_from_frozen_graph(src, width, is_fc)
+    save_pnnw(dst, flat, width, is_fc)
+    return flat
+
+
 def write_model_table(path, entries):
     """entries: [(width, is_pair, channel, path)] -> the `width,is_pair,channel,path` text table of
     hevc/hm_common/paths_to_graphs_output/{single,pair}.txt."""

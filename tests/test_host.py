@@ -261,3 +261,47 @@ def test_tf_compat_headers_compile(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall"] + inc + [os.path.join(ROOT, "tests", "hm_callsite_sample.cpp"), "-o", exe,
                            "-L" + libdir, "-lpnn_hip", "-Wl,-rpath," + libdir])
     assert os.path.exists(exe)
+
+
+def _pb_varint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _pb_field(num, payload):                              # length-delimited field
+    return _pb_varint((num << 3) | 2) + _pb_varint(len(payload)) + payload
+
+
+def _pb_const_node(name, arr, use_float_val=False):
+    shape = b"".join(_pb_field(2, _pb_varint((1 << 3) | 0) + _pb_varint(d)) for d in arr.shape)
+    tensor = _pb_varint((1 << 3) | 0) + _pb_varint(1) + _pb_field(2, shape)
+    tensor += _pb_field(5, arr.astype("<f4").tobytes()) if use_float_val else _pb_field(4, arr.astype("<f4").tobytes())
+    attr = _pb_field(1, b"value") + _pb_field(2, _pb_field(8, tensor))
+    return _pb_field(1, _pb_field(1, name.encode()) + _pb_field(2, b"Const") + _pb_field(5, attr))
+
+
+def test_frozen_graphdef_reader(tmp_path):
+    """A binary GraphDef with the layout freeze_graph produces (Const nodes named like the variables),
+    hand-encoded here with a minimal protobuf writer: weights come back in the canonical order."""
+    w, fc = 4, False
+    flat = wts.init_params(w, fc, seed=9, bias_std=0.1)
+    parts = wts.split_params(flat, w, fc)
+    blob = _pb_field(1, _pb_field(1, b"node_portion_above") + _pb_field(2, b"Placeholder"))
+    for i, (name, arr) in enumerate(parts.items()):
+        blob += _pb_const_node(name, arr, use_float_val=(i % 5 == 4))
+    blob += _pb_field(1, _pb_field(1, b"convolutional/merger/transpose_convolution_1/node_output") + _pb_field(2, b"BiasAdd"))
+    path = str(tmp_path / "graph_output.pbtxt")
+    with open(path, "wb") as f:
+        f.write(blob)
+    back = wts.params_from_frozen_graph(path, w, fc)
+    assert np.array_equal(back, flat)
+    out = str(tmp_path / "m.pnnw")
+    wts.convert_model(path, out, w, fc)
+    assert np.array_equal(wts.load_pnnw(out)[0], flat)
+    with pytest.raises((KeyError, ValueError)):
+        wts.params_from_frozen_graph(path, 8, False)       # a width-8 net does not match this file's tensors
