@@ -344,3 +344,30 @@ def test_tf_compat_session_run(pnn, oracle, tmp_path):
     ab = ((np.arange(768) * 37 % 256).astype(np.float32) - mean).reshape(1, 16, 48)
     lf = (((np.arange(512) * 53 + 11) % 256).astype(np.float32) - mean).reshape(1, 32, 16)
     np.testing.assert_allclose(got_cv, oracle.conv_forward(pc, 16, ab, lf)[0], rtol=0, atol=FLOAT_ATOL)
+
+
+def test_python_evaluator_real_weights(pnn, oracle):
+    """evaluation.predict_mask (the PNN half of comparing_pnn_ipfcns_hevc_best_mode.py:162-322) with the reference's
+    trained conv-8 model on a smooth synthetic image: predictions equal the oracle's, PSNRs follow tools.compute_psnr,
+    and a trained model predicts a smooth image far better than chance."""
+    from context_adaptive_neural_network_based_prediction_amd import evaluation
+    w = 8
+    net = pnn.PredictionNeuralNetwork(4, w, False, path_to_model=os.path.join(GOLD, "conv%d_single.pnnw" % w))
+    yy, xx = np.mgrid[0:64, 0:96]
+    img = np.clip(90 + 0.9 * xx + 0.5 * yy + 12 * np.sin(xx / 7.0), 0, 255).astype(np.uint8)[None, :, :, None]
+    rows = np.array([0, 8, 24, 40], dtype=np.int32)
+    cols = np.array([4, 32, 60, 72], dtype=np.int32)
+    res = evaluation.predict_mask(img, w, rows, cols, net, 2, util.MEAN, (0, 0))
+    assert res['predictions_pnn_uint8'].shape == (4, w, w, 1) and res['psnrs_pnn'].shape == (4,)
+    flat, _, _ = wts.load_pnnw(os.path.join(GOLD, "conv%d_single.pnnw" % w))
+    for i, (r, c) in enumerate(zip(rows, cols)):
+        rc, a, l = oracle.extract_context_u8_rect(img[0, :, :, 0], w, int(r), int(c), util.MEAN, 0, 0)
+        want = oracle.conv_forward(flat, w, a[None], l[None])[0] + np.float32(util.MEAN)
+        got = res['predictions_pnn_uint8'][i, :, :, 0].astype(int)
+        assert np.abs(got - np.round(np.clip(want, 0, 255))).max() <= 1
+        tgt = img[0, r + w:r + 2 * w, c + w:c + 2 * w, 0]
+        assert np.array_equal(res['targets_uint8'][i, :, :, 0], tgt)
+        assert abs(res['psnrs_pnn'][i] - evaluation.compute_psnr(tgt, res['predictions_pnn_uint8'][i, :, :, 0])) < 1e-9
+    assert res['mean_psnr_pnn'] > 25.0
+    with pytest.raises(TypeError):
+        evaluation.compute_psnr(img.astype(np.float32), img)
