@@ -499,7 +499,8 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
         // calibrated on device sweeps (tools/sp_check.py, tools/sp_prof.py): time ~ padded work x (1 + 2/NT) (operand
         // traffic per MFMA), mild tail quantisation, RT = 2 and KC = 4 lose a resident workgroup, KC = 1 adds barriers
         const double per_cu = wgs / 256.0;
-        const double fill = 1.0 + 0.4 * std::max(0.0, 1.5 - per_cu);              // under-filled chip: no co-resident workgroup
+        // under-filled chip: idle CUs below one workgroup per CU, no co-resident workgroup below ~1.5
+        const double fill = per_cu < 1.0 ? 1.2 * std::pow(1.0 / per_cu, 0.7) : 1.0 + 0.4 * std::max(0.0, 1.5 - per_cu);
         const double pad = (double)(tm * bm) * (tn * bn) / ((double)M * cout);
         const double reuse = 1.0 + 2.0 / (t.nt * (4 / t.wm));
         const double shape = (t.rt * t.wm >= 8 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
@@ -610,11 +611,22 @@ Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
     return m;
 }
 
+// Which arithmetic a pass of nb blocks runs on: the split-precision GEMM wins once the layers fill the chip; small
+// passes (HM's per-TB calls, short batches) are latency-bound and faster on the f32 kernels, whose split-K variant
+// spreads a small-M layer over all CUs (crossovers measured on device: ~500 blocks for the FC nets, ~200 for the
+// convolutional ones).  With canonical_order = 1 the choice must not depend on the batch size.
+bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
+{
+    if (c->opt_precision != 1) return false;
+    if (c->opt_canonical) return true;
+    return nb >= (m->is_fc ? 512 : 200);
+}
+
 int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
 {
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
     int rc;
-    if (c->opt_precision == 1) {
+    if (pass_uses_split(c, m, nb)) {
         // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32)
         const long nin = nb * 5L * m->width * m->width;
         const void* S = d_ctx;                        // already in the split layout when the gather wrote it
@@ -641,7 +653,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     float* F[2] = {(float*)c->ws[2].p, (float*)c->ws[3].p};
     // Split-precision mode: tensors between two tap GEMMs travel in the split f16 layout (same byte count as f32);
     // tensors consumed by the merger / the last transposed convolution stay f32.
-    const bool sp = c->opt_precision == 1;
+    const bool sp = pass_uses_split(c, m, nb);
     int rc;
     for (int br = 0; br < 2; br++) {
         const size_t nl = m->branch[br].size();
@@ -1019,7 +1031,7 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
         float* ab = ctxbuf;
         float* lf = m->is_fc ? ctxbuf + 3 * w2 : ctxbuf + nb * 3 * w2;
         const long pa = m->is_fc ? 5 * w2 : 3 * w2, pl = m->is_fc ? 5 * w2 : 2 * w2;
-        const bool split_ctx = m->is_fc && c->opt_precision == 1;   // the FC chain starts on the split-precision GEMM
+        const bool split_ctx = m->is_fc && pass_uses_split(c, m, nb);   // the FC chain starts on the split-precision GEMM
         GatherParams g;
         g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs + b0); g.N = (int)nb; g.w = width;
         g.unit = 4; g.mean = c->mean; g.above = ab; g.left = lf; g.pitch_above = pa; g.pitch_left = pl; g.split = split_ctx ? 1 : 0;

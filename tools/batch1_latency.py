@@ -1,0 +1,23 @@
+"""Batch-1 latency of the host-buffer entry point HM binds (pnn_predict_pel: H2D + net + epilogue + D2H + sync)."""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork, _lib
+from tests import util
+L = _lib.lib()
+for w, fc in ((4, True), (8, True), (16, False), (32, False), (64, False)):
+    net = PredictionNeuralNetwork(1, w, fc, params=util.make_params(w, fc, 1))
+    a, l = util.make_contexts(w, 1, 2)
+    x = util.flatten_fc(a, l) if fc else a
+    dst = np.zeros((w, w), np.int32)
+    lp = None if fc else l.ctypes.data_as(_lib.f32p)
+    for mode in (0, 1):
+        net.set_option("canonical_order", mode)
+        for _ in range(20):
+            L.pnn_predict_pel(net.ctx, w, x.ctypes.data_as(_lib.f32p), lp, 1, dst.ctypes.data_as(_lib.i32p), w)
+        t0 = time.perf_counter()
+        n = 200
+        for _ in range(n):
+            L.pnn_predict_pel(net.ctx, w, x.ctypes.data_as(_lib.f32p), lp, 1, dst.ctypes.data_as(_lib.i32p), w)
+        dt = (time.perf_counter() - t0) / n
+        print("width %2d %-4s canonical_order=%d: %.1f us per TB call" % (w, "FC" if fc else "conv", mode, dt * 1e6))
