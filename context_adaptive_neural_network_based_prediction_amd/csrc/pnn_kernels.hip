@@ -264,31 +264,42 @@ __global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams
     };
 
     if (wave < nchunks) {                           // wave-uniform
-        int c = wave;
-        int t = t0 + c / cpt, cc = c - (c / cpt) * cpt;
+        // This wave's chunks are wave, wave+4, ...  A ring of D register sets keeps D chunks in flight: each layer
+        // of a small pass is a dependent chain of L2/MALL round trips, so depth -- not bandwidth -- sets its time.
+        constexpr int D = 4;
+        f32x4 a_r[D], b_r[D][NT];
+        int c_ld = wave;                            // load cursor (stays on this wave's last chunk once it gets there)
+        int t = t0 + c_ld / cpt, cc = c_ld - (c_ld / cpt) * cpt;
         tap_setup(t);
-        f32x4 a_cur, a_nxt, b_cur[NT], b_nxt[NT];
-        load_chunk(c, cc, a_cur, b_cur);
-        for (; c < nchunks; c += 4) {
-            const bool more = c + 4 < nchunks;
-            if (more) {
+        auto advance_ld = [&]() {
+            if (c_ld + 4 < nchunks) {
+                c_ld += 4;
                 cc += 4;
-                if (cc >= cpt) {                    // next chunk of this wave lies in a later tap
+                if (cc >= cpt) {                    // the next chunk of this wave lies in a later tap
                     while (cc >= cpt) { cc -= cpt; ++t; }
                     tap_setup(t);
                 }
             }
-            load_chunk(more ? c + 4 : c, cc, a_nxt, b_nxt);
-            __builtin_amdgcn_sched_barrier(0);
+        };
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+        for (int u = 0; u < D; u++) {
+            load_chunk(c_ld, cc, a_r[u], b_r[u]);
+            advance_ld();
+        }
+        for (int c = wave; c < nchunks; c += 4 * D) {
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[nt][e], a_cur[e], acc[nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt;
+            for (int u = 0; u < D; u++) {
+                if (c + 4 * u < nchunks) {          // wave-uniform
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) b_cur[nt] = b_nxt[nt];
+                    for (int e = 0; e < 4; e++)
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_r[u][nt][e], a_r[u][e], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_chunk(c_ld, cc, a_r[u], b_r[u]);
+                    advance_ld();
+                }
+            }
         }
     }
 #pragma unroll
