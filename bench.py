@@ -103,6 +103,7 @@ def main():
     # ---- synthetic workload, resident in HBM before the timed region -------------------------------------
     params = util.make_params(width, is_fc, seed=1, out_gain=30.0)     # reference initialiser statistics
     net = PredictionNeuralNetwork(batch, width, is_fc, params=params, device=local_rank)
+    net.set_option("autotune", int(os.environ.get("PNN_AUTOTUNE", "1")))   # tile choice measured on the device during warm-up
     plane_h, plane_w = 1088, 1920                                       # one HD luminance plane of int32 Pel
     plane = util.make_plane(plane_h, plane_w, seed=100 + rank, pad=64)
     xs, ys, flags = util.make_tbs(plane_h, plane_w, width, batch, seed=200 + rank, partial_fraction=0.3)
@@ -235,7 +236,8 @@ def main():
             "config": {"workload": cfg_name, "width": width, "arch": "fully_connected" if is_fc else "convolutional",
                        "batch_per_gpu": batch, "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
                        "weights": "seeded random init with the reference initialisers' statistics",
-                       "parallelism": "independent blocks sharded over ranks, no data-path collective"},
+                       "parallelism": "independent blocks sharded over ranks, no data-path collective",
+                       "tile_autotune": "on first use, in the warm-up steps (pnn_set_option autotune)"},
             "launches_per_step": stats["launches"],
             "max_abs_lsb_vs_oracle": parity,
             "roofline": {"bound": "mfma", "kernel": kinds[dom]["kernel"], "achieved": achieved_tflops,

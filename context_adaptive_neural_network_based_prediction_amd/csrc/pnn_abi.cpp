@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,8 @@ struct pnn_ctx {
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
+    long opt_autotune = 0;                            // 1: time every split-GEMM tile config on first use of a (layer, M) and keep the best
+    std::map<std::pair<const void*, long>, int> tuned;
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
     struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
     std::vector<LaunchRec> launch_recs;
@@ -527,7 +530,38 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
     if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation plane of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
     p.x_bytes = (unsigned)xb;
-    const int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    if (c->opt_autotune && c->opt_sp_cfg < 0) {
+        // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
+        // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
+        const auto key = std::make_pair((const void*)&L, M);
+        auto it = c->tuned.find(key);
+        if (it == c->tuned.end()) {
+            const int cpt = p.Cin / 16;
+            const bool one_tap = (L.k_total == (double)p.Cin);
+            hipEvent_t e0, e1;
+            HIPCHK(c, hipEventCreate(&e0));
+            HIPCHK(c, hipEventCreate(&e1));
+            float best_ms = 1e30f;
+            int best = cfg;
+            for (int i = 0; i < tapgemm_sp_num_cfgs(); i++) {
+                const TileCfg ti = tapgemm_sp_cfg(i);
+                if (!one_tap && cpt % ti.kc) continue;
+                HIPCHK(c, launch_tapgemm_sp(p, i, s));                 // warm
+                HIPCHK(c, hipEventRecord(e0, s));
+                for (int r = 0; r < 3; r++) HIPCHK(c, launch_tapgemm_sp(p, i, s));
+                HIPCHK(c, hipEventRecord(e1, s));
+                HIPCHK(c, hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) { best_ms = ms; best = i; }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            it = c->tuned.emplace(key, best).first;
+        }
+        cfg = it->second;
+    }
     static const bool debug = getenv("PNN_DEBUG") != nullptr;
     static const bool profile = getenv("PNN_PROFILE") != nullptr;
     const TileCfg t = tapgemm_sp_cfg(cfg);
@@ -801,6 +835,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_TILE_CFG")) c->opt_tile_cfg = atol(e);
     if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
     if (const char* e = getenv("PNN_PRECISION")) c->opt_precision = atol(e);
+    if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
     *out = c;
     return PNN_OK;
 }
@@ -909,6 +944,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
     else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
     else if (!strcmp(name, "precision")) c->opt_precision = value;
+    else if (!strcmp(name, "autotune")) c->opt_autotune = value;
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);

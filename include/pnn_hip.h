@@ -64,6 +64,8 @@ float pnn_mean(const pnn_ctx* ctx);
 
 /* Options: "precision" (1, default: tap GEMMs form every f32 product from three f16 MFMAs on hi/lo operand halves --
  * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice),
+ * "autotune" (1: the first call that meets a new (layer, batch size) pair times every legal tile configuration of the
+ * split-precision GEMM on the device and keeps the fastest -- do it in a warm-up call, outside any timed region),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
