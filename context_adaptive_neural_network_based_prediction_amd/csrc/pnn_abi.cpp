@@ -559,6 +559,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             it = c->tuned.emplace(key, best).first;
+            if (getenv("PNN_DEBUG")) {
+                const TileCfg tb = tapgemm_sp_cfg(best), th = tapgemm_sp_cfg(cfg);
+                fprintf(stderr, "[pnn] autotune M=%ld K=%.0f N=%d ncls=%d: best {%d,%d,%d,wm%d} %.1f us (heuristic {%d,%d,%d,wm%d})\n", M, L.k_total, p.Cout,
+                        p.ncls, tb.rt, tb.nt, tb.kc, tb.wm, best_ms * 1e3 / 3, th.rt, th.nt, th.kc, th.wm);
+            }
         }
         cfg = it->second;
     }
@@ -851,6 +856,7 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
     if (rc) return rc;
     free_model(c->models[idx]);
     c->models[idx] = m;
+    c->tuned.clear();                                 // keys point into the replaced model
     return PNN_OK;
 }
 
