@@ -145,7 +145,7 @@ def main():
     stats = net.last_call_stats()
 
     gpu_pred = d_dst.cpu().numpy() if rank == 0 else None   # what the timed steps produced; checked in the CPU leg below
-    parity = None
+    parity, parity_detail = None, None
 
     # ---- roofline of the dominant kernel (tapgemm_kernel), HIP events on the launch stream ---------------
     # Region = the network alone on pre-gathered contexts: for FC nets exactly 4 tap-GEMM launches per pass.
@@ -210,7 +210,9 @@ def main():
             reps_cpu += 1
         cdt = time.perf_counter() - c0
         # the CPU leg's output doubles as the parity check of what the GPU steps produced (uint8 LSBs after the HM epilogue)
-        parity = int(np.abs(gpu_pred[:ncpu].astype(np.int64) - cpu_pred).max())
+        pdiff = np.abs(gpu_pred[:ncpu].astype(np.int64) - cpu_pred)
+        parity = int(pdiff.max())
+        parity_detail = {"pixels_compared": int(pdiff.size), "pixels_differing": int((pdiff != 0).sum())}
         cpu = {"value": ncpu * reps_cpu / cdt, "unit": "blocks/s", "cores": os.cpu_count(), "kind": "port",
                "sample": "%d x %d blocks of the same workload through oracle/pnn_oracle.c (OpenMP, -O3 -mavx2 -mfma), "
                          "batched; stand-in for the reference's TF-1.9 CPU path" % (reps_cpu, ncpu)}
@@ -237,6 +239,7 @@ def main():
                        "tile_autotune": "on first use, in the warm-up steps (pnn_set_option autotune)"},
             "launches_per_step": stats["launches"],
             "max_abs_lsb_vs_oracle": parity,
+            "parity_detail": parity_detail,
             "roofline": {"bound": "mfma", "kernel": kinds[dom]["kernel"], "achieved": achieved_tflops,
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
                          "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": gemm_flops_per_launch,
