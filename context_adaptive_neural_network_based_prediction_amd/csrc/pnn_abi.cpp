@@ -85,11 +85,14 @@ struct pnn_ctx {
     Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf ws[4];                                     // P0, P1, F0, F1 (FC uses P0, P1)
     DevBuf stage_in[2], stage_out[2], stage_tbs;
+    void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
+    long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
+    long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 0;                            // 1: time every split-GEMM tile config on first use of a (layer, M) and keep the best
     std::map<std::pair<const void*, long>, int> tuned;
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
@@ -482,6 +485,35 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     return PNN_OK;
 }
 
+// convimg_sp_kernel: how many images one workgroup of tile `t` stages for this layer (0 = tile cannot run the layer).
+static int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap)
+{
+    if (one_tap || (p.Cin / 16) % t.kc) return 0;
+    const int rows = 32 * t.rt * t.wm, sp = p.SH * p.SW;
+    int g = rows / sp;
+    while (g > 0 && convimg_sp_lds_bytes(p, t, g) > (size_t)156 * 1024) --g;
+    return g;
+}
+
+// Rule-based choice among the convimg tiles: fewest idle rows and columns, then the larger wave tile.  -1 = none fits.
+static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
+{
+    int best = -1;
+    double best_cost = 1e300;
+    for (int i = 0; i < convimg_sp_num_cfgs(); i++) {
+        const TileCfg t = convimg_sp_cfg(i);
+        const int g = convimg_images(p, t, one_tap);
+        if (g <= 0) continue;
+        const long rows = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
+        const long tn = (p.Cout + bn - 1) / bn;
+        const double pad = (double)rows * (tn * bn) / ((double)g * p.SH * p.SW * p.Cout);
+        const double reuse = 1.0 + 0.5 / t.rt + 0.5 / t.nt;          // LDS fragment reads per MFMA
+        const double cost = pad * reuse;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best_cost <= 1.6 ? best : -1;
+}
+
 // Split-precision launch (3 x f16 MFMA): activations as two f16 planes, outputs f32 and/or two f16 planes.
 int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
 {
@@ -530,47 +562,73 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
     if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation plane of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
     p.x_bytes = (unsigned)xb;
+    const int cpt = p.Cin / 16;
+    const bool one_tap = (L.k_total == (double)p.Cin);
+    const int nsp = tapgemm_sp_num_cfgs(), nci = convimg_sp_num_cfgs(), nrg = tapgemm_ring_num_cfgs();
+    // configuration codes: [0, nsp) = tapgemm_sp_kernel tiles, then the convimg_sp_kernel tiles (images resident in
+    // LDS), then the tapgemm_ring_kernel tiles (LDS-DMA ring)
+    p.zero = c->d_zero;
+    auto cfg_of = [&](int code) { return code < nsp ? tapgemm_sp_cfg(code) : code < nsp + nci ? convimg_sp_cfg(code - nsp) : tapgemm_ring_cfg(code - nsp - nci); };
+    auto kind_of = [&](int code) { return code < nsp ? "" : code < nsp + nci ? "img" : "ring"; };
+    auto legal = [&](int code) {
+        if (code < nsp) return one_tap || cpt % tapgemm_sp_cfg(code).kc == 0;
+        if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
+        return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
+    };
+    auto launch = [&](int code) {
+        if (code < nsp) return launch_tapgemm_sp(p, code, s);
+        if (code < nsp + nci) {
+            const TileCfg t = convimg_sp_cfg(code - nsp);
+            return launch_convimg_sp(p, code - nsp, convimg_images(p, t, one_tap), s);
+        }
+        return launch_tapgemm_ring(p, code - nsp - nci, s);
+    };
     int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
+    else if (c->opt_sp_cfg < 0 && c->opt_convimg) {
+        const int ci = choose_cfg_convimg(p, one_tap);
+        if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
+    }
     if (c->opt_autotune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
         // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
         const auto key = std::make_pair((const void*)&L, M);
         auto it = c->tuned.find(key);
         if (it == c->tuned.end()) {
-            const int cpt = p.Cin / 16;
-            const bool one_tap = (L.k_total == (double)p.Cin);
             hipEvent_t e0, e1;
             HIPCHK(c, hipEventCreate(&e0));
             HIPCHK(c, hipEventCreate(&e1));
             float best_ms = 1e30f;
             int best = cfg;
-            for (int i = 0; i < tapgemm_sp_num_cfgs(); i++) {
-                const TileCfg ti = tapgemm_sp_cfg(i);
-                if (!one_tap && cpt % ti.kc) continue;
-                HIPCHK(c, launch_tapgemm_sp(p, i, s));                 // warm
+            for (int i = 0; i < nsp + nci + nrg; i++) {
+                if (!legal(i)) continue;
+                HIPCHK(c, launch(i));                 // warm
                 HIPCHK(c, hipEventRecord(e0, s));
-                for (int r = 0; r < 3; r++) HIPCHK(c, launch_tapgemm_sp(p, i, s));
+                for (int r = 0; r < 3; r++) HIPCHK(c, launch(i));
                 HIPCHK(c, hipEventRecord(e1, s));
                 HIPCHK(c, hipEventSynchronize(e1));
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+                if (getenv("PNN_DEBUG_TUNE")) fprintf(stderr, "[pnn]   code %d: %.1f us\n", i, ms * 1e3 / 3);
                 if (ms < best_ms) { best_ms = ms; best = i; }
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             it = c->tuned.emplace(key, best).first;
             if (getenv("PNN_DEBUG")) {
-                const TileCfg tb = tapgemm_sp_cfg(best), th = tapgemm_sp_cfg(cfg);
-                fprintf(stderr, "[pnn] autotune M=%ld K=%.0f N=%d ncls=%d: best {%d,%d,%d,wm%d} %.1f us (heuristic {%d,%d,%d,wm%d})\n", M, L.k_total, p.Cout,
-                        p.ncls, tb.rt, tb.nt, tb.kc, tb.wm, best_ms * 1e3 / 3, th.rt, th.nt, th.kc, th.wm);
+                const TileCfg tb = cfg_of(best), th = cfg_of(cfg);
+                fprintf(stderr, "[pnn] autotune M=%ld K=%.0f N=%d ncls=%d: best %s{%d,%d,%d,wm%d,d%d} %.1f us (heuristic %s{%d,%d,%d,wm%d,d%d})\n", M,
+                        L.k_total, p.Cout, p.ncls, kind_of(best), tb.rt, tb.nt, tb.kc, tb.wm, tb.d, best_ms * 1e3 / 3, kind_of(cfg), th.rt, th.nt,
+                        th.kc, th.wm, th.d);
             }
         }
         cfg = it->second;
     }
     static const bool debug = getenv("PNN_DEBUG") != nullptr;
     static const bool profile = getenv("PNN_PROFILE") != nullptr;
-    const TileCfg t = tapgemm_sp_cfg(cfg);
-    if (debug) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc);
+    const TileCfg t = cfg_of(cfg);
+    if (debug) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d %s{rt %d, nt %d, kc %d, wm %d, d %d}\n", M, L.k_total, p.Cout, p.ncls,
+                       cfg, kind_of(cfg), t.rt, t.nt, t.kc, t.wm, t.d);
     if (profile || c->opt_time_launches) {
         pnn_ctx::LaunchRec r;
         HIPCHK(c, hipEventCreate(&r.e0));
@@ -578,7 +636,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         r.kind = 2;
         r.flops = 2.0 * (double)M * L.k_total * p.Cout;
         HIPCHK(c, hipEventRecord(r.e0, s));
-        HIPCHK(c, launch_tapgemm_sp(p, cfg, s));
+        HIPCHK(c, launch(cfg));
         HIPCHK(c, hipEventRecord(r.e1, s));
         if (profile) {
             HIPCHK(c, hipEventSynchronize(r.e1));
@@ -592,11 +650,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
             c->launch_recs.push_back(r);
         }
     } else {
-        HIPCHK(c, launch_tapgemm_sp(p, cfg, s));
+        HIPCHK(c, launch(cfg));
     }
     if (diag) {
         HIPCHK(c, hipStreamSynchronize(s));
-        const TileCfg tt = tapgemm_sp_cfg(cfg);
+        const TileCfg tt = tapgemm_sp_cfg(cfg);   // (diag runs never take the convimg kernel)
         const long bm = 32L * tt.rt * tt.wm, bn = 32L * tt.nt * (4 / tt.wm);
         const size_t nwg = (size_t)((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
         std::vector<unsigned long long> h(4 * nwg);
@@ -841,6 +899,12 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
     if (const char* e = getenv("PNN_PRECISION")) c->opt_precision = atol(e);
     if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
+    if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
+    if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
+    if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
+        pnn_destroy(c);
+        return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
+    }
     *out = c;
     return PNN_OK;
 }
@@ -925,6 +989,7 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_in) if (b.p) (void)hipFree(b.p);
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
+    if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -951,6 +1016,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
     else if (!strcmp(name, "precision")) c->opt_precision = value;
     else if (!strcmp(name, "autotune")) c->opt_autotune = value;
+    else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
+    else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);

@@ -1,0 +1,276 @@
+// Split-precision tap GEMM with the activation IMAGES resident in LDS (convolutions on small feature maps).
+//
+// tapgemm_sp_kernel re-reads every input pixel once per tap through the CU's vector-memory path (9x for a 3x3
+// layer), and that path -- not the matrix cores -- bounds it.  The feature maps of the PNNs are tiny (4x4 ... 32x96
+// pixels), so this kernel stages G whole images [pixels][Cin] (split f16 layout, 4 B per element) in LDS ONCE and
+// builds the MFMA operand of every tap from LDS; only the weights still stream global -> registers -> LDS.
+// Same contract and parameter block as the other tap-GEMM kernels (TapGemmParams; forward convs of any stride,
+// transposed convs incl. the four stride-2 output-parity classes), same per-output summation order as
+// tapgemm_sp_kernel, hence bit-identical results.
+//
+//   workgroup = 256 threads = 4 waves as WM x WN; wave tile (32*RT) x (32*NT); workgroup rows = G images x SH*SW
+//   output pixels (rows past G*SH*SW idle), all of them taken from the G staged input images.
+//   LDS: weights [2][KC][4 planes][BN] slots | images [(G*IH*IW + 1)][Cin/4 + 1] slots (16-B slots; the +1 slot of
+//   pitch keeps the 64-lane fragment reads conflict-free; the extra pixel is all zeros = SAME padding / idle rows).
+#include "pnn_kernels.h"
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int RT, int NT, int KC, int WM>
+__global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, const int G)
+{
+    constexpr int WN = 4 / WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int E = 4 * BN;
+    constexpr int NLD = (E + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    f32x4* Bs = lds;                                  // [2][KC][E]
+    f32x4* Ai = lds + 2 * KC * E;                     // [(G*NPIN + 1)][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const long img0 = (long)blockIdx.x * G;           // first image of this workgroup
+    const int SP = p.SH * p.SW;
+    const int NPIN = p.IH * p.IW;
+    const int PITCH = (p.Cin >> 2) + 1;
+    const int nimg = (int)((long)p.M / SP - img0 < G ? (long)p.M / SP - img0 : G);   // images that exist
+
+    // ---- stage the images (contiguous in memory) and the zero pixel ------------------------------------------
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.X) + (size_t)img0 * NPIN * (p.Cin >> 2);
+        const int c4n = p.Cin >> 2;
+        const int total = nimg * NPIN * c4n;
+        constexpr int U = 8;                          // loads in flight per thread (a serial copy pays the full
+        for (int base = 0; base < total; base += 256 * U) {   // memory latency once per 16 bytes)
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int idx = base + tid + 256 * u;
+                v[u] = src[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int idx = base + tid + 256 * u;
+                const int pix = idx / c4n, c4 = idx - pix * c4n;
+                if (idx < total) Ai[pix * PITCH + c4] = v[u];
+            }
+        }
+        for (int idx = tid; idx < PITCH; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- this lane's output pixels ---------------------------------------------------------------------------------
+    int pg[RT], pi[RT], pj[RT];
+    bool mv[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int ml = wm * (32 * RT) + rt * 32 + l31;
+        const int g = ml / SP;
+        mv[rt] = g < nimg;
+        const int r = ml - g * SP;
+        pg[rt] = g;
+        pi[rt] = r / p.SW;
+        pj[rt] = r - pi[rt] * p.SW;
+    }
+
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const int nstages = (nchunks + KC - 1) / KC;
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
+
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
+
+    int abase[RT];                                    // slot index of this lane's source pixel for the current tap
+    auto tap_setup = [&](int tp) {
+        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
+            const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            abase[rt] = (ok ? (pg[rt] * NPIN + iy * p.IW + ix) : G * NPIN) * PITCH;
+        }
+    };
+    const f32x4* bsrc[NLD];
+    int bdst[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+        int e = tid + 256 * r;
+        if (E % 256 != 0) e = e < E ? e : E - 1;
+        const int qq = e / BN, nn = e - qq * BN;
+        bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+        bdst[r] = e;
+    }
+    const size_t bstride = (size_t)4 * p.Npad;
+    auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
+#pragma unroll
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) dst[j][r] = bsrc[r][(size_t)(stage * KC + j) * bstride];
+    };
+    auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
+#pragma unroll
+        for (int j = 0; j < KC; j++)
+#pragma unroll
+            for (int r = 0; r < NLD; r++) Bs[(buf * KC + j) * E + bdst[r]] = src[j][r];
+    };
+    auto read_frags = [&](int buf, int j, int cj, f32x4 (&wf)[NT][2], f32x4 (&af)[RT][2]) {   // [..][0] = hi, [..][1] = lo
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            wf[nt][0] = Bs[(buf * KC + j) * E + (0 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
+            wf[nt][1] = Bs[(buf * KC + j) * E + (2 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            af[rt][0] = Ai[abase[rt] + cj * 4 + 0 + h];
+            af[rt][1] = Ai[abase[rt] + cj * 4 + 2 + h];
+        }
+    };
+    auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2]) {
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const f16x8 whi = __builtin_bit_cast(f16x8, wf[nt][0]), wlo = __builtin_bit_cast(f16x8, wf[nt][1]);
+                    const f16x8 ahi = __builtin_bit_cast(f16x8, a[rt][0]), alo = __builtin_bit_cast(f16x8, a[rt][1]);
+                    if (part == 0) {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[rt][nt], 0, 0, 0);
+                    } else {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[rt][nt], 0, 0, 0);
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc[rt][nt], 0, 0, 0);
+                    }
+                }
+    };
+
+    // ---- K loop: (tap, chunk group) stages; only the weights are fetched per stage -------------------------
+    f32x4 b_stage[KC][NLD];
+    int t = t0, cc = 0;
+    tap_setup(p.tap[t0]);
+    int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
+    load_b(0, b_stage);
+    store_b(0, b_stage);
+    __syncthreads();                                  // images + first weight stage visible
+    for (int s = 0; s < nstages; s++) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nstages;
+        load_b(more ? s + 1 : s, b_stage);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
+        read_frags(buf, 0, cc < cpt ? cc : cpt - 1, wf0, af0);
+#pragma unroll
+        for (int j = 0; j < KC; j++) {
+            const int cn = cc + j + 1 < cpt ? cc + j + 1 : cpt - 1;   // tail stage of a one-tap layer: zero weights, any data
+            if (j + 1 < KC) { if (j & 1) read_frags(buf, j + 1, cn, wf0, af0); else read_frags(buf, j + 1, cn, wf1, af1); }
+            if (j & 1) mfma_chunk(wf1, af1); else mfma_chunk(wf0, af0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(buf ^ 1, b_stage);
+        if (more) {
+            cc += KC;
+            if (cc >= cpt) {                          // wave-uniform: next stage starts the next tap
+                cc = 0;
+                ++t;
+                tap_setup(tp_next);
+                tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as tapgemm_sp_kernel) -------------------------------------------------------------------------
+    const int py = p.py[cls], px = p.px[cls];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        if (!mv[rt]) continue;
+        const int oy = pi[rt] * p.os + py, ox = pj[rt] * p.os + px;
+        const size_t obase = ((((size_t)img0 + pg[rt]) * p.OH + oy) * p.OW + ox) * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+                if (n < p.Cout) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
+                    if (p.act) {
+                        v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    }
+                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                    if (p.Yhi) store_split4(p.Yhi, obase, n, v);
+                    if (p.Yi) {
+                        int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                            hm_round(v[3], p.mean));
+                        *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                    }
+                }
+            }
+    }
+}
+
+// X(rt, nt, kc, wm): workgroup rows 32*rt*wm, columns 32*nt*(4/wm)
+#define PNN_CI_CFGS(X) \
+    X(3, 2, 2, 4) X(1, 2, 2, 4) X(2, 2, 2, 4) X(1, 4, 2, 4) X(2, 4, 2, 4) X(3, 2, 2, 2) X(2, 2, 2, 2) X(2, 1, 2, 2) X(3, 1, 2, 2) \
+    X(1, 1, 2, 2) X(1, 2, 2, 2) X(4, 2, 2, 4)
+
+static const TileCfg kCfgsCi[] = {
+#define X(rt, nt, kc, wm) {rt, nt, kc, 316, wm},
+    PNN_CI_CFGS(X)
+#undef X
+};
+
+int convimg_sp_num_cfgs() { return (int)(sizeof(kCfgsCi) / sizeof(kCfgsCi[0])); }
+TileCfg convimg_sp_cfg(int idx) { return kCfgsCi[idx]; }
+
+// LDS bytes of configuration `t` staging G images of this layer (0 if it cannot run: too big / bad shape).
+size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)
+{
+    const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
+    const size_t slots = 2 * (size_t)t.kc * 4 * bn + ((size_t)G * p.IH * p.IW + 1) * ((size_t)(p.Cin >> 2) + 1);
+    return slots * 16;
+}
+
+template <int RT, int NT, int KC, int WM>
+static hipError_t launch_ci(const TapGemmParams& p, int G, hipStream_t s)
+{
+    constexpr int BN = 32 * NT * (4 / WM);
+    const TileCfg t{RT, NT, KC, 316, WM};
+    const size_t lds = convimg_sp_lds_bytes(p, t, G);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convimg_sp_kernel<RT, NT, KC, WM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long nimg = p.M / (p.SH * p.SW);
+    dim3 grid((unsigned)((nimg + G - 1) / G), (p.Cout + BN - 1) / BN, p.ncls);
+    hipLaunchKernelGGL((convimg_sp_kernel<RT, NT, KC, WM>), grid, dim3(256), lds, s, p, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    int i = 0;
+#define X(rt, nt, kc, wm) if (idx == i++) return launch_ci<rt, nt, kc, wm>(p, G, s);
+    PNN_CI_CFGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pnn

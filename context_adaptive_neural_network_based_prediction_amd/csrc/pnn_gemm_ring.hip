@@ -1,0 +1,424 @@
+// Split-precision tap GEMM with dedicated loader waves and an LDS-DMA ring.
+//
+// Measured on tapgemm_sp_kernel and on a first ring version of this file (tools/ring_prof.hip): a CU's vector-memory
+// path accepts 64 B/clk, a wave that issues a 1-KiB load is BLOCKED until the path takes it (in-order issue), and with
+// four waves per CU the ~600 cycles a stage's loads need are therefore added to its ~960 MFMA cycles instead of
+// running under them -- however far ahead the loads are requested.  So the two jobs get separate waves:
+//
+//   workgroup = 512 threads = 8 waves, two per SIMD: waves 0-3 ("MFMA waves", WM x WN, wave tile (32*RT) x (32*NT))
+//   only read fragments from LDS and issue MFMAs; waves 4-7 ("loader waves") only issue global_load_lds_dwordx4 into a
+//   D-deep ring of stage buffers (no VGPR destination, no ds_write) and wait for them with counted vmcnt.
+//   One raw s_barrier per stage joins them: before barrier s the loaders have seen stage s+1 land (D-3 later stages
+//   may stay in flight); after it the MFMA waves may read stage s+1 (they prefetch its first fragments under the
+//   last chunk of stage s) and the loaders refill buffer (s-1) % D, which nobody reads any more.
+//   BM = 32*RT*WM, BN = 32*NT*WN; stage = KC 16-deep chunks: activations [BM rows][PPR = 4*KC 16-byte pieces] (hi|lo
+//   halves of each chunk), a row's pieces XOR-swizzled so that the fragment reads (ds_read_b128, 16-lane groups) are
+//   conflict-free -- an LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address and
+//   again by the reader; weights [KC][4 planes][BN] pieces, read lane-contiguous.
+//   Out-of-image taps, rows past M and chunks past the end of a one-tap layer's K are fetched from a zero page.
+// Same contract, parameter block, weight packing and per-output summation order as tapgemm_sp_kernel: bit-identical.
+#include "pnn_kernels.h"
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16(const void* g, f32x4* l)
+{
+#ifdef PNN_RING_NO_LOAD        // ablation builds of tools/ring_prof.hip only
+    asm volatile("" ::"v"(g), "s"(l));
+    return;
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int RT, int NT, int KC, int WM, int D>
+__global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p)
+{
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * RT * WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int E = 4 * BN;                       // 16-byte pieces per staged weight chunk
+    constexpr int PPR = KC * 4;                     // pieces per activation row and stage
+    constexpr int NLA = BM * PPR / 256;             // activation LDS-DMA instructions per wave and stage
+    constexpr int NLB = KC * E / 256;               // weight LDS-DMA instructions per wave and stage
+    constexpr int NI = NLA + NLB;
+    constexpr int ASLOTS = BM * PPR, SS = ASLOTS + KC * E;
+    constexpr int RPS = 16 / PPR > 0 ? 16 / PPR : 1;   // rows per swizzle step
+    static_assert((KC * E) % 256 == 0 && (BM * PPR) % 256 == 0, "stage pieces must split evenly over the 4 waves");
+    static_assert((D - 2) * NI <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D][A pieces | B pieces]
+
+#ifdef PNN_RING_DIAG2           // coarse stamps (tools/ring_prof.hip): entry / loop begin / loop end / exit of wave 0
+    const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (tid >> 6) & 3;                 // index within the role (MFMA waves 0-3, loader waves 4-7)
+    const bool loader = tid >= 256;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int mblk = blockIdx.x * BM;
+    const int SP = p.SH * p.SW;
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const int nstages = (nchunks + KC - 1) / KC;
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X);
+    const char* __restrict__ Zb = reinterpret_cast<const char*>(p.zero);
+    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
+
+    // ---- epilogue, second half (all 8 waves): split-f16 output tile LDS -> global in 16-byte pieces, whole rows ---------
+    // The MFMA waves leave the tile in LDS as [BM rows][BN/16 chunks][hi 16 x f16 | lo 16 x f16] (the global layout of a
+    // row segment, row pitch OP bytes); consecutive lanes then store consecutive pieces: full lines instead of the
+    // 8-byte fragments a lane of the accumulator layout owns (measured: 21k -> see DESIGN.md cycles per workgroup).
+    constexpr int OPP = BN / 4 + 1;                  // out-tile row pitch in 16-byte pieces (+1: spreads the rows over the banks)
+    static_assert((size_t)BM * OPP <= (size_t)D * SS, "output tile must fit the ring");
+    auto copy_out = [&]() {
+        if (!p.Yhi) return;
+        const int cpy = p.py[cls], cpx = p.px[cls];
+        f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Yhi);
+#pragma unroll 2
+        for (int i = tid; i < BM * (BN / 4); i += 512) {
+            const int row = i / (BN / 4), q = i - row * (BN / 4);
+            const int mg = mblk + row;
+            const int nq = (n0 >> 2) + q;             // piece index within the output pixel's [Cout/4] pieces
+            if (mg >= p.M || nq >= (p.Cout >> 2)) continue;
+            size_t opix = mg;
+            if (SP != 1 || p.os != 1) {
+                const int pbq = mg / SP;
+                const int rq = mg - pbq * SP;
+                const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+                opix = ((size_t)pbq * p.OH + piq * p.os + cpy) * p.OW + pjq * p.os + cpx;
+            }
+            yo[opix * (p.Cout >> 2) + nq] = ring[row * OPP + q];
+        }
+    };
+
+    if (loader) {
+    // ---- loader side: this lane's pieces of a stage -------------------------------------------------------------
+        // activation instruction r of this wave covers ring pieces [64*(wave + 4r), +64): piece L -> row L / PPR, slot
+        // L % PPR, which holds source piece (slot ^ swizzle(row)).
+        int lb[NLA], li[NLA], lj[NLA], lpiece[NLA];
+        bool lv[NLA];
+#pragma unroll
+        for (int r = 0; r < NLA; r++) {
+            const int L = 64 * (wave + 4 * r) + lane;
+            const int row = L / PPR, slot = L - row * PPR;
+            lpiece[r] = slot ^ ((row / RPS) % PPR);
+            const int mg = mblk + row;
+            lv[r] = mg < p.M;
+            const int mc = lv[r] ? mg : 0;
+            const int b = mc / SP;
+            const int q = mc - b * SP;
+            lb[r] = b;
+            li[r] = q / p.SW;
+            lj[r] = q - li[r] * p.SW;
+        }
+        const char* asrc[NLA];                          // source of this lane's piece for chunk 0 of the issue-side tap (or the zero page)
+        bool aok[NLA];
+        auto tap_setup = [&](int tp) {
+            const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+            for (int r = 0; r < NLA; r++) {
+                const int iy = li[r] * p.a + dy, ix = lj[r] * p.a + dx;
+                aok[r] = lv[r] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                const size_t pix = ((size_t)lb[r] * p.IH + iy) * p.IW + ix;
+                asrc[r] = aok[r] ? Xb + pix * ((size_t)p.Cin << 2) + (lpiece[r] << 4) : Zb + (lpiece[r] << 4);
+            }
+        };
+        const f32x4* bsrc[NLB];
+#pragma unroll
+        for (int r = 0; r < NLB; r++) {
+            const int L = 64 * (wave + 4 * r) + lane;
+            const int j = L / E, e = L - j * E;
+            const int qq = e / BN, nn = e - qq * BN;
+            bsrc[r] = Wg + (size_t)(j * 4 + qq) * p.Npad + n0 + nn;
+        }
+        const size_t bstride = (size_t)KC * 4 * p.Npad;   // pieces per stage in the packed weights
+        int it = t0, icc = 0, istage = 0;               // issue-side position
+        int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
+        tap_setup(p.tap[t0]);
+        auto issue = [&]() {                             // fetch stage `istage` into ring buffer istage % D, then advance
+            f32x4* dst = ring + (istage % D) * SS;
+#pragma unroll
+            for (int r = 0; r < NLA; r++) {
+                // a one-tap layer's last stage may run past K (the weights there are zero padding): take zeros, not the next row
+                const bool past = icc + (lpiece[r] >> 2) >= cpt;
+                const char* src = (aok[r] && !past) ? asrc[r] + ((size_t)icc << 6) : Zb + (lpiece[r] << 4);
+                glds16(src, dst + 64 * (wave + 4 * r));
+            }
+#pragma unroll
+            for (int r = 0; r < NLB; r++) glds16(bsrc[r] + (size_t)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));
+            ++istage;
+            icc += KC;
+            if (icc >= cpt && it + 1 < t1) {             // wave-uniform
+                icc = 0;
+                ++it;
+                tap_setup(tp_next);
+                tp_next = p.tap[it + 1 < t1 ? it + 1 : it];
+            }
+        };
+
+        // ---- loader pipeline ----
+#pragma unroll
+        for (int s = 0; s < D - 1; s++)
+            if (s < nstages) issue();
+        if (D - 1 <= nstages) wait_vm<(D - 2) * NI>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                // stage 0 is visible
+        for (int s = 0; s < nstages; s++) {
+            if (s + 1 < nstages) {                   // stage s+1 must have landed; later stages may stay in flight
+                if (s + D - 2 < nstages) wait_vm<(D - 3) * NI>(); else wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();            // barrier s
+            if (s + D - 1 < nstages) issue();        // into buffer (s-1) % D
+        }
+        __builtin_amdgcn_s_barrier();                // epilogue barrier A (see below)
+        __builtin_amdgcn_s_barrier();                // epilogue barrier B
+        copy_out();
+        return;
+    }
+
+    // ---- consumer side ------------------------------------------------------------------------------------------------
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
+    int arow[RT], aswz[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int row = wm * (32 * RT) + rt * 32 + l31;
+        arow[rt] = row * PPR;
+        aswz[rt] = (row / RPS) % PPR;
+    }
+    auto read_frags = [&](const f32x4* buf, int j, f32x4 (&wf)[NT][2], f32x4 (&af)[RT][2]) {   // [..][0] = hi, [..][1] = lo
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            wf[nt][0] = buf[ASLOTS + j * E + (0 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
+            wf[nt][1] = buf[ASLOTS + j * E + (2 + h) * BN + wn * (32 * NT) + nt * 32 + l31];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            af[rt][0] = buf[arow[rt] + ((j * 4 + 0 + h) ^ aswz[rt])];
+            af[rt][1] = buf[arow[rt] + ((j * 4 + 2 + h) ^ aswz[rt])];
+        }
+    };
+    auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2]) {
+#pragma unroll
+        for (int part = 0; part < 2; part++)        // part 0: hi*hi for every tile;  part 1: the two cross terms
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const f16x8 whi = __builtin_bit_cast(f16x8, wf[nt][0]), wlo = __builtin_bit_cast(f16x8, wf[nt][1]);
+                    const f16x8 ahi = __builtin_bit_cast(f16x8, a[rt][0]), alo = __builtin_bit_cast(f16x8, a[rt][1]);
+#ifdef PNN_RING_NO_MFMA        // ablation builds of tools/ring_prof.hip only: keep the fragment reads alive, skip the matrix work
+                    asm volatile("" ::"v"(whi), "v"(wlo), "v"(ahi), "v"(alo));
+                    continue;
+#endif
+                    if (part == 0) {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[rt][nt], 0, 0, 0);
+                    } else {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[rt][nt], 0, 0, 0);
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc[rt][nt], 0, 0, 0);
+                    }
+                }
+    };
+
+#ifdef PNN_RING_DIAG
+    // Diagnostic build only (tools/ring_prof.hip): cycle sums of wave 0 per phase, written to p.Xlo.
+    unsigned long long dg_t = 0, dg_a = 0, dg_w = 0, dg_i = 0, dg_b = 0;
+#define DG_STAMP(acc_)                                                                    \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory");   \
+        acc_ += now_ - dg_t; dg_t = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#else
+#define DG_STAMP(acc_) do {} while (0)
+#endif
+    // Issue order inside a chunk: one MFMA, then two of the NEXT chunk's fragment reads, ... -- two ds_read_b128 fit in the
+    // shadow of a 32-cycle MFMA; issued as a burst of 2*(RT+NT) they hold the wave (and its MFMA pipe) for ~16 cycles each.
+    auto interleave = [&]() {
+#ifndef PNN_RING_DIAG
+#pragma unroll
+        for (int i = 0; i < RT + NT; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * RT * NT - (RT + NT), 0);
+#endif
+    };
+    // ---- MFMA-wave pipeline -----------------------------------------------------------------------------------------
+    static_assert(KC % 2 == 0 && D >= 3, "fragment register sets alternate per chunk");
+    __builtin_amdgcn_s_barrier();                    // stage 0 is visible
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
+    read_frags(ring, 0, wf0, af0);
+#ifdef PNN_RING_DIAG
+    { unsigned long long d0_ = 0; DG_STAMP(d0_); (void)d0_; }
+#endif
+#ifdef PNN_RING_DIAG2
+    const unsigned long long dq1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int s = 0; s < nstages; s++) {
+        const f32x4* buf = ring + (s % D) * SS;
+        __builtin_amdgcn_s_barrier();                // barrier s: stage s+1 is visible, buffer (s-1) % D is released
+        __builtin_amdgcn_sched_barrier(0);
+        DG_STAMP(dg_w);
+#pragma unroll
+        for (int j = 0; j + 1 < KC; j++) {
+            if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1); }
+            else       { read_frags(buf, j + 1, wf1, af1); mfma_chunk(wf0, af0); }
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        DG_STAMP(dg_a);
+        // first fragments of the next stage -- unconditional (after the last stage they come from a stale buffer and are
+        // dropped): behind a branch the compiler's merged wait state makes the next MFMA wait for THESE reads too
+        read_frags(ring + ((s + 1) % D) * SS, 0, wf0, af0);
+        DG_STAMP(dg_i);
+        mfma_chunk(wf1, af1);                        // chunk KC-1 (KC even: its fragments are in set 1)
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_STAMP(dg_b);
+    }
+#ifdef PNN_RING_DIAG
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        d[0] = dg_a; d[1] = dg_w; d[2] = dg_i; d[3] = dg_b;
+    }
+#endif
+
+#ifdef PNN_RING_DIAG2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long dq2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // ---- epilogue, first half (MFMA waves): scale, bias, LeakyReLU; f32 / HM outputs straight from the accumulator layout,
+    // the split-f16 output through LDS (copy_out above) ------------------------------------------------------------
+    const int py = p.py[cls], px = p.px[cls];
+    __builtin_amdgcn_s_barrier();                    // barrier A: every wave is done with the ring
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int lrow = wm * (32 * RT) + rt * 32 + l31;
+        const int mg = mblk + lrow;
+        const bool rowok = mg < p.M;
+        const int mc = rowok ? mg : 0;
+        const int pbq = mc / SP;
+        const int rq = mc - pbq * SP;
+        const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+        const int oy = piq * p.os + py, ox = pjq * p.os + px;
+        const size_t obase = (((size_t)pbq * p.OH + oy) * p.OW + ox) * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int nl = wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+                const int n = n0 + nl;
+                const int nb = n < p.Cout ? n : 0;    // columns past Cout: computed on valid memory, never stored
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
+                if (p.act) {
+                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                }
+#ifdef PNN_RING_NO_STORE       // ablation builds of tools/ring_prof.hip only
+                asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                continue;
+#endif
+                if (p.Yhi) {                          // same values and rounding as store_split4
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+                    _Float16* dst = reinterpret_cast<_Float16*>(ring + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
+                    *reinterpret_cast<h4*>(dst) = hi;
+                    *reinterpret_cast<h4*>(dst + 16) = lo;
+                }
+                if (rowok && n < p.Cout) {
+                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                    if (p.Yi) {
+                        int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                            hm_round(v[3], p.mean));
+                        *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                    }
+                }
+            }
+    }
+    __builtin_amdgcn_s_barrier();                    // barrier B: the output tile is complete
+    copy_out();
+#ifdef PNN_RING_DIAG2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        const unsigned long long dq3 = __builtin_amdgcn_s_memtime(), dr3 = __builtin_amdgcn_s_memrealtime();
+        d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = dq3 - dq2; d[3] = dr3 - dr0;
+    }
+#endif
+}
+
+// X(rt, nt, kc, wm, d): tile 32*rt*wm x 32*nt*(4/wm), d-deep ring
+#define PNN_RING_CFGS(X) \
+    X(1, 4, 2, 4, 4) X(1, 4, 2, 4, 3) X(2, 2, 2, 2, 4) X(2, 2, 2, 2, 3) X(2, 4, 2, 4, 3) X(4, 2, 2, 2, 3) X(2, 3, 2, 2, 3) X(1, 3, 2, 4, 3) \
+    X(1, 2, 2, 4, 4) X(1, 2, 2, 4, 3) X(2, 1, 2, 2, 4) X(2, 1, 2, 2, 3) X(1, 2, 2, 2, 4) X(2, 2, 2, 4, 3) X(1, 5, 2, 4, 4) X(1, 5, 2, 4, 3) \
+    X(2, 3, 2, 4, 3) X(3, 2, 2, 2, 3) X(1, 3, 2, 4, 4) X(2, 3, 2, 2, 4)
+
+static const TileCfg kCfgsRing[] = {
+#define X(rt, nt, kc, wm, d) {rt, nt, kc, 316, wm, d},
+    PNN_RING_CFGS(X)
+#undef X
+};
+
+int tapgemm_ring_num_cfgs() { return (int)(sizeof(kCfgsRing) / sizeof(kCfgsRing[0])); }
+TileCfg tapgemm_ring_cfg(int idx) { return kCfgsRing[idx]; }
+
+size_t tapgemm_ring_lds_bytes(const TileCfg& t)
+{
+    const size_t bm = 32 * (size_t)t.rt * t.wm, bn = 32 * (size_t)t.nt * (4 / t.wm);
+    return (size_t)t.d * (bm * 4 * t.kc + (size_t)t.kc * 4 * bn) * 16;
+}
+
+template <int RT, int NT, int KC, int WM, int D>
+static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
+{
+    constexpr int BM = 32 * RT * WM, BN = 32 * NT * (4 / WM);
+    const size_t lds = tapgemm_ring_lds_bytes(TileCfg{RT, NT, KC, 316, WM, D});
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_ring_kernel<RT, NT, KC, WM, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
+    hipLaunchKernelGGL((tapgemm_ring_kernel<RT, NT, KC, WM, D>), grid, dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    if (!p.zero) return hipErrorInvalidValue;
+    int i = 0;
+#define X(rt, nt, kc, wm, d) if (idx == i++) return launch_ring<rt, nt, kc, wm, d>(p, s);
+    PNN_RING_CFGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pnn

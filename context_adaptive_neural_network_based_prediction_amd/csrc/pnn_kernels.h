@@ -20,6 +20,7 @@ constexpr int kMaxClasses = 4;
 struct TapGemmParams {
     const float* X;    // f32 activations, or the hi f16 plane for the split-precision kernel
     const void* Xlo;   // lo f16 plane (split-precision kernel only)
+    const void* zero;  // >= 256 bytes of zeros (ring kernel: source of padding / out-of-range pieces)
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
@@ -44,13 +45,21 @@ inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsi
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
 constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
-struct TileCfg { int rt, nt, kc, mf, wm = 4; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
+struct TileCfg { int rt, nt, kc, mf, wm = 4, d = 2; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
 int tapgemm32_num_cfgs();
 TileCfg tapgemm32_cfg(int idx);
 hipError_t launch_tapgemm32(const TapGemmParams& p, int idx, hipStream_t s);
 int tapgemm_sp_num_cfgs();
 TileCfg tapgemm_sp_cfg(int idx);
 hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s);   // 3 x f16 MFMA, f32-class accuracy
+int tapgemm_ring_num_cfgs();
+TileCfg tapgemm_ring_cfg(int idx);
+size_t tapgemm_ring_lds_bytes(const TileCfg& t);
+hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)
+int convimg_sp_num_cfgs();
+TileCfg convimg_sp_cfg(int idx);
+size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
+hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s);   // G images per workgroup, resident in LDS
 hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
