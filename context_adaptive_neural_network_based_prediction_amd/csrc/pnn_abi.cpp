@@ -514,6 +514,29 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
     return best_cost <= 1.6 ? best : -1;
 }
 
+// Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
+// kernels.  Calibrated with tools/ring_prof.hip: a workgroup costs ~(prologue + epilogue) + stages x 1.45 x its MFMA
+// cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
+static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap)
+{
+    if (!one_tap || (double)M * p.Cout < 2.0e6 || p.Cin < 256) return -1;
+    int best = -1;
+    double best_cost = 1e300;
+    for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
+        const TileCfg t = tapgemm_ring_cfg(i);
+        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
+        const long nwg = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
+        const int resident = tapgemm_ring_lds_bytes(t) > (size_t)80 * 1024 ? 1 : 2;
+        const double stages = std::ceil((p.Cin / 16) / (double)t.kc);
+        const double mfma = 96.0 * t.rt * t.nt * t.kc;
+        const double wg = 9000.0 + 55.0 * t.rt * t.nt * 4 + stages * mfma * (resident == 2 ? 1.25 : (t.d >= 4 ? 1.45 : 2.1));
+        const double rounds = std::ceil(nwg / (256.0 * resident));
+        const double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);   // two co-resident workgroups share the CU's MFMA pipes
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
 // Split-precision launch (3 x f16 MFMA): activations as two f16 planes, outputs f32 and/or two f16 planes.
 int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
 {
@@ -585,9 +608,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     };
     int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
     if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
-    else if (c->opt_sp_cfg < 0 && c->opt_convimg) {
-        const int ci = choose_cfg_convimg(p, one_tap);
-        if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
+    else if (c->opt_sp_cfg < 0) {
+        const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
+        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap) : -1;
+        if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
+        else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
     }
     if (c->opt_autotune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
@@ -1006,6 +1031,8 @@ int pnn_model_info(const pnn_ctx* c, int width, int* is_fc, int* n_layers, long*
     if (n_params) *n_params = c->models[idx]->n_params;
     return PNN_OK;
 }
+
+int pnn_num_split_configs(void) { return tapgemm_sp_num_cfgs() + convimg_sp_num_cfgs() + tapgemm_ring_num_cfgs(); }
 
 int pnn_set_option(pnn_ctx* c, const char* name, long value)
 {

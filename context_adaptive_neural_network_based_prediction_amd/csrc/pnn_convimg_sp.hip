@@ -194,6 +194,16 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 
     // ---- epilogue (as tapgemm_sp_kernel) -------------------------------------------------------------------------
     const int py = p.py[cls], px = p.px[cls];
+    // all bias values first: a load placed next to its use cannot be hoisted over the stores in between (the compiler
+    // must assume they alias), and every group then pays one L2 round trip (measured in the ring kernel: 600 cycles each)
+    f32x4 bvs[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+            bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));
+        }
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
         if (!mv[rt]) continue;
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             for (int g = 0; g < 4; g++) {
                 const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
                 if (n < p.Cout) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const f32x4 bv = bvs[nt][g];
                     f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
                     if (p.act) {
                         v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);

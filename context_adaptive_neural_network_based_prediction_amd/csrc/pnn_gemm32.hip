@@ -177,6 +177,14 @@ __global__ __launch_bounds__(256) void tapgemm32_kernel(const TapGemmParams p)
 
     // Epilogue: bias (+ LeakyReLU); register group g of a tile holds channels 8g + 4h .. +3 of this lane's pixel.
     const int py = p.py[cls], px = p.px[cls];
+    f32x4 bvs[NT][4];                                // all bias loads before the first store (see pnn_gemm_sp.hip)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + nt * 32 + 8 * g + 4 * h;
+            bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));
+        }
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
         if (!mv[rt]) continue;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void tapgemm32_kernel(const TapGemmParams p)
             for (int g = 0; g < 4; g++) {
                 const int n = n0 + nt * 32 + 8 * g + 4 * h;
                 if (n < p.Cout) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const f32x4 bv = bvs[nt][g];
                     f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} + bv;
                     if (p.act) {
                         v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);

@@ -313,7 +313,22 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     // ---- epilogue, first half (MFMA waves): scale, bias, LeakyReLU; f32 / HM outputs straight from the accumulator layout,
     // the split-f16 output through LDS (copy_out above) ------------------------------------------------------------
     const int py = p.py[cls], px = p.px[cls];
+    // all bias values first: a load placed next to its use cannot be hoisted over the stores in between (the compiler
+    // must assume they alias), and the groups below then pay one L2 round trip EACH (measured: 600 cycles per group)
+    f32x4 bvs[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+            bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));   // columns past Cout: any valid address, never stored
+        }
     __builtin_amdgcn_s_barrier();                    // barrier A: every wave is done with the ring
+#ifdef PNN_RING_DIAG2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long de1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
         const int lrow = wm * (32 * RT) + rt * 32 + l31;
@@ -331,8 +346,7 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
             for (int g = 0; g < 4; g++) {
                 const int nl = wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
                 const int n = n0 + nl;
-                const int nb = n < p.Cout ? n : 0;    // columns past Cout: computed on valid memory, never stored
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                const f32x4 bv = bvs[nt][g];
                 f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
                 if (p.act) {
                     v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
@@ -360,14 +374,32 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
                 }
             }
     }
+#ifdef PNN_RING_DIAG2
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long de2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __builtin_amdgcn_s_barrier();                    // barrier B: the output tile is complete
+#ifdef PNN_RING_DIAG2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long de3 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     copy_out();
+#ifdef PNN_RING_DIAG2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long de4 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef PNN_RING_DIAG2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.Xlo && tid == 0) {
         unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         const unsigned long long dq3 = __builtin_amdgcn_s_memtime(), dr3 = __builtin_amdgcn_s_memrealtime();
         d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = dq3 - dq2; d[3] = dr3 - dr0;
+        unsigned long long* e = (unsigned long long*)p.Xlo + (1 << 18) + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        e[0] = de1 - dq2; e[1] = de2 - de1; e[2] = de3 - de2; e[3] = de4 - de3; e[4] = dq3 - de4;
     }
 #endif
 }

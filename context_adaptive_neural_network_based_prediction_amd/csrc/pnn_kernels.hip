@@ -187,6 +187,12 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 
     // Epilogue: bias (+ LeakyReLU), float4 store of channels n .. n+3 of this lane's pixel.
     const int py = p.py[cls], px = p.px[cls];
+    f32x4 bvs[NT];                                   // all bias loads before the first store (see pnn_gemm_sp.hip)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int n = n0 + nt * 16 + (q << 2);
+        bvs[nt] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
         if (!mv[rt]) continue;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
         for (int nt = 0; nt < NT; nt++) {
             const int n = n0 + nt * 16 + (q << 2);
             if (n < p.Cout) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 bv = bvs[nt];
                 f32x4 v = acc[rt][nt] + bv;
                 if (p.act) {
                     v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);

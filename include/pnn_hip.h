@@ -63,7 +63,10 @@ const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last err
 float pnn_mean(const pnn_ctx* ctx);
 
 /* Options: "precision" (1, default: tap GEMMs form every f32 product from three f16 MFMAs on hi/lo operand halves --
- * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice),
+ * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice; an
+ * "sp_cfg" code in [0, pnn_num_split_configs()) forces one configuration of one of the three split-GEMM kernels on
+ * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
+ * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never),
  * "autotune" (1: the first call that meets a new (layer, batch size) pair times every legal tile configuration of the
  * split-precision GEMM on the device and keeps the fastest -- do it in a warm-up call, outside any timed region),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
@@ -72,6 +75,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * pair needs; 0 (default) lets small batches use the faster split-K kernel, whose float result can differ in
  * the last bits, i.e. by one LSB on an exact .5 tie). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
+/* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
+int pnn_num_split_configs(void);
 
 /* ---- host-buffer entry points (what the HM side binds; synchronous) ---------------------------------- */
 

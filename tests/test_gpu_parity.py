@@ -275,6 +275,34 @@ def test_torch_device_path_and_empty_batch(pnn, oracle):
         net.predict(a)                                               # conv nets take two inputs
 
 
+@pytest.mark.parametrize("w,is_fc,n", [(8, True, 300), (4, False, 130), (16, False, 21), (32, False, 3)])
+def test_split_gemm_kernel_families_bit_identical(pnn, precision, w, is_fc, n):
+    """The three split-precision GEMM kernels (register-staged tapgemm_sp, LDS-resident-image convimg_sp, LDS-DMA ring
+    with loader waves) and all their tile shapes keep one per-output summation order: forcing any configuration code on
+    every layer it can run must not change a single bit of the float predictions (ragged M, idle rows/columns, taps
+    that leave the image, stride-2 transposed-convolution classes are all in these nets)."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, is_fc, 31, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 32)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    run = (lambda: net.predict(util.flatten_fc(above, left))) if is_fc else (lambda: net.predict(above, left))
+    net.set_option("canonical_order", 1)
+    net.set_option("ring", 0)
+    net.set_option("convimg", 0)
+    want = run()
+    net.set_option("ring", 1)
+    net.set_option("convimg", 1)
+    ncodes = L.pnn_num_split_configs()
+    assert ncodes >= 40
+    for rep in range(2):                                             # a pipeline race would show as a rare wrong tile
+        for code in range(ncodes):
+            net.set_option("sp_cfg", code)
+            assert np.array_equal(run(), want), "split-GEMM configuration code %d changes the result" % code
+
+
 # ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
 def test_full_size_properties(pnn, oracle, w, is_fc, n):

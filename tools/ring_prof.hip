@@ -45,6 +45,14 @@ int main(int argc, char** argv)
 #ifdef PNN_RING_DIAG2
         printf("ring{%d,%d,%d,wm%d,d%d} %3dx%3d  %4d WGs  %7.1f us | wave 0 avg: prologue %6.0f cyc  loop %6.0f cyc (%5.0f/stage, MFMA work %d)  epilogue %6.0f cyc  workgroup lifetime %5.1f us\n",
                t.rt, t.nt, t.kc, t.wm, t.d, bm, bn, nwg, us, s[0] / nwg, s[1] / nwg, s[1] / nwg / nst, t.rt * t.nt * 3 * t.kc * 32, s[2] / nwg, s[3] / nwg / 100.0);
+        {
+            std::vector<unsigned long long> he(8 * (size_t)nwg);
+            hipMemcpy(he.data(), (char*)dd + 8 * (1 << 18), he.size() * 8, hipMemcpyDeviceToHost);
+            double e[5] = {0, 0, 0, 0, 0};
+            for (int w = 0; w < nwg; w++) for (int k = 0; k < 5; k++) e[k] += (double)he[8 * w + k];
+            printf("      epilogue: barrier A %5.0f | scale/bias/split -> LDS %5.0f | barrier B %5.0f | copy-out issue %5.0f | store drain %5.0f\n", e[0] / nwg, e[1] / nwg,
+                   e[2] / nwg, e[3] / nwg, e[4] / nwg);
+        }
         continue;
 #endif
         printf("ring{%d,%d,%d,wm%d,d%d} %3dx%3d  %4d WGs  %7.1f us  %6.1f TF-eq | per stage, wave 0: mfma-a %5.0f  wait+barrier %5.0f  frag+issue %5.0f  mfma-b %5.0f  (MFMA work %d cyc)\n",
