@@ -91,6 +91,7 @@ struct pnn_ctx {
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
+    long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 0;                            // 1: time every split-GEMM tile config on first use of a (layer, M) and keep the best
@@ -517,13 +518,14 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 // Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
 // kernels.  Calibrated with tools/ring_prof.hip: a workgroup costs ~(prologue + epilogue) + stages x 1.45 x its MFMA
 // cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
-static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap)
+static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, bool fused = false)
 {
-    if (!one_tap || (double)M * p.Cout < 2.0e6 || p.Cin < 256) return -1;
+    if (!fused && (!one_tap || (double)M * p.Cout < 2.0e6 || p.Cin < 256)) return -1;
     int best = -1;
     double best_cost = 1e300;
     for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
         const TileCfg t = tapgemm_ring_cfg(i);
+        if (fused && !tapgemm_ring_can_fuse(i)) continue;
         const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
         const long nwg = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
         const int resident = tapgemm_ring_lds_bytes(t) > (size_t)80 * 1024 ? 1 : 2;
@@ -568,10 +570,16 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
     return best < 0 ? 0 : best;
 }
 
+// `next` (optional): a following fully-connected layer with <= 64 outputs that the ring kernel applies to its output tile
+// in LDS; `part` then receives the per-column-tile partial products [tiles][M][64] and *tiles_out their count (the caller
+// finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
 int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
-                long nblocks, hipStream_t s)
+                long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr)
 {
     TapGemmParams p = L.proto;
+    if (next) {
+        p.W2p = next->d_w_sp; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part;
+    }
     p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp;
     static const bool diag = getenv("PNN_SP_DIAG") != nullptr;   // diagnostic library only: phase stamps of every workgroup
     if (diag) {
@@ -594,6 +602,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     auto cfg_of = [&](int code) { return code < nsp ? tapgemm_sp_cfg(code) : code < nsp + nci ? convimg_sp_cfg(code - nsp) : tapgemm_ring_cfg(code - nsp - nci); };
     auto kind_of = [&](int code) { return code < nsp ? "" : code < nsp + nci ? "img" : "ring"; };
     auto legal = [&](int code) {
+        if (next) return code >= nsp + nci && !diag && c->opt_ring && tapgemm_ring_can_fuse(code - nsp - nci);
         if (code < nsp) return one_tap || cpt % tapgemm_sp_cfg(code).kc == 0;
         if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
         return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
@@ -610,14 +619,14 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
-        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap) : -1;
+        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, next != nullptr) : -1;
         if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
     }
     if (c->opt_autotune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
         // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
-        const auto key = std::make_pair((const void*)&L, M);
+        const auto key = std::make_pair((const void*)((const char*)&L + (next ? 1 : 0)), M);
         auto it = c->tuned.find(key);
         if (it == c->tuned.end()) {
             hipEvent_t e0, e1;
@@ -659,7 +668,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         HIPCHK(c, hipEventCreate(&r.e0));
         HIPCHK(c, hipEventCreate(&r.e1));
         r.kind = 2;
-        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
+        r.flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
         HIPCHK(c, hipEventRecord(r.e0, s));
         HIPCHK(c, launch(cfg));
         HIPCHK(c, hipEventRecord(r.e1, s));
@@ -692,6 +701,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     }
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    if (next) {
+        if (!legal(cfg)) return fail(c, PNN_E_ARG, "no ring configuration can fuse the next layer");
+        c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
+        if (tiles_out) *tiles_out = (int)((p.Cout + 32L * t.nt * (4 / t.wm) - 1) / (32L * t.nt * (4 / t.wm)));
+    }
     return PNN_OK;
 }
 
@@ -759,6 +773,18 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
         }
         if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
+        const int n_out = m->fc[3].proto.Cout;
+        if (c->opt_fuse_last && c->opt_ring && !c->opt_canonical && c->opt_sp_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && nb >= 1024) {
+            // last hidden layer + output layer in one launch: the 1200-wide activations of the third hidden layer never
+            // leave the workgroups that produce them (pnn_gemm_ring.hip, FUSE); a small kernel sums the column tiles' partials
+            if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
+            int tiles = 0;
+            if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], (float*)c->ws[3].p, &tiles))) return rc;
+            if (tiles > 20) return fail(c, PNN_E_ARG, "fused layer: %d column tiles exceed the partial buffer", tiles);
+            HIPCHK(c, launch_fuse_reduce((const float*)c->ws[3].p, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
+            c->stat_launches++;
+            return PNN_OK;
+        }
         if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
         return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
     }
@@ -926,6 +952,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
+    if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -1045,6 +1072,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "autotune")) c->opt_autotune = value;
     else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
+    else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);

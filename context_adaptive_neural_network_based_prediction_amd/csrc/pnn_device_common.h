@@ -6,6 +6,21 @@ namespace pnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Kernel arguments live in host-visible memory: the first scalar load of each 64-byte line of the argument block is a
+// round trip of 1-2 us, and the compiler requests the lines one by one where their fields are first used (measured in
+// tapgemm_ring_kernel: 4.5k cycles of "setup").  Touch every line of an N-byte argument block in ONE batch at kernel
+// entry; the later field loads then hit the scalar cache.
+template <int N>
+__device__ __forceinline__ void touch_kernargs()
+{
+    typedef const int __attribute__((address_space(4))) kint;
+    kint* k = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+    int t = 0;
+#pragma unroll
+    for (int off = 0; off < N; off += 64) t += k[off / 4];
+    asm volatile("" ::"s"(t));
+}
+
 __device__ __forceinline__ float leaky(float v) { return fmaxf(0.1f * v, v); }   // pnn/tfutils.py:192
 
 // TComPrediction.cpp:632: (int) std::round(max(0, min(255, p + mean))), half away from zero.

@@ -40,7 +40,7 @@ __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int RT, int NT, int KC, int WM, int D>
+template <int RT, int NT, int KC, int WM, int D, bool FUSE = false>
 __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p)
 {
     constexpr int WN = 4 / WM;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
 #ifdef PNN_RING_DIAG2           // coarse stamps (tools/ring_prof.hip): entry / loop begin / loop end / exit of wave 0
     const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    touch_kernargs<sizeof(TapGemmParams)>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (tid >> 6) & 3;                 // index within the role (MFMA waves 0-3, loader waves 4-7)
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     // 8-byte fragments a lane of the accumulator layout owns (measured: 21k -> see DESIGN.md cycles per workgroup).
     constexpr int OPP = BN / 4 + 1;                  // out-tile row pitch in 16-byte pieces (+1: spreads the rows over the banks)
     static_assert((size_t)BM * OPP <= (size_t)D * SS, "output tile must fit the ring");
+    // FUSE: the NEXT fully-connected layer (at most 64 outputs, no activation) is applied to this workgroup's activated
+    // output tile while it sits in LDS: partial[tile_n][m][0..63] = tile[m][BN columns] x W2[those BN rows][64], the
+    // column tiles' partials are summed (+ bias, HM epilogue) by fuse_reduce_kernel.  W2's BN/16 packed chunks
+    // ([chunk][4 planes][64 columns] pieces) are fetched behind the output tile by the loader waves.
+    constexpr int W2OFF = BM * OPP, W2CH = BN / 16, W2PCS = W2CH * 4 * 64;
+    static_assert(!FUSE || (WM == 4 && (size_t)W2OFF + W2PCS <= (size_t)D * SS && W2PCS % 256 == 0), "fused layer needs WM = 4 and room behind the tile");
     auto copy_out = [&]() {
         if (!p.Yhi) return;
         const int cpy = p.py[cls], cpx = p.px[cls];
@@ -119,11 +126,15 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
             const int mg = mblk + row;
             lv[r] = mg < p.M;
             const int mc = lv[r] ? mg : 0;
-            const int b = mc / SP;
-            const int q = mc - b * SP;
-            lb[r] = b;
-            li[r] = q / p.SW;
-            lj[r] = q - li[r] * p.SW;
+            if (SP == 1) {                            // fully-connected layer (wave-uniform): no divisions on the start-up path
+                lb[r] = mc; li[r] = 0; lj[r] = 0;
+            } else {
+                const unsigned b = (unsigned)mc / (unsigned)SP;
+                const unsigned q = (unsigned)mc - b * (unsigned)SP;
+                lb[r] = (int)b;
+                li[r] = (int)(q / (unsigned)p.SW);
+                lj[r] = (int)(q - (unsigned)li[r] * (unsigned)p.SW);
+            }
         }
         const char* asrc[NLA];                          // source of this lane's piece for chunk 0 of the issue-side tap (or the zero page)
         bool aok[NLA];
@@ -171,11 +182,34 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
         };
 
         // ---- loader pipeline ----
-#pragma unroll
-        for (int s = 0; s < D - 1; s++)
-            if (s < nstages) issue();
-        if (D - 1 <= nstages) wait_vm<(D - 2) * NI>(); else wait_vm<0>();
+#ifdef PNN_RING_DIAG3
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long dl1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        // stages 0 and 1 only: the MFMA waves start as soon as stage 0 has landed (they need stage 1 at barrier 0); the
+        // remaining D-3 stages of lookahead are requested behind the first barrier, off their critical path
+        issue();
+        if (1 < nstages) issue();
+#ifdef PNN_RING_DIAG3
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long dl2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (1 < nstages) wait_vm<NI>(); else wait_vm<0>();
+#ifdef PNN_RING_DIAG3
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long dl3 = __builtin_amdgcn_s_memtime();
+        if (p.Xlo && tid == 256) {
+            unsigned long long* e = (unsigned long long*)p.Xlo + (1 << 19) + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            e[0] = dq0; e[1] = dl1 - dq0; e[2] = dl2 - dl1; e[3] = dl3 - dl2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         __builtin_amdgcn_s_barrier();                // stage 0 is visible
+#pragma unroll
+        for (int s = 2; s < D - 1; s++)
+            if (s < nstages) issue();
         for (int s = 0; s < nstages; s++) {
             if (s + 1 < nstages) {                   // stage s+1 must have landed; later stages may stay in flight
                 if (s + D - 2 < nstages) wait_vm<(D - 3) * NI>(); else wait_vm<0>();
@@ -184,6 +218,18 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
             if (s + D - 1 < nstages) issue();        // into buffer (s-1) % D
         }
         __builtin_amdgcn_s_barrier();                // epilogue barrier A (see below)
+        if (FUSE) {
+            const f32x4* __restrict__ W2 = reinterpret_cast<const f32x4*>(p.W2p);
+#pragma unroll
+            for (int r = 0; r < W2PCS / 256; r++) {
+                const int L = 64 * (wave + 4 * r) + lane;          // piece L = (chunk c, plane q, column n)
+                const int c2 = L >> 8, q2 = (L >> 6) & 3, n2 = L & 63;
+                const int kc2 = (n0 >> 4) + c2;                     // chunk of the next layer's K = our output columns
+                const void* src = kc2 < p.K2chunks ? (const void*)(W2 + ((size_t)kc2 * 4 + q2) * p.Npad2 + n2) : (const void*)(Zb + ((L & 15) << 4));
+                glds16(src, ring + W2OFF + 64 * (wave + 4 * r));
+            }
+            wait_vm<0>();
+        }
         __builtin_amdgcn_s_barrier();                // epilogue barrier B
         copy_out();
         return;
@@ -276,10 +322,22 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
 #ifdef PNN_RING_DIAG2
     const unsigned long long dq1 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef PNN_RING_DIAG3
+    unsigned long long dg3 = 0;
+#endif
     for (int s = 0; s < nstages; s++) {
         const f32x4* buf = ring + (s % D) * SS;
+#ifdef PNN_RING_DIAG3           // time spent waiting at the stage barrier (MFMA wave 0), tools/ring_prof.hip
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long db0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         __builtin_amdgcn_s_barrier();                // barrier s: stage s+1 is visible, buffer (s-1) % D is released
         __builtin_amdgcn_sched_barrier(0);
+#ifdef PNN_RING_DIAG3
+        dg3 += __builtin_amdgcn_s_memtime() - db0;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         DG_STAMP(dg_w);
 #pragma unroll
         for (int j = 0; j + 1 < KC; j++) {
@@ -355,7 +413,7 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
                 asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
                 continue;
 #endif
-                if (p.Yhi) {                          // same values and rounding as store_split4
+                if (p.Yhi || FUSE) {                  // same values and rounding as store_split4
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 hi, lo;
 #pragma unroll
@@ -380,13 +438,64 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     const unsigned long long de2 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    __builtin_amdgcn_s_barrier();                    // barrier B: the output tile is complete
+    __builtin_amdgcn_s_barrier();                    // barrier B: the output tile (and the fused layer's weights) are complete
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long de3 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
     copy_out();
+    if (FUSE) {
+        f32x16 acc2[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc2[rt][nt][i] = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < W2CH; c2++) {
+            f32x4 w2[2][2], a2[RT][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                w2[nt][0] = ring[W2OFF + c2 * 256 + (0 + h) * 64 + nt * 32 + l31];
+                w2[nt][1] = ring[W2OFF + c2 * 256 + (2 + h) * 64 + nt * 32 + l31];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int lrow = wm * (32 * RT) + rt * 32 + l31;
+                a2[rt][0] = ring[lrow * OPP + c2 * 4 + 0 + h];
+                a2[rt][1] = ring[lrow * OPP + c2 * 4 + 2 + h];
+            }
+#pragma unroll
+            for (int part = 0; part < 2; part++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const f16x8 whi = __builtin_bit_cast(f16x8, w2[nt][0]), wlo = __builtin_bit_cast(f16x8, w2[nt][1]);
+                        const f16x8 ahi = __builtin_bit_cast(f16x8, a2[rt][0]), alo = __builtin_bit_cast(f16x8, a2[rt][1]);
+                        if (part == 0) {
+                            acc2[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc2[rt][nt], 0, 0, 0);
+                        } else {
+                            acc2[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc2[rt][nt], 0, 0, 0);
+                            acc2[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc2[rt][nt], 0, 0, 0);
+                        }
+                    }
+        }
+        float* __restrict__ part = p.part + ((size_t)blockIdx.y * p.M) * 64;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int mg = mblk + wm * (32 * RT) + rt * 32 + l31;
+            if (mg >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *reinterpret_cast<f32x4*>(part + (size_t)mg * 64 + nt * 32 + 8 * g + 4 * h) =
+                        (f32x4){acc2[rt][nt][4 * g], acc2[rt][nt][4 * g + 1], acc2[rt][nt][4 * g + 2], acc2[rt][nt][4 * g + 3]};
+        }
+    }
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long de4 = __builtin_amdgcn_s_memtime();
@@ -399,6 +508,9 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
         const unsigned long long dq3 = __builtin_amdgcn_s_memtime(), dr3 = __builtin_amdgcn_s_memrealtime();
         d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = dq3 - dq2; d[3] = dr3 - dr0;
         unsigned long long* e = (unsigned long long*)p.Xlo + (1 << 18) + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+#ifdef PNN_RING_DIAG3
+        e[5] = dg3; e[6] = dq0;
+#endif
         e[0] = de1 - dq2; e[1] = de2 - de1; e[2] = de3 - de2; e[3] = de4 - de3; e[4] = dq3 - de4;
     }
 #endif
@@ -425,27 +537,71 @@ size_t tapgemm_ring_lds_bytes(const TileCfg& t)
     return (size_t)t.d * (bm * 4 * t.kc + (size_t)t.kc * 4 * bn) * 16;
 }
 
-template <int RT, int NT, int KC, int WM, int D>
+// Sums the column tiles' partial products of a fused layer in tile order, undoes the weight scale, adds the bias and
+// writes float and / or HM-epilogue outputs: Y[m][n] = bias[n] + scale * sum_t part[t][m][n], n < N2 <= 64.
+__global__ __launch_bounds__(256) void fuse_reduce_kernel(const float* __restrict__ part, int ntiles, int M, int N2, const float* __restrict__ bias,
+                                                          float scale, float mean, float* __restrict__ Y, int32_t* __restrict__ Yi)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 consecutive columns
+    const int m = (int)(i >> 4), n = (int)(i & 15) << 2;
+    if (m >= M || n >= N2) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ntiles; t++) acc += *reinterpret_cast<const f32x4*>(part + ((size_t)t * M + m) * 64 + n);
+    const f32x4 v = acc * scale + *reinterpret_cast<const f32x4*>(bias + n);
+    if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)m * N2 + n) = v;
+    if (Yi) *reinterpret_cast<int4*>(Yi + (size_t)m * N2 + n) = make_int4(hm_round(v[0], mean), hm_round(v[1], mean), hm_round(v[2], mean), hm_round(v[3], mean));
+}
+
+hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
+                              hipStream_t s)
+{
+    if (M <= 0) return hipSuccess;
+    if (N2 % 4 || N2 > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fuse_reduce_kernel, dim3((unsigned)(((long)M * 16 + 255) / 256)), dim3(256), 0, s, part, ntiles, M, N2, bias, scale, mean, Y, Yi);
+    return hipGetLastError();
+}
+
+template <int RT, int NT, int KC, int WM, int D, bool FUSE = false>
 static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
 {
     constexpr int BM = 32 * RT * WM, BN = 32 * NT * (4 / WM);
     const size_t lds = tapgemm_ring_lds_bytes(TileCfg{RT, NT, KC, 316, WM, D});
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_ring_kernel<RT, NT, KC, WM, D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
-    hipLaunchKernelGGL((tapgemm_ring_kernel<RT, NT, KC, WM, D>), grid, dim3(512), lds, s, p);
+    hipLaunchKernelGGL((tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>), grid, dim3(512), lds, s, p);
     return hipGetLastError();
+}
+
+// Tiles that also exist with the fused next layer (FUSE = true): WM = 4 and room for W2 behind the output tile.
+#define PNN_RING_FUSE_CFGS(X) X(1, 5, 2, 4, 4) X(1, 4, 2, 4, 4) X(1, 3, 2, 4, 4) X(1, 2, 2, 4, 4)
+
+bool tapgemm_ring_can_fuse(int idx)
+{
+    const TileCfg t = tapgemm_ring_cfg(idx);
+#define X(r_, n_, k_, w_, d_) if (t.rt == r_ && t.nt == n_ && t.kc == k_ && t.wm == w_ && t.d == d_) return true;
+    PNN_RING_FUSE_CFGS(X)
+#undef X
+    return false;
 }
 
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s)
 {
     if (p.M <= 0) return hipSuccess;
     if (!p.zero) return hipErrorInvalidValue;
+    if (p.W2p) {                                      // fused next layer requested
+        if (p.ncls != 1 || p.SH * p.SW != 1 || !p.part) return hipErrorInvalidValue;
+        const TileCfg t = tapgemm_ring_cfg(idx);
+#define X(r_, n_, k_, w_, d_) if (t.rt == r_ && t.nt == n_ && t.kc == k_ && t.wm == w_ && t.d == d_) return launch_ring<r_, n_, k_, w_, d_, true>(p, s);
+        PNN_RING_FUSE_CFGS(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
     int i = 0;
 #define X(rt, nt, kc, wm, d) if (idx == i++) return launch_ring<rt, nt, kc, wm, d>(p, s);
     PNN_RING_CFGS(X)

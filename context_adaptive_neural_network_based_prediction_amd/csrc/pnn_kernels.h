@@ -21,6 +21,9 @@ struct TapGemmParams {
     const float* X;    // f32 activations, or the hi f16 plane for the split-precision kernel
     const void* Xlo;   // lo f16 plane (split-precision kernel only)
     const void* zero;  // >= 256 bytes of zeros (ring kernel: source of padding / out-of-range pieces)
+    // ring kernel, fused next fully-connected layer (<= 64 outputs): its split-packed weights, their Npad, the number of
+    // packed 16-deep chunks, and the partial-product buffer [column tiles][M][64] (see pnn_gemm_ring.hip)
+    const float* W2p; int Npad2; int K2chunks; float* part;
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
@@ -55,6 +58,9 @@ hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s);   
 int tapgemm_ring_num_cfgs();
 TileCfg tapgemm_ring_cfg(int idx);
 size_t tapgemm_ring_lds_bytes(const TileCfg& t);
+bool tapgemm_ring_can_fuse(int idx);
+hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
+                              hipStream_t s);
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);

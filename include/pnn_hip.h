@@ -66,7 +66,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice; an
  * "sp_cfg" code in [0, pnn_num_split_configs()) forces one configuration of one of the three split-GEMM kernels on
  * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
- * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never),
+ * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
+ * >= 1024 blocks through a fully-connected PNN with <= 64 outputs run the output layer inside the last hidden layer's
+ * kernel; 0: separate launches),
  * "autotune" (1: the first call that meets a new (layer, batch size) pair times every legal tile configuration of the
  * split-precision GEMM on the device and keeps the fastest -- do it in a warm-up call, outside any timed region),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",

@@ -18,7 +18,7 @@ int main(int argc, char** argv)
     for (auto& v : hx) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
     for (auto& v : hw) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
     void *dx, *dw, *dy, *dz, *dd; float* db;
-    hipMalloc(&dx, xb); hipMalloc(&dw, wb); hipMalloc(&dy, (size_t)M * N * 4); hipMalloc(&dz, 4096); hipMalloc(&dd, 1 << 22);
+    hipMalloc(&dx, xb); hipMalloc(&dw, wb); hipMalloc(&dy, (size_t)M * N * 4); hipMalloc(&dz, 4096); hipMalloc(&dd, 1 << 24);
     hipMalloc(&db, Npad * 4);
     hipMemcpy(dx, hx.data(), xb, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice);
     hipMemset(dz, 0, 4096); hipMemset(db, 0, Npad * 4);
@@ -48,8 +48,19 @@ int main(int argc, char** argv)
         {
             std::vector<unsigned long long> he(8 * (size_t)nwg);
             hipMemcpy(he.data(), (char*)dd + 8 * (1 << 18), he.size() * 8, hipMemcpyDeviceToHost);
-            double e[5] = {0, 0, 0, 0, 0};
-            for (int w = 0; w < nwg; w++) for (int k = 0; k < 5; k++) e[k] += (double)he[8 * w + k];
+            double e[6] = {0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < nwg; w++) for (int k = 0; k < 6; k++) e[k] += (double)he[8 * w + k];
+#ifdef PNN_RING_DIAG3
+            {
+                std::vector<unsigned long long> hl(8 * (size_t)nwg);
+                hipMemcpy(hl.data(), (char*)dd + 8 * (1 << 19), hl.size() * 8, hipMemcpyDeviceToHost);
+                double l[4] = {0, 0, 0, 0};
+                for (int w = 0; w < nwg; w++) { l[0] += (double)((long long)hl[8 * w] - (long long)he[8 * w + 6]); for (int k = 1; k < 4; k++) l[k] += (double)hl[8 * w + k]; }
+                printf("      loader wave 4: starts %5.0f cycles after MFMA wave 0 | setup %5.0f | issue of D-1 stages %5.0f | wait for stage 0 %5.0f\n", l[0] / nwg, l[1] / nwg,
+                       l[2] / nwg, l[3] / nwg);
+            }
+            printf("      stage barrier wait (MFMA wave 0): %5.0f cycles per stage\n", e[5] / nwg / nst);
+#endif
             printf("      epilogue: barrier A %5.0f | scale/bias/split -> LDS %5.0f | barrier B %5.0f | copy-out issue %5.0f | store drain %5.0f\n", e[0] / nwg, e[1] / nwg,
                    e[2] / nwg, e[3] / nwg, e[4] / nwg);
         }

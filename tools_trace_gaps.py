@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (one gather_kernel launch to the
+next), the kernels in launch order with their duration and the idle gap in front of each."""
+import csv, glob, sys
+d = sys.argv[1]
+rows = []
+for f in glob.glob(d + "/*/*_kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("pnn::", "").replace("void ", "")[:40]))
+rows.sort()
+starts = [i for i, r in enumerate(rows) if r[2].startswith("gather_kernel")]
+# the timed steps are the longest run of equally long gather-to-gather segments: take the 6 segments before the last 2
+segs = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
+pick = [s for s in segs if s[1] - s[0] == min(b - a for a, b in segs)][-8:-2]
+tot_busy = tot_span = 0
+for a, b in pick:
+    tot_span += rows[b][0] - rows[a][0]
+    tot_busy += sum(r[1] - r[0] for r in rows[a:b])
+a, b = pick[-1]
+prev_end = rows[a - 1][1]
+print("one step (of %d averaged):" % len(pick))
+for r in rows[a:b]:
+    print("  gap %6.1f us | %-40s %7.1f us" % ((r[0] - prev_end) / 1e3, r[2], (r[1] - r[0]) / 1e3))
+    prev_end = r[1]
+print("mean step span %.1f us, kernels busy %.1f us, idle between kernels %.1f us" % (tot_span / len(pick) / 1e3, tot_busy / len(pick) / 1e3, (tot_span - tot_busy) / len(pick) / 1e3))
