@@ -177,7 +177,9 @@ def main():
     kinds = {}
     for kind, name in ((0, "tapgemm_kernel (exact f32 MFMA 16x16x4, LDS-staged weights)"),
                        (1, "tapgemm_splitk_kernel (f32 MFMA, small M)"),
-                       (2, "tapgemm_sp_kernel (f32-class split products on 3 x f16 MFMA 32x32x16, LDS-staged operands)")):
+                       (2, "tapgemm_sp_kernel (f32-class split products on 3 x f16 MFMA 32x32x16, register-staged operands)"),
+                       (3, "convimg_sp_kernel (same split-product MFMAs, feature maps resident in LDS)"),
+                       (4, "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)")):
         n_k, us_k, fl_k = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
         L.pnn_launch_times(net.ctx, kind, ctypes.byref(n_k), ctypes.byref(us_k), ctypes.byref(fl_k))
         kinds[kind] = {"kernel": name, "launches_timed": n_k.value, "total_us": us_k.value, "flops": fl_k.value}
@@ -187,7 +189,7 @@ def main():
     achieved_tflops = gemm_flops_per_launch / avg_launch_s / 1e12
     # peak: exact-f32 MFMA 157.3 TFLOP/s; the split-precision kernel issues three f16 MFMAs (2.5 PFLOP/s dense) per
     # algorithmic product, so its roof in algorithmic FLOPs is 2500 / 3.
-    peak_tflops = PEAK_F32_MFMA_TFLOPS if dom != 2 else PEAK_F16_MFMA_TFLOPS / 3.0
+    peak_tflops = PEAK_F32_MFMA_TFLOPS if dom < 2 else PEAK_F16_MFMA_TFLOPS / 3.0
     other_launches = nstats["launches"] - nstats["gemm_launches"]
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # PMC pass results (FETCH_SIZE x2 + WRITE_SIZE, per launch)
@@ -244,7 +246,7 @@ def main():
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
                          "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": gemm_flops_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": kinds[dom]["launches_timed"],
-                         "peak_note": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if dom == 2
+                         "peak_note": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if dom >= 2
                                        else "f32 dense MFMA peak at 2.4 GHz"),
                          "frac_of_f32_mfma_peak": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
                          "gemm_launches_per_pass": nstats["gemm_launches"], "non_gemm_launches_per_pass": other_launches,

@@ -667,7 +667,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         pnn_ctx::LaunchRec r;
         HIPCHK(c, hipEventCreate(&r.e0));
         HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = 2;
+        r.kind = cfg < nsp ? 2 : cfg < nsp + nci ? 3 : 4;
         r.flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
         HIPCHK(c, hipEventRecord(r.e0, s));
         HIPCHK(c, launch(cfg));

@@ -23,6 +23,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int RT, int NT, int KC, int WM>
 __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, const int G)
 {
+    touch_kernargs<sizeof(TapGemmParams) + 4>();   // see pnn_device_common.h
     constexpr int WN = 4 / WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int E = 4 * BN;

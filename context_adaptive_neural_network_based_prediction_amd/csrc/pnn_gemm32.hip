@@ -21,6 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int RT, int NT, int KC>
 __global__ __launch_bounds__(256) void tapgemm32_kernel(const TapGemmParams p)
 {
+    touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int BM = 128 * RT;
     constexpr int BN = 32 * NT;
     constexpr int E = 4 * BN;                       // float4 per staged weight chunk

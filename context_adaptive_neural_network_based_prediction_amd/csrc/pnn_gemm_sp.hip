@@ -28,6 +28,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int RT, int NT, int KC, int WM>
 __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
 {
+    touch_kernargs<sizeof(TapGemmParams)>();   // see pnn_device_common.h
     constexpr int WN = 4 / WM;                      // waves along N (WM x WN = 4 waves)
     constexpr int BM = 32 * RT * WM;
     constexpr int BN = 32 * NT * WN;
@@ -215,6 +216,17 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
         for (int j = 0; j + 1 < KC; j++) {
             if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); }
             else       { read_frags(buf, j + 1, wf1, af1); mfma_chunk(wf0, af0, 0); mfma_chunk(wf0, af0, 1); }
+#ifndef PNN_SP_DIAG
+            // issue order: one MFMA, two of the next chunk's fragment reads, ... (two ds_read_b128 fit in the shadow of a
+            // 32-cycle MFMA; as a burst they hold the wave and its MFMA pipe ~16 cycles each -- measured in the ring kernel)
+#pragma unroll
+            for (int i = 0; i < RT + NT; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * RT * NT - (RT + NT), 0);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if ((KC - 1) & 1) { mfma_chunk(wf1, af1, 0); mfma_chunk(wf1, af1, 1); } else { mfma_chunk(wf0, af0, 0); mfma_chunk(wf0, af0, 1); }
         __builtin_amdgcn_sched_barrier(0);

@@ -30,6 +30,7 @@ namespace pnn {
 template <int RT, int NT, int KC>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 {
+    touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int BM = 64 * RT;
     constexpr int BN = 16 * NT;
     constexpr int E = 4 * BN;                       // float4 per staged weight chunk
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 template <int NT>
 __global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams p)
 {
+    touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int BN = 16 * NT;
     __shared__ f32x4 red[4][NT][64];
     const int tid = threadIdx.x;

@@ -20,6 +20,7 @@ namespace pnn {
 template <int K>
 __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
 {
+    touch_kernargs<sizeof(Conv1Params)>();
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int PH = (p.OH - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
     const long b = blockIdx.x;
@@ -73,6 +74,7 @@ hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
 {
+    touch_kernargs<sizeof(TConv1Params)>();
     extern __shared__ __attribute__((aligned(16))) f32x4 xt[];       // [image in WG][Cin/4][TI*TI]
     const int s = p.s, K = p.k;
     const int OH = p.IH * s, OW = p.IW * s;
@@ -175,6 +177,7 @@ hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)
 constexpr int kMergerMB = 2;
 __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
 {
+    touch_kernargs<sizeof(MergerParams)>();
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(gid % p.C);
     const long r = gid / p.C;
@@ -237,6 +240,7 @@ hipError_t launch_merger(const MergerParams& p, hipStream_t s)
 template <typename Pel>
 __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
 {
+    touch_kernargs<sizeof(GatherParams)>();
     const int w = p.w;
     const int na = 3 * w * w, per = 5 * w * w;
     const long total = (long)p.N * per;

@@ -142,8 +142,8 @@ int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_f
 
 /* With pnn_set_option(ctx, "time_launches", 1) every tap-GEMM launch is bracketed by HIP events on its launch
  * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_kernel / tapgemm32_kernel,
- * 1 = tapgemm_splitk_kernel), the number of launches since the last call, their summed duration and their
- * summed algorithmic FLOPs. */
+ * 1 = tapgemm_splitk_kernel, 2 = tapgemm_sp_kernel, 3 = convimg_sp_kernel, 4 = tapgemm_ring_kernel), the number of
+ * launches since the last call, their summed duration and their summed algorithmic FLOPs. */
 int pnn_launch_times(pnn_ctx* ctx, int kind, int* n_launches, double* total_us, double* total_flops);
 
 #ifdef __cplusplus

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the per-round profile evidence on the GPU box into gpurun_out/profiles_<round>/ :
 #   rocprofv3 --kernel-trace --stats of the default bench command (FC 8x8) and of conv16, plus PMC passes
-#   (separate runs, --pmc only) for MFMA utilisation, LDS conflicts and HBM traffic.
+#   (separate runs, --pmc only) for MFMA utilisation, LDS conflicts and HBM traffic, and the step timeline.
 export TMPDIR=/tmp
 r=${1:-r01}
 out=gpurun_out/profiles_$r
@@ -15,10 +15,16 @@ for wl in fc8 conv16; do
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > $out/${wl}_pmc_p$i.log 2>&1
+    PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > $out/${wl}_pmc_p$i.log 2>&1
   done
   python3 tools_pmc_summary.py $wl > $out/${wl}_pmc_summary.txt
   rm -rf $out/${wl}_trace
+done
+python3 tools_pmc_traffic.py $out/pmc_traffic.json fc8 conv16 > /dev/null
+for wl in fc8 conv16; do   # timeline of one steady-state step (rule-based tiles: no tuning launches in the trace)
+  PNN_AUTOTUNE=0 rocprofv3 --kernel-trace --output-format csv -d $out/${wl}_tl -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  python3 tools_trace_gaps.py $out/${wl}_tl > $out/${wl}_step_timeline.txt
+  rm -rf $out/${wl}_tl
 done
 python3 bench.py --steps 100 --warmup 10 > $out/bench_fc8.json 2> $out/bench_fc8.err
 python3 bench.py --workload conv16 --steps 50 --warmup 5 > $out/bench_conv16.json 2> $out/bench_conv16.err
