@@ -39,6 +39,13 @@ __device__ __forceinline__ void wait_vm()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// wait until at most `stages` stages of this wave's LDS-DMA are outstanding; a wave issues HI or HI - 1 instructions per
+// stage (`fewer`, wave-uniform)
+template <int STAGES, int HI>
+__device__ __forceinline__ void wait_stages(bool fewer)
+{
+    if (fewer) wait_vm<STAGES * (HI - 1)>(); else wait_vm<STAGES * HI>();
+}
 
 template <int RT, int NT, int KC, int WM, int D, bool FUSE = false>
 __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p)
@@ -49,11 +56,13 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     constexpr int E = 4 * BN;                       // 16-byte pieces per staged weight chunk
     constexpr int PPR = KC * 4;                     // pieces per activation row and stage
     constexpr int NLA = BM * PPR / 256;             // activation LDS-DMA instructions per wave and stage
-    constexpr int NLB = KC * E / 256;               // weight LDS-DMA instructions per wave and stage
-    constexpr int NI = NLA + NLB;
+    constexpr int NBI = KC * E / 64;                // weight LDS-DMA instructions per stage, dealt round-robin to the 4 loader waves
+    constexpr int NLB = (NBI + 3) / 4;              // ... per wave: NLB for waves < NBX, NLB - 1 for the others (NBX = 0: all NLB)
+    constexpr int NBX = NBI % 4;
+    constexpr int NI = NLA + NLB;                   // upper bound of a wave's instructions per stage
     constexpr int ASLOTS = BM * PPR, SS = ASLOTS + KC * E;
     constexpr int RPS = 16 / PPR > 0 ? 16 / PPR : 1;   // rows per swizzle step
-    static_assert((KC * E) % 256 == 0 && (BM * PPR) % 256 == 0, "stage pieces must split evenly over the 4 waves");
+    static_assert((KC * E) % 64 == 0 && (BM * PPR) % 256 == 0, "stage pieces must split into whole wave instructions");
     static_assert((D - 2) * NI <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D][A pieces | B pieces]
 
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
                 glds16(src, dst + 64 * (wave + 4 * r));
             }
 #pragma unroll
-            for (int r = 0; r < NLB; r++) glds16(bsrc[r] + (size_t)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));
+            for (int r = 0; r < NLB; r++)
+                if (wave + 4 * r < NBI) glds16(bsrc[r] + (size_t)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));   // wave-uniform
             ++istage;
             icc += KC;
             if (icc >= cpt && it + 1 < t1) {             // wave-uniform
@@ -196,7 +206,8 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
         const unsigned long long dl2 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (1 < nstages) wait_vm<NI>(); else wait_vm<0>();
+        const bool fewer = NBX != 0 && wave >= NBX;
+        if (1 < nstages) wait_stages<1, NI>(fewer); else wait_vm<0>();
 #ifdef PNN_RING_DIAG3
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long dl3 = __builtin_amdgcn_s_memtime();
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
             if (s < nstages) issue();
         for (int s = 0; s < nstages; s++) {
             if (s + 1 < nstages) {                   // stage s+1 must have landed; later stages may stay in flight
-                if (s + D - 2 < nstages) wait_vm<(D - 3) * NI>(); else wait_vm<0>();
+                if (s + D - 2 < nstages) wait_stages<D - 3, NI>(fewer); else wait_vm<0>();
             }
             __builtin_amdgcn_s_barrier();            // barrier s
             if (s + D - 1 < nstages) issue();        // into buffer (s-1) % D
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
 #endif
     };
     // ---- MFMA-wave pipeline -----------------------------------------------------------------------------------------
-    static_assert(KC % 2 == 0 && D >= 3, "fragment register sets alternate per chunk");
+    static_assert((KC % 2 == 0 || KC == 1) && D >= 3, "fragment register sets alternate per chunk");
     __builtin_amdgcn_s_barrier();                    // stage 0 is visible
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
@@ -325,36 +336,60 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
 #ifdef PNN_RING_DIAG3
     unsigned long long dg3 = 0;
 #endif
-    for (int s = 0; s < nstages; s++) {
-        const f32x4* buf = ring + (s % D) * SS;
+    auto stage_barrier = [&]() {                     // barrier s: stage s+1 is visible, buffer (s-1) % D is released
 #ifdef PNN_RING_DIAG3           // time spent waiting at the stage barrier (MFMA wave 0), tools/ring_prof.hip
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long db0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        __builtin_amdgcn_s_barrier();                // barrier s: stage s+1 is visible, buffer (s-1) % D is released
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #ifdef PNN_RING_DIAG3
         dg3 += __builtin_amdgcn_s_memtime() - db0;
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        DG_STAMP(dg_w);
-#pragma unroll
-        for (int j = 0; j + 1 < KC; j++) {
-            if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1); }
-            else       { read_frags(buf, j + 1, wf1, af1); mfma_chunk(wf0, af0); }
+    };
+    if constexpr (KC == 1) {
+        // one 16-deep chunk per stage: twice the ring depth in the same LDS.  Measured SLOWER (FC 1200x1200: 2030 cycles per
+        // 32 of K against 1450 with KC = 2, D = 4): an activation row is then fetched in 64-byte pieces, half a cache line
+        // per request, and the loader waves fall behind.  Kept as two configurations for the record; the fragment sets
+        // alternate per STAGE, hence the loop over stage pairs
+        for (int s = 0; s < nstages; s += 2) {
+            stage_barrier();
+            read_frags(ring + ((s + 1) % D) * SS, 0, wf1, af1);      // after the last stage: stale buffer, values dropped
+            mfma_chunk(wf0, af0);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nstages) {
+                stage_barrier();
+                read_frags(ring + ((s + 2) % D) * SS, 0, wf0, af0);
+                mfma_chunk(wf1, af1);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        DG_STAMP(dg_a);
-        // first fragments of the next stage -- unconditional (after the last stage they come from a stale buffer and are
-        // dropped): behind a branch the compiler's merged wait state makes the next MFMA wait for THESE reads too
-        read_frags(ring + ((s + 1) % D) * SS, 0, wf0, af0);
-        DG_STAMP(dg_i);
-        mfma_chunk(wf1, af1);                        // chunk KC-1 (KC even: its fragments are in set 1)
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        DG_STAMP(dg_b);
+    } else {
+        for (int s = 0; s < nstages; s++) {
+            const f32x4* buf = ring + (s % D) * SS;
+            stage_barrier();
+            DG_STAMP(dg_w);
+#pragma unroll
+            for (int j = 0; j + 1 < KC; j++) {
+                if (j & 1) { read_frags(buf, j + 1, wf0, af0); mfma_chunk(wf1, af1); }
+                else       { read_frags(buf, j + 1, wf1, af1); mfma_chunk(wf0, af0); }
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DG_STAMP(dg_a);
+            // first fragments of the next stage -- unconditional (after the last stage they come from a stale buffer and are
+            // dropped): behind a branch the compiler's merged wait state makes the next MFMA wait for THESE reads too
+            read_frags(ring + ((s + 1) % D) * SS, 0, wf0, af0);
+            DG_STAMP(dg_i);
+            mfma_chunk(wf1, af1);                    // chunk KC-1 (KC even: its fragments are in set 1)
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            DG_STAMP(dg_b);
+        }
     }
 #ifdef PNN_RING_DIAG
     if (p.Xlo && tid == 0) {
@@ -520,7 +555,8 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
 #define PNN_RING_CFGS(X) \
     X(1, 4, 2, 4, 4) X(1, 4, 2, 4, 3) X(2, 2, 2, 2, 4) X(2, 2, 2, 2, 3) X(2, 4, 2, 4, 3) X(4, 2, 2, 2, 3) X(2, 3, 2, 2, 3) X(1, 3, 2, 4, 3) \
     X(1, 2, 2, 4, 4) X(1, 2, 2, 4, 3) X(2, 1, 2, 2, 4) X(2, 1, 2, 2, 3) X(1, 2, 2, 2, 4) X(2, 2, 2, 4, 3) X(1, 5, 2, 4, 4) X(1, 5, 2, 4, 3) \
-    X(2, 3, 2, 4, 3) X(3, 2, 2, 2, 3) X(1, 3, 2, 4, 4) X(2, 3, 2, 2, 4)
+    X(2, 3, 2, 4, 3) X(3, 2, 2, 2, 3) X(1, 3, 2, 4, 4) X(2, 3, 2, 2, 4) \
+    X(1, 5, 1, 4, 8) X(1, 2, 1, 4, 8)
 
 static const TileCfg kCfgsRing[] = {
 #define X(rt, nt, kc, wm, d) {rt, nt, kc, 316, wm, d},
