@@ -34,6 +34,7 @@ SIGNATURES = {
     "pnn_mean": (ctypes.c_float, [vp]),
     "pnn_set_option": (ci, [vp, ctypes.c_char_p, ctypes.c_long]),
     "pnn_num_split_configs": (ci, []),
+    "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),
     "pnn_predict_conv": (ci, [vp, ci, f32p, f32p, ci, f32p]),
     "pnn_predict_pel": (ci, [vp, ci, f32p, f32p, ci, i32p, ci]),

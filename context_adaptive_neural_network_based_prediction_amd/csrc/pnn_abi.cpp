@@ -85,6 +85,12 @@ struct pnn_ctx {
     Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf ws[4];                                     // P0, P1, F0, F1 (FC uses P0, P1)
     DevBuf stage_in[2], stage_out[2], stage_tbs;
+    // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
+    // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.
+    struct CacheEntry { uint64_t hash = 0; bool valid = false; std::vector<float> in, out; std::vector<int32_t> pel; };
+    std::vector<CacheEntry> cache[5];
+    long opt_cache_mb = 0;                            // 0 = off
+    long cache_hits = 0, cache_misses = 0;
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
@@ -123,6 +129,11 @@ int fail(pnn_ctx* c, int code, const char* fmt, ...)
         hipError_t e_ = (expr);                                                                     \
         if (e_ != hipSuccess) return fail((c), PNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+void cache_clear(pnn_ctx* c)
+{
+    for (auto& t : c->cache) { t.clear(); t.shrink_to_fit(); }
+}
 
 int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
 {
@@ -973,6 +984,7 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
     free_model(c->models[idx]);
     c->models[idx] = m;
     c->tuned.clear();                                 // keys point into the replaced model
+    cache_clear(c);
     return PNN_OK;
 }
 
@@ -1073,9 +1085,11 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
+    else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
+    cache_clear(c);                                   // any option may change the arithmetic path: cached predictions are dropped
     return PNN_OK;
 }
 
@@ -1210,6 +1224,13 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
 
 // ---- host-buffer entry points ----------------------------------------------------------------------------
 
+static uint64_t fnv1a(const void* data, size_t bytes, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst,
                         int dst_stride)
 {
@@ -1217,6 +1238,30 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     const long w2 = (long)w * w;
     if (n < 0 || (n > 0 && (!above || (!out && !dst)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     if (n == 0) return PNN_OK;
+    if (!m->is_fc && !left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
+    // ---- prediction cache (single-block calls only) ----
+    pnn_ctx::CacheEntry* slot = nullptr;
+    uint64_t hash = 0;
+    const size_t na = (size_t)(m->is_fc ? 5 : 3) * w2, nl = m->is_fc ? 0 : (size_t)2 * w2;
+    if (n == 1 && c->opt_cache_mb > 0) {
+        const int wi = width_index(w);
+        auto& table = c->cache[wi];
+        if (table.empty()) {
+            const size_t entry = (na + nl + 2 * w2) * 4 + 64;
+            table.resize(std::max<size_t>(16, ((size_t)c->opt_cache_mb << 20) / 5 / entry));
+        }
+        hash = fnv1a(above, na * 4);
+        if (nl) hash = fnv1a(left, nl * 4, hash);
+        slot = &table[hash % table.size()];
+        if (slot->valid && slot->hash == hash && !memcmp(slot->in.data(), above, na * 4) && (!nl || !memcmp(slot->in.data() + na, left, nl * 4))) {
+            c->cache_hits++;
+            if (out) memcpy(out, slot->out.data(), w2 * 4);
+            if (dst)
+                for (int y = 0; y < w; y++) memcpy(dst + (size_t)y * dst_stride, slot->pel.data() + (size_t)y * w, (size_t)w * 4);
+            return PNN_OK;
+        }
+        c->cache_misses++;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     reset_stats(c);
     int rc;
@@ -1227,12 +1272,10 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if ((rc = dev_reserve(c, c->stage_out[0], (size_t)n * w2 * 4))) return rc;
     if (dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->stage_in[0].p, above, in_a, hipMemcpyHostToDevice, s));
-    if (in_l) {
-        if (!left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
-        HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
-    }
+    if (in_l) HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
+    if (slot && !dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;   // a cached entry serves both result kinds
     float* d_out = (float*)c->stage_out[0].p;
-    int32_t* d_dst = dst ? (int32_t*)c->stage_out[1].p : nullptr;
+    int32_t* d_dst = (dst || slot) ? (int32_t*)c->stage_out[1].p : nullptr;
     rc = run_net(c, m, (const float*)c->stage_in[0].p, m->is_fc ? 5 * w2 : 3 * w2, (const float*)c->stage_in[1].p, 2 * w2, n,
                  d_out, d_dst, s);
     if (rc) return rc;
@@ -1242,7 +1285,24 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         else HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, d_dst, (size_t)w * 4, (size_t)w * 4, (size_t)n * w,
                                         hipMemcpyDeviceToHost, s));
     }
+    if (slot) {
+        slot->valid = false;
+        slot->in.resize(na + nl); slot->out.resize(w2); slot->pel.resize(w2);
+        memcpy(slot->in.data(), above, na * 4);
+        if (nl) memcpy(slot->in.data() + na, left, nl * 4);
+        HIPCHK(c, hipMemcpyAsync(slot->out.data(), d_out, w2 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(slot->pel.data(), d_dst, w2 * 4, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(c, hipStreamSynchronize(s));
+    if (slot) { slot->hash = hash; slot->valid = true; }
+    return PNN_OK;
+}
+
+int pnn_cache_stats(pnn_ctx* c, long* hits, long* misses)
+{
+    if (!c) return PNN_E_ARG;
+    if (hits) *hits = c->cache_hits;
+    if (misses) *misses = c->cache_misses;
     return PNN_OK;
 }
 

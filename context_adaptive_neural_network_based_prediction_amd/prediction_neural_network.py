@@ -151,6 +151,12 @@ class PredictionNeuralNetwork(object):
         self._L.pnn_last_call_stats(self._ctx, ctypes.byref(ng), ctypes.byref(fl), ctypes.byref(nl))
         return {"gemm_launches": ng.value, "gemm_flops": fl.value, "launches": nl.value}
 
+    def cache_stats(self):
+        """(hits, misses) of the single-block prediction cache (option "cache_mb")."""
+        h, m = ctypes.c_long(), ctypes.c_long()
+        self._L.pnn_cache_stats(self._ctx, ctypes.byref(h), ctypes.byref(m))
+        return h.value, m.value
+
 
 def divide_ints_check_divisible(numerator, denominator):
     """tools/tools.py:403-434."""

@@ -68,7 +68,10 @@ float pnn_mean(const pnn_ctx* ctx);
  * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
  * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
  * >= 1024 blocks through a fully-connected PNN with <= 64 outputs run the output layer inside the last hidden layer's
- * kernel; 0: separate launches),
+ * kernel; 0: separate launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
+ * _conv with n == 1, what HM issues -- are answered from a direct-mapped cache of that many MiB when the same input
+ * bytes were predicted before: HM's rate-distortion search asks for the same block repeatedly; exact
+ * match on the inputs, dropped whenever a model or an option changes),
  * "autotune" (1: the first call that meets a new (layer, batch size) pair times every legal tile configuration of the
  * split-precision GEMM on the device and keeps the fastest -- do it in a warm-up call, outside any timed region),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
@@ -79,6 +82,8 @@ float pnn_mean(const pnn_ctx* ctx);
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
 int pnn_num_split_configs(void);
+/* Hits / misses of the "cache_mb" prediction cache since the option was last set. */
+int pnn_cache_stats(pnn_ctx* ctx, long* hits, long* misses);
 
 /* ---- host-buffer entry points (what the HM side binds; synchronous) ---------------------------------- */
 

@@ -303,6 +303,31 @@ def test_split_gemm_kernel_families_bit_identical(pnn, precision, w, is_fc, n):
             assert np.array_equal(run(), want), "split-GEMM configuration code %d changes the result" % code
 
 
+@pytest.mark.parametrize("w,is_fc", [(8, True), (16, False)])
+def test_prediction_cache_for_single_block_calls(pnn, w, is_fc):
+    """`cache_mb`: a repeated single-block call (HM's RDO re-evaluates the same TB) is answered from the cache with the
+    very same values, for both result kinds; a different context misses; changing an option drops the entries."""
+    params = util.make_params(w, is_fc, 41, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, 3, 42)
+    net = pnn.PredictionNeuralNetwork(1, w, is_fc, params=params)
+    one = (lambda i: (util.flatten_fc(above[i:i + 1], left[i:i + 1]),)) if is_fc else (lambda i: (above[i:i + 1], left[i:i + 1]))
+    ref_f = [net.predict(*one(i)).copy() for i in range(3)]
+    ref_p = [net.predict_pel(*one(i)).copy() for i in range(3)]
+    net.set_option("cache_mb", 8)
+    assert net.cache_stats() == (0, 0)
+    assert np.array_equal(net.predict_pel(*one(0)), ref_p[0])      # miss, fills the entry
+    assert net.cache_stats() == (0, 1)
+    assert np.array_equal(net.predict_pel(*one(0)), ref_p[0])      # hit
+    assert np.array_equal(net.predict(*one(0)), ref_f[0])          # hit: the entry holds the float prediction too
+    assert net.cache_stats() == (2, 1)
+    assert np.array_equal(net.predict(*one(1)), ref_f[1])          # other context: miss
+    assert np.array_equal(net.predict_pel(*one(2)), ref_p[2])
+    assert net.cache_stats() == (2, 3)
+    net.set_option("canonical_order", 1)                            # any option change drops the cache
+    net.predict_pel(*one(0))
+    assert net.cache_stats()[1] == 4
+
+
 # ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
 def test_full_size_properties(pnn, oracle, w, is_fc, n):
