@@ -46,6 +46,8 @@ SIGNATURES = {
     "pnn_make_tb_desc": (ci, [ctypes.POINTER(TbDev), ctypes.c_int64, ctypes.c_int32, u8p, ci, ci, ci]),
     "pnn_gather_device": (ci, [vp, ci, ci, vp, ci, vp, ci, vp, ctypes.c_long, vp, ctypes.c_long, vp]),
     "pnn_predict_tbs_device": (ci, [vp, ci, vp, ci, vp, ci, vp, vp, vp]),
+    "pnn_block_cost_device": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp]),
+    "pnn_predict_tbs_cost_device": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, vp, vp, vp]),
     "pnn_last_call_stats": (ci, [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci)]),
     "pnn_launch_times": (ci, [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }

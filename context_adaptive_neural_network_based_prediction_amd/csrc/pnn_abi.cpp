@@ -1222,6 +1222,36 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
     return PNN_OK;
 }
 
+int pnn_block_cost_device(pnn_ctx* c, int width, const void* d_org_plane, int pel_bytes, const pnn_tb_dev* d_tbs, int n,
+                          const int32_t* d_pred, int hadamard, uint32_t* d_cost, void* stream)
+{
+    if (!c) return PNN_E_ARG;
+    if (width_index(width) < 0 || n < 0 || (n > 0 && (!d_org_plane || !d_tbs || !d_pred || !d_cost))) return fail(c, PNN_E_ARG, "bad cost arguments");
+    if (pel_bytes != 4 && pel_bytes != 1) return fail(c, PNN_E_ARG, "pel_bytes must be 4 (HM Pel) or 1 (uint8)");
+    HIPCHK(c, hipSetDevice(c->device));
+    BlockCostParams b;
+    b.org_plane = d_org_plane; b.pel_bytes = pel_bytes; b.tbs = reinterpret_cast<const TbDev*>(d_tbs); b.N = n; b.w = width;
+    b.pred = d_pred; b.hadamard = hadamard; b.cost = d_cost;
+    HIPCHK(c, launch_block_cost(b, (hipStream_t)stream));
+    return PNN_OK;
+}
+
+int pnn_predict_tbs_cost_device(pnn_ctx* c, int width, const void* d_plane, const void* d_org_plane, int pel_bytes,
+                                const pnn_tb_dev* d_tbs, int n, int hadamard, uint32_t* d_cost, int32_t* d_dst, void* stream)
+{
+    if (!c) return PNN_E_ARG;
+    if (n > 0 && (!d_org_plane || !d_cost)) return fail(c, PNN_E_ARG, "bad cost arguments");
+    int rc;
+    if (!d_dst && n > 0) {                            // the predictions themselves are not wanted: keep them in the context's buffer
+        if ((rc = dev_reserve(c, c->stage_out[1], (size_t)n * width * width * 4))) return rc;
+        d_dst = (int32_t*)c->stage_out[1].p;
+    }
+    if ((rc = pnn_predict_tbs_device(c, width, d_plane, pel_bytes, d_tbs, n, d_dst, nullptr, stream))) return rc;
+    rc = pnn_block_cost_device(c, width, d_org_plane, pel_bytes, d_tbs, n, d_dst, hadamard, d_cost, stream);
+    if (rc == PNN_OK) c->stat_launches++;
+    return rc;
+}
+
 // ---- host-buffer entry points ----------------------------------------------------------------------------
 
 static uint64_t fnv1a(const void* data, size_t bytes, uint64_t h = 1469598103934665603ull)

@@ -110,6 +110,12 @@ struct GatherParams {
 };
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);
 
+// (f4) HM distortion (HADs or SAD) of predicted blocks [N][w][w] against the original picture at the descriptors' positions.
+struct BlockCostParams {
+    const void* org_plane; int pel_bytes; const TbDev* tbs; int N; int w; const int32_t* pred; int hadamard; uint32_t* cost;
+};
+hipError_t launch_block_cost(const BlockCostParams& p, hipStream_t s);
+
 // Stand-alone HM epilogue for float predictions.
 hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, hipStream_t s);
 

@@ -296,4 +296,74 @@ hipError_t launch_epilogue(const float* pred, long n, float mean, int32_t* dst, 
     return hipGetLastError();
 }
 
+// (f4) Distortion of N predicted blocks against the original picture, as HM's first intra pass computes it for a
+// candidate mode (TEncSearch.cpp:2376-2389 -> TComRdCost::xGetHADs / xGetSAD, TComRdCost.cpp:1753-1824, 1549-1751):
+// one thread per 8x8 (4x4 for 4-wide blocks) sub-block, Walsh-Hadamard transform in registers, integer adds only
+// (the per-block sum over sub-blocks is an integer atomicAdd: order-independent, bit-exact).
+template <int T>
+__device__ __forceinline__ void wht_rows_cols(int (&d)[T * T])
+{
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {            // rows, then columns
+        const int es = pass == 0 ? 1 : T, vs = pass == 0 ? T : 1;
+#pragma unroll
+        for (int v = 0; v < T; v++)
+#pragma unroll
+            for (int len = 1; len < T; len <<= 1)
+#pragma unroll
+                for (int i = 0; i < T; i += len << 1)
+#pragma unroll
+                    for (int j = i; j < i + len; j++) {
+                        const int a = d[v * vs + j * es], b = d[v * vs + (j + len) * es];
+                        d[v * vs + j * es] = a + b;
+                        d[v * vs + (j + len) * es] = a - b;
+                    }
+    }
+}
+
+template <typename Pel, int T>
+__global__ __launch_bounds__(256) void block_cost_kernel(const BlockCostParams p)
+{
+    const int per = (p.w / T) * (p.w / T);
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)p.N * per) return;
+    const int blk = (int)(gid / per), sb = (int)(gid - (long)blk * per);
+    const int by = (sb / (p.w / T)) * T, bx = (sb % (p.w / T)) * T;
+    const TbDev tb = p.tbs[blk];
+    const Pel* org = reinterpret_cast<const Pel*>(p.org_plane) + tb.origin + (long)by * tb.stride + bx;
+    const int32_t* cur = p.pred + ((size_t)blk * p.w + by) * p.w + bx;
+    int d[T * T];
+#pragma unroll
+    for (int y = 0; y < T; y++)
+#pragma unroll
+        for (int x = 0; x < T; x++) d[y * T + x] = (int)org[(long)y * tb.stride + x] - cur[y * p.w + x];
+    unsigned s = 0;
+    if (p.hadamard) {
+        wht_rows_cols<T>(d);
+#pragma unroll
+        for (int k = 0; k < T * T; k++) s += (unsigned)abs(d[k]);
+        s = T == 8 ? (s + 2) >> 2 : (s + 1) >> 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < T * T; k++) s += (unsigned)abs(d[k]);
+    }
+    atomicAdd(p.cost + blk, s);
+}
+
+hipError_t launch_block_cost(const BlockCostParams& p, hipStream_t s)
+{
+    if (p.N <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(p.cost, 0, (size_t)p.N * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const int t = p.w >= 8 ? 8 : 4;
+    const long threads = (long)p.N * (p.w / t) * (p.w / t);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (p.pel_bytes == 4 && t == 8) hipLaunchKernelGGL((block_cost_kernel<int32_t, 8>), grid, block, 0, s, p);
+    else if (p.pel_bytes == 4) hipLaunchKernelGGL((block_cost_kernel<int32_t, 4>), grid, block, 0, s, p);
+    else if (p.pel_bytes == 1 && t == 8) hipLaunchKernelGGL((block_cost_kernel<uint8_t, 8>), grid, block, 0, s, p);
+    else if (p.pel_bytes == 1) hipLaunchKernelGGL((block_cost_kernel<uint8_t, 4>), grid, block, 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace pnn

@@ -141,6 +141,17 @@ int pnn_gather_device(pnn_ctx* ctx, int width, int unit, const void* d_plane, in
 int pnn_predict_tbs_device(pnn_ctx* ctx, int width, const void* d_plane, int pel_bytes, const pnn_tb_dev* d_tbs,
                            int n, int32_t* d_dst, float* d_out_f32, void* stream);
 
+/* Distortion of n predicted blocks d_pred [n][w][w] against the ORIGINAL picture d_org_plane (same geometry as the
+ * reconstructed plane: the descriptors' origin / stride address both), as HM's first intra pass computes it for a
+ * candidate mode (TEncSearch.cpp:2376-2389, distParam.DistFunc): hadamard != 0 -> TComRdCost::xGetHADs (8x8 / 4x4
+ * Hadamard SATD, TComRdCost.cpp:1753-1824), 0 -> SAD; 8-bit video.  Integer arithmetic, bit-exact. */
+int pnn_block_cost_device(pnn_ctx* ctx, int width, const void* d_org_plane, int pel_bytes, const pnn_tb_dev* d_tbs, int n,
+                          const int32_t* d_pred, int hadamard, uint32_t* d_cost, void* stream);
+/* pnn_predict_tbs_device followed by pnn_block_cost_device on the same stream: only the n cost scalars need to leave
+ * the device for candidates that are not selected (d_dst may be NULL). */
+int pnn_predict_tbs_cost_device(pnn_ctx* ctx, int width, const void* d_plane, const void* d_org_plane, int pel_bytes,
+                                const pnn_tb_dev* d_tbs, int n, int hadamard, uint32_t* d_cost, int32_t* d_dst, void* stream);
+
 /* Per-launch accounting of the last *_device call (for bench.py's roofline object): number of tap-GEMM
  * launches and their algorithmic FLOPs (2 * M * K * N summed, padding excluded). */
 int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_flops, int* n_launches);

@@ -24,7 +24,8 @@ def build(force=False):
             os.path.join(_HERE, "pnn_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(
-            os.path.join(_HERE, "_ref", "libref_extract.so"))):
+            os.path.join(_HERE, "_ref", "libref_extract.so")) or not os.path.exists(
+            os.path.join(_HERE, "_ref", "libref_rdcost.so"))):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -184,6 +185,46 @@ def dense(x, W, b, act):
     y = np.empty((x.shape[0], W.shape[1]), np.float32)
     lib().oracle_dense(_p(x, _f32p), _p(W, _f32p), _p(b, _f32p), _p(y, _f32p), x.shape[0], W.shape[0], W.shape[1], int(act))
     return y
+
+
+def block_costs(org_plane, xs, ys, w, pred, hadamard=True, use_ref=False):
+    """Distortion (HM's HADs / SAD, first intra pass) of N predicted blocks [N][w][w] against the original picture.
+    use_ref=True: the reference's own TComRdCost (oracle/_ref/libref_rdcost.so), block by block."""
+    org_plane = _c(org_plane, np.int32); pred = _c(pred, np.int32)
+    xs = _c(xs, np.int32); ys = _c(ys, np.int32)
+    N = xs.size
+    cost = np.empty(N, np.uint32)
+    if use_ref:
+        R = ref_rdcost_lib()
+        for i in range(N):
+            blk = np.ascontiguousarray(org_plane[ys[i]:ys[i] + w, xs[i]:xs[i] + w])
+            cost[i] = R.ref_block_cost(_p(blk, _i32p), w, _p(np.ascontiguousarray(pred[i]), _i32p), w, w, w, int(hadamard))
+        return cost
+    L = lib()
+    L.oracle_block_costs.restype = None
+    L.oracle_block_costs(_p(org_plane, _i32p), org_plane.shape[1], _p(xs, _i32p), _p(ys, _i32p), N, w, _p(pred, _i32p),
+                         int(hadamard), cost.ctypes.data_as(ctypes.c_void_p))
+    return cost
+
+
+_REF_RD = None
+
+
+def ref_rdcost_lib():
+    """The reference's TComRdCost behind a C shim (oracle/_ref); None when it was never built."""
+    global _REF_RD
+    if _REF_RD is None:
+        path = os.path.join(_HERE, "_ref", "libref_rdcost.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference"):
+                build()
+            if not os.path.exists(path):
+                return None
+        R = ctypes.CDLL(path)
+        R.ref_block_cost.restype = ctypes.c_uint
+        R.ref_block_cost.argtypes = [_i32p, ctypes.c_int, _i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _REF_RD = R
+    return _REF_RD
 
 
 def predict_tbs(params, w, is_fc, plane, xs, ys, flags, mean):

@@ -214,3 +214,24 @@ def test_param_counts(oracle):
               (16, False): 1339073, (32, False): 5622657, (64, False): 20652545}
     for (w, fc), n in expect.items():
         assert wts.param_count(w, fc) == n == oracle.param_count(w, fc)
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("hadamard", [True, False])
+def test_block_cost_equals_reference_rdcost(oracle, w, hadamard):
+    """(f4) the oracle's HADs / SAD restatement vs the reference's own TComRdCost (compiled into oracle/_ref):
+    random blocks, an exact copy (cost 0), a flat offset and extreme contrast."""
+    if oracle.ref_rdcost_lib() is None:
+        pytest.skip("reference checkout absent and oracle/_ref/libref_rdcost.so not prebuilt")
+    rs = np.random.RandomState(100 + w)
+    plane = rs.randint(0, 256, (160, 224)).astype(np.int32)
+    n = 24
+    xs, ys = rs.randint(0, 224 - w, n), rs.randint(0, 160 - w, n)
+    pred = rs.randint(0, 256, (n, w, w)).astype(np.int32)
+    pred[0] = plane[ys[0]:ys[0] + w, xs[0]:xs[0] + w]
+    pred[1] = np.clip(plane[ys[1]:ys[1] + w, xs[1]:xs[1] + w] + 7, 0, 255)
+    pred[2] = 255 * (rs.rand(w, w) > 0.5)
+    got = oracle.block_costs(plane, xs, ys, w, pred, hadamard)
+    want = oracle.block_costs(plane, xs, ys, w, pred, hadamard, use_ref=True)
+    assert got[0] == 0
+    assert np.array_equal(got, want)
