@@ -22,6 +22,17 @@ class TbDev(ctypes.Structure):
                 ("left_units", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+BACKEND = ctypes.CFUNCTYPE(ci, vp, ci, f32p, f32p, ci, i32p)   # pnn_service_backend of include/pnn_service.h
+
+# include/pnn_service.h (cross-process batching service); same conventions
+SERVICE_SIGNATURES = {
+    "pnn_service_run_backend": (ci, [ctypes.c_char_p, BACKEND, vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
+    "pnn_service_run": (ci, [ctypes.c_char_p, vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
+    "pnn_client_connect": (ci, [ctypes.POINTER(vp), ctypes.c_char_p]),
+    "pnn_client_predict_pel": (ci, [vp, ci, f32p, f32p, i32p, ci]),
+    "pnn_client_close": (None, [vp]),
+}
+
 # name -> (restype, argtypes); also the list the symbol-export test walks.
 SIGNATURES = {
     "pnn_create_empty": (ci, [ctypes.POINTER(vp), ctypes.c_float, ci]),
@@ -69,7 +80,7 @@ def lib():
         except ImportError:
             pass
         L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(SERVICE_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

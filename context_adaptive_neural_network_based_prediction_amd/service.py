@@ -1,0 +1,116 @@
+"""Cross-process batching service (include/pnn_service.h).
+
+One server process owns the GPU context; encoder processes (HM links the C client stub, Python tools use `Client`)
+send their single-block requests over a Unix-domain socket and the server coalesces the requests of one width that are
+pending at the same time into one batched `pnn_predict_pel` call.
+
+    python -m context_adaptive_neural_network_based_prediction_amd.service --socket /tmp/pnn.sock --table single.txt
+
+`serve_in_thread` runs the same loop in a background thread of this process (tests, notebooks).
+"""
+import argparse
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+
+class Server:
+    """The C server loop (`pnn_service_run` / `pnn_service_run_backend`) in a background thread."""
+
+    def __init__(self, socket_path, ctx=None, backend=None, max_batch=256, window_us=200):
+        if (ctx is None) == (backend is None):
+            raise ValueError("give exactly one of `ctx` (a pnn context handle) and `backend` (a Python callable)")
+        self._L = _lib.lib()
+        self._stop = ctypes.c_int(0)
+        self._stats = (ctypes.c_long * 4)()
+        self.rc = None
+        path = socket_path.encode()
+        if backend is not None:
+            def trampoline(user, width, above, left, n, dst):
+                w2 = width * width
+                na = (3 if left else 5) * w2
+                a = np.ctypeslib.as_array(above, shape=(n, na))
+                l = np.ctypeslib.as_array(left, shape=(n, 2 * w2)) if left else None
+                out = np.ctypeslib.as_array(dst, shape=(n, width, width))
+                try:
+                    out[...] = backend(width, a, l)
+                    return 0
+                except Exception:                      # nothing may propagate into the C loop
+                    return -1
+            self._cb = _lib.BACKEND(trampoline)       # keep the callback object alive
+            target = lambda: self._L.pnn_service_run_backend(path, self._cb, None, max_batch, window_us, ctypes.byref(self._stop), self._stats)
+        else:
+            target = lambda: self._L.pnn_service_run(path, ctx, max_batch, window_us, ctypes.byref(self._stop), self._stats)
+
+        def run():
+            self.rc = target()
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        """Stops the loop and returns {"requests", "backend_calls", "largest_batch", "clients"}."""
+        self._stop.value = 1
+        self._thread.join()
+        s = self._stats
+        return {"requests": s[0], "backend_calls": s[1], "largest_batch": s[2], "clients": s[3]}
+
+
+def serve_in_thread(socket_path, **kw):
+    return Server(socket_path, **kw)
+
+
+class Client:
+    """`pnn_client_*`: what an encoder process uses instead of a GPU context."""
+
+    def __init__(self, socket_path, retries=200):
+        import time
+        self._L = _lib.lib()
+        self._c = ctypes.c_void_p()
+        for _ in range(retries):                       # the server may still be binding its socket
+            if self._L.pnn_client_connect(ctypes.byref(self._c), socket_path.encode()) == 0:
+                return
+            time.sleep(0.01)
+        raise ConnectionError("no PNN service at %s" % socket_path)
+
+    def predict_pel(self, width, above, left=None):
+        a = np.ascontiguousarray(above, np.float32)
+        l = None if left is None else np.ascontiguousarray(left, np.float32)
+        dst = np.empty((width, width), np.int32)
+        rc = self._L.pnn_client_predict_pel(self._c, width, a.ctypes.data_as(_lib.f32p), None if l is None else l.ctypes.data_as(_lib.f32p),
+                                            dst.ctypes.data_as(_lib.i32p), width)
+        if rc != 0:
+            raise _lib.PnnError("service returned %d" % rc)
+        return dst
+
+    def close(self):
+        if self._c:
+            self._L.pnn_client_close(self._c)
+            self._c = ctypes.c_void_p()
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--socket", required=True)
+    ap.add_argument("--table", required=True, help="model table (width,is_pair,channel,path per line)")
+    ap.add_argument("--pair", type=int, default=0)
+    ap.add_argument("--mean", type=float, default=117.8952234192841)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--max-batch", type=int, default=256)
+    ap.add_argument("--window-us", type=int, default=200)
+    args = ap.parse_args()
+    L = _lib.lib()
+    ctx = ctypes.c_void_p()
+    _lib.check(L.pnn_create(ctypes.byref(ctx), args.table.encode(), args.pair, ctypes.c_float(args.mean), args.device))
+    stop = ctypes.c_int(0)
+    stats = (ctypes.c_long * 4)()
+    try:
+        L.pnn_service_run(args.socket.encode(), ctx, args.max_batch, args.window_us, ctypes.byref(stop), stats)
+    finally:
+        L.pnn_destroy(ctx)
+
+
+if __name__ == "__main__":
+    main()

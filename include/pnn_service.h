@@ -1,0 +1,43 @@
+/* pnn_service.h -- cross-process batching service for the in-loop PNN calls.
+ *
+ * Inside one HM encode the PNN calls are serially dependent and arrive one block at a time
+ * (TComPrediction.cpp:554-655); the data-parallel axis is ACROSS the many independent encodes an experiment runs
+ * (hevc/running.py, comparing_rate_distortion.py:96-123: images x QPs x variants).  One server process owns the GPU
+ * context; every encoder process connects over a Unix-domain socket and issues the same single-block call it would
+ * issue locally; the server coalesces the requests of one width that are pending at the same time into ONE batched
+ * pnn_predict_pel call and routes the results back.  Blocking, one outstanding request per client -- exactly HM's
+ * calling pattern.  Same error conventions as pnn_hip.h (0 / negative, nothing throws).
+ */
+#ifndef PNN_SERVICE_H
+#define PNN_SERVICE_H
+#include <stdint.h>
+#include "pnn_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* What the server calls for a batch: n blocks of one width, inputs stacked as pnn_predict_pel takes them
+ * (FC widths: `above` = [n][5w^2] flattened contexts, `left` = NULL), dst = [n][w][w].  Returns 0 or a negative code. */
+typedef int (*pnn_service_backend)(void* user, int width, const float* above, const float* left, int n, int32_t* dst);
+
+/* Serves `socket_path` until *stop becomes non-zero (checked at least every 50 ms).  max_batch: largest batch handed to
+ * the backend; window_us: after the first pending request the server waits up to this long for more before it
+ * dispatches (0 = dispatch whatever is pending right now).  stats (optional, 4 longs): requests served, backend
+ * calls, largest batch, clients accepted. */
+int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend, void* user, int max_batch, int window_us,
+                            volatile int* stop, long* stats);
+/* The same with backend = pnn_predict_pel on `ctx` (is_fc per width as the loaded models say). */
+int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats);
+
+/* Client side: what an encoder process links instead of owning a GPU context. */
+typedef struct pnn_client pnn_client;
+int pnn_client_connect(pnn_client** out, const char* socket_path);
+/* == pnn_predict_pel(ctx, width, above, left, 1, dst, dst_stride) executed by the server (left = NULL for FC widths,
+ * where `above` is the [5w^2] flattened context). */
+int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const float* left, int32_t* dst, int dst_stride);
+void pnn_client_close(pnn_client* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNN_SERVICE_H */

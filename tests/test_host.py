@@ -33,6 +33,60 @@ def test_abi_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_service_header_symbols_exported():
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pnn_service.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(pnn_(?:service|client)_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SERVICE_SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), "libpnn_hip.so does not export %s" % name
+
+
+def test_batching_service_routes_and_coalesces(tmp_path):
+    """include/pnn_service.h on the CPU with a stand-in backend (sum of the inputs per block): several client threads,
+    mixed widths and both input kinds; every client gets ITS result, and concurrent requests are served in batches."""
+    import threading
+    from context_adaptive_neural_network_based_prediction_amd import service
+
+    def backend(width, above, left):
+        s = above.sum(axis=1) + (0 if left is None else left.sum(axis=1))
+        ramp = np.arange(width * width, dtype=np.int64).reshape(1, width, width)
+        return (np.round(s).astype(np.int64)[:, None, None] + ramp).astype(np.int32)
+
+    sock = str(tmp_path / "pnn.sock")
+    srv = service.serve_in_thread(sock, backend=backend, max_batch=8, window_us=3000)
+    errors = []
+
+    def client(k):
+        try:
+            c = service.Client(sock)
+            rs = np.random.RandomState(k)
+            for it in range(40):
+                w = (4, 8, 16)[(k + it) % 3]
+                if w <= 8:
+                    a, l = rs.randint(-100, 100, 5 * w * w).astype(np.float32), None
+                else:
+                    a, l = rs.randint(-100, 100, 3 * w * w).astype(np.float32), rs.randint(-100, 100, 2 * w * w).astype(np.float32)
+                got = c.predict_pel(w, a, l)
+                want = backend(w, a[None], None if l is None else l[None])[0]
+                if not np.array_equal(got, want):
+                    errors.append((k, it))
+            c.close()
+        except Exception as e:                          # pragma: no cover
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=client, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stats = srv.stop()
+    assert not errors, errors
+    assert srv.rc == 0
+    assert stats["requests"] == 240 and stats["clients"] == 6
+    assert stats["backend_calls"] < stats["requests"] and 2 <= stats["largest_batch"] <= 8
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
