@@ -22,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+RAMP_SECONDS = 0.4          # untimed device ramp-up before the warm-up steps (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32)
 DEFAULT_PRECISION = "1"           # library default (pnn_set_option "precision"); PNN_PRECISION overrides
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
@@ -67,7 +68,7 @@ def flops_per_block(width, is_fc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (0 = the workload's default)")
@@ -127,6 +128,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Set-up, untimed and outside the W warm-up steps: the first calls autotune the tile configurations, and the device
+    # needs a few hundred milliseconds of sustained work before it holds its clocks (measured: 0.126 ms per step right
+    # after start, 0.113 ms once warm) -- run steps for RAMP_SECONDS so that W and K see the steady state.
+    step()
+    torch.cuda.synchronize()
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < RAMP_SECONDS:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -238,7 +249,8 @@ def main():
                        "batch_per_gpu": batch, "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
                        "weights": "seeded random init with the reference initialisers' statistics",
                        "parallelism": "independent blocks sharded over ranks, no data-path collective",
-                       "tile_autotune": "on first use, in the warm-up steps (pnn_set_option autotune)"},
+                       "tile_autotune": "on first use, before the warm-up steps (pnn_set_option autotune)",
+                       "device_ramp": "%.2f s of untimed steps before the W warm-up steps (clock ramp)" % RAMP_SECONDS},
             "launches_per_step": stats["launches"],
             "max_abs_lsb_vs_oracle": parity,
             "parity_detail": parity_detail,

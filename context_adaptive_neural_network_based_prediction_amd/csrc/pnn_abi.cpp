@@ -100,7 +100,7 @@ struct pnn_ctx {
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
-    long opt_autotune = 0;                            // 1: time every split-GEMM tile config on first use of a (layer, M) and keep the best
+    long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
     std::map<std::pair<const void*, long>, int> tuned;
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
     struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
@@ -508,6 +508,9 @@ static int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap
 }
 
 // Rule-based choice among the convimg tiles: fewest idle rows and columns, then the larger wave tile.  -1 = none fits.
+// (A cost model with workgroup counts and residency was tried against the autotuner's per-configuration timings of
+// the conv-16/32 layers and picked WORSE tiles overall -- 0.58 vs 0.54 ms per conv-16 pass; the three kernel families
+// are within 10-15 % of each other on most layers, so big passes are simply autotuned, see run_gemm_sp.)
 static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 {
     int best = -1;
@@ -529,7 +532,7 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 // Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
 // kernels.  Calibrated with tools/ring_prof.hip: a workgroup costs ~(prologue + epilogue) + stages x 1.45 x its MFMA
 // cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
-static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, bool fused = false)
+static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
 {
     if (!fused && (!one_tap || (double)M * p.Cout < 2.0e6 || p.Cin < 256)) return -1;
     int best = -1;
@@ -537,12 +540,14 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, bool fu
     for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
         const TileCfg t = tapgemm_ring_cfg(i);
         if (fused && !tapgemm_ring_can_fuse(i)) continue;
+        if (!one_tap && (p.Cin / 16) % t.kc) continue;
         const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
         const long nwg = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
         const int resident = tapgemm_ring_lds_bytes(t) > (size_t)80 * 1024 ? 1 : 2;
-        const double stages = std::ceil((p.Cin / 16) / (double)t.kc);
+        const double stages = std::ceil((k_total / 16.0 / p.ncls) / (double)t.kc);
         const double mfma = 96.0 * t.rt * t.nt * t.kc;
-        const double wg = 9000.0 + 55.0 * t.rt * t.nt * 4 + stages * mfma * (resident == 2 ? 1.25 : (t.d >= 4 ? 1.45 : 2.1));
+        const double slow = t.kc == 1 ? 2.0 : (resident == 2 ? 1.25 : (t.d >= 4 ? 1.45 : 2.1));   // 16-deep stages fetch half lines: measured 2x
+        const double wg = 9000.0 + 55.0 * t.rt * t.nt * 4 + stages * mfma * slow;
         const double rounds = std::ceil(nwg / (256.0 * resident));
         const double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);   // two co-resident workgroups share the CU's MFMA pipes
         if (cost < best_cost) { best_cost = cost; best = i; }
@@ -630,11 +635,15 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
-        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, next != nullptr) : -1;
+        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
         if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
     }
-    if (c->opt_autotune && c->opt_sp_cfg < 0) {
+    // autotune: 1 = every split GEMM, 2 (default) = only launches of >= 4 GFLOP, where trying all configurations once
+    // (~70 x 4 launches) costs a few tens of milliseconds and the choice is worth 10-20 %; 0 = rule-based choice only.
+    // All configurations give bit-identical results, so the choice never shows in the predictions.
+    const bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
+    if (tune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
         // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
         const auto key = std::make_pair((const void*)((const char*)&L + (next ? 1 : 0)), M);

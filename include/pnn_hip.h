@@ -72,8 +72,10 @@ float pnn_mean(const pnn_ctx* ctx);
  * _conv with n == 1, what HM issues -- are answered from a direct-mapped cache of that many MiB when the same input
  * bytes were predicted before: HM's rate-distortion search asks for the same block repeatedly; exact
  * match on the inputs, dropped whenever a model or an option changes),
- * "autotune" (1: the first call that meets a new (layer, batch size) pair times every legal tile configuration of the
- * split-precision GEMM on the device and keeps the fastest -- do it in a warm-up call, outside any timed region),
+ * "autotune" (the first call that meets a new (layer, batch size) pair times every legal configuration of the three
+ * split-precision GEMM kernels on the device and keeps the fastest -- all of them give bit-identical results, so only
+ * the speed depends on it; 2, default: only for launches of >= 4 GFLOP, i.e. big batches, where it costs a few tens
+ * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
