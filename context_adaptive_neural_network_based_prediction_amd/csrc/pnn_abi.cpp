@@ -97,6 +97,19 @@ struct pnn_ctx {
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
+    // fc_chain_kernel (pnn_gemm_ring.hip): the three hidden layers + output layer of an FC net in one launch.  OFF by
+    // default: measured 0.118 ms against 0.115 ms for the per-layer launches (FC 8x8, batch 4096) -- the ~5 us by which a
+    // kernel's duration exceeds its workgroups' lifetime is start skew and stragglers, which the inter-layer handshake
+    // waits for just the same, not dispatch cost that a fused launch would save.
+    long opt_chain = 0;
+    int chain_state = 0;                              // 0: placement not probed yet, 1: usable, -1: disabled for this context
+    int num_cus = 0;
+    ChainParams h_chain;                              // what d_chain holds
+    bool h_chain_valid = false;
+    ChainParams* d_chain = nullptr;
+    unsigned* d_chain_cnt = nullptr;                  // [3][64] handshake counters, monotonic
+    int* h_chain_err = nullptr;                       // host-visible: raised by a workgroup that gave up waiting
+    unsigned chain_epoch = 0;
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
@@ -778,6 +791,100 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     return nb >= (m->is_fc ? 512 : 200);
 }
 
+// The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
+// when this batch cannot use it (tile grid larger than the chip, row tiles not a multiple of the 8 XCDs, ...).
+int fc_chain_pass(pnn_ctx* c, Model* m, const void* S, float* P0, float* P1, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
+{
+    if (!c->num_cus) {
+        int n = 0;
+        HIPCHK(c, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->num_cus = n;
+    }
+    int cfg = -1, gx = 0, gy = 0;
+    for (int i = 0; i < tapgemm_ring_num_cfgs() && cfg < 0; i++) {
+        if (!fc_chain_has_cfg(i) || !tapgemm_ring_can_fuse(i)) continue;
+        const TileCfg t = tapgemm_ring_cfg(i);
+        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
+        const long tx = (nb + bm - 1) / bm, ty = (m->fc[1].proto.Cout + bn - 1) / bn;
+        if (tx % 8 == 0 && tx <= 64 && tx * ty <= c->num_cus) { cfg = i; gx = (int)tx; gy = (int)ty; }
+    }
+    if (cfg < 0) return 1;
+    for (int l = 0; l < 3; l++)                       // the hidden layers share the tile grid
+        if (m->fc[l].proto.Cout != m->fc[1].proto.Cout || m->fc[l].proto.ncls != 1) return 1;
+    if (c->h_chain_err && *c->h_chain_err) {          // a previous chained launch gave up waiting: its result was not valid
+        c->chain_state = -1;
+        *c->h_chain_err = 0;
+        return fail(c, PNN_E_HIP, "a chained FC launch timed out at its inter-layer handshake; chained launches are now disabled for this context");
+    }
+    if (c->chain_state == 0) {                        // once: allocate, and check that the workgroups (x, *) share an XCD
+        HIPCHK(c, hipMalloc((void**)&c->d_chain, sizeof(ChainParams)));
+        HIPCHK(c, hipMalloc((void**)&c->d_chain_cnt, 3 * 64 * sizeof(unsigned)));
+        HIPCHK(c, hipMemset(c->d_chain_cnt, 0, 3 * 64 * sizeof(unsigned)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocDefault));
+        *c->h_chain_err = 0;
+        int* d_probe = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d_probe, (size_t)gx * gy * sizeof(int)));
+        HIPCHK(c, launch_xcc_probe(gx, gy, tapgemm_ring_lds_bytes(tapgemm_ring_cfg(cfg)), d_probe, s));
+        std::vector<int> xcc((size_t)gx * gy);
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipMemcpy(xcc.data(), d_probe, xcc.size() * sizeof(int), hipMemcpyDeviceToHost));
+        (void)hipFree(d_probe);
+        bool same = true;
+        for (int x = 0; x < gx; x++)
+            for (int y = 1; y < gy; y++) same &= xcc[(size_t)y * gx + x] == xcc[x];
+        c->chain_state = same ? 1 : -1;
+        if (getenv("PNN_DEBUG")) fprintf(stderr, "[pnn] chained FC kernel: %dx%d workgroups, column groups on one XCD each: %s\n", gx, gy, same ? "yes" : "NO -> disabled");
+        if (!same) return 1;
+    }
+    int rc;
+    if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
+    ChainParams cp;
+    memset(&cp, 0, sizeof cp);
+    const GemmLayer* Ls[3] = {&m->fc[0], &m->fc[1], &m->fc[2]};
+    const void* Xs[3] = {S, P0, P1};
+    void* Ys[3] = {P0, P1, nullptr};
+    double flops = 0;
+    for (int l = 0; l < 3; l++) {
+        TapGemmParams p = Ls[l]->proto;
+        p.X = (const float*)Xs[l]; p.Wp = Ls[l]->d_w_sp; p.bias = Ls[l]->d_bias; p.Yhi = Ys[l];
+        p.mean = c->mean; p.out_scale = Ls[l]->sp_inv_scale; p.M = (int)nb; p.zero = c->d_zero;
+        p.x_bytes = (unsigned)std::min<double>(4.0 * (double)nb * p.Cin, 2147483647.0);
+        flops += 2.0 * (double)nb * Ls[l]->k_total * p.Cout;
+        cp.layer[l] = p;
+    }
+    const GemmLayer& Lo = m->fc[3];
+    cp.layer[2].W2p = Lo.d_w_sp; cp.layer[2].Npad2 = Lo.proto.Npad; cp.layer[2].K2chunks = Lo.proto.chunk_begin[1];
+    cp.layer[2].part = (float*)c->ws[3].p;
+    flops += 2.0 * (double)nb * Lo.k_total * Lo.proto.Cout;
+    cp.nlayers = 3; cp.counters = c->d_chain_cnt; cp.error = c->h_chain_err;
+    if (!c->h_chain_valid || memcmp(&cp, &c->h_chain, sizeof cp)) {
+        HIPCHK(c, hipStreamSynchronize(s));           // the block a running launch reads must not change under it
+        HIPCHK(c, hipMemcpy(c->d_chain, &cp, sizeof cp, hipMemcpyHostToDevice));
+        c->h_chain = cp;
+        c->h_chain_valid = true;
+    }
+    const unsigned target = (unsigned)gy * ++c->chain_epoch;
+    static const bool debug = getenv("PNN_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[pnn] fc-chain M=%ld: 3 hidden layers + output layer in one launch, ring cfg %d, grid %dx%d\n", nb, cfg, gx, gy);
+    if (c->opt_time_launches) {
+        pnn_ctx::LaunchRec r;
+        HIPCHK(c, hipEventCreate(&r.e0));
+        HIPCHK(c, hipEventCreate(&r.e1));
+        r.kind = 4; r.flops = flops;
+        HIPCHK(c, hipEventRecord(r.e0, s));
+        HIPCHK(c, launch_fc_chain(cp, c->d_chain, target, cfg, s));
+        HIPCHK(c, hipEventRecord(r.e1, s));
+        c->launch_recs.push_back(r);
+    } else {
+        HIPCHK(c, launch_fc_chain(cp, c->d_chain, target, cfg, s));
+    }
+    c->stat_gemm_launches++; c->stat_launches++;
+    c->stat_gemm_flops += flops;
+    HIPCHK(c, launch_fuse_reduce((const float*)c->ws[3].p, gy, (int)nb, Lo.proto.Cout, Lo.d_bias, Lo.sp_inv_scale, c->mean, d_out, d_dst, s));
+    c->stat_launches++;
+    return PNN_OK;
+}
+
 int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
 {
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
@@ -791,10 +898,15 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
             c->stat_launches++;
             S = c->ws[2].p;
         }
+        const int n_out = m->fc[3].proto.Cout;
+        const bool fuse_ok = c->opt_fuse_last && c->opt_ring && !c->opt_canonical && c->opt_sp_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && nb >= 1024;
+        if (fuse_ok && c->opt_chain && c->chain_state >= 0) {
+            rc = fc_chain_pass(c, m, S, P0, P1, nb, d_out, d_dst, s);
+            if (rc != 1) return rc;                   // 1: this batch does not fit the chained kernel, use the per-layer launches
+        }
         if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
-        const int n_out = m->fc[3].proto.Cout;
-        if (c->opt_fuse_last && c->opt_ring && !c->opt_canonical && c->opt_sp_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && nb >= 1024) {
+        if (fuse_ok) {
             // last hidden layer + output layer in one launch: the 1200-wide activations of the third hidden layer never
             // leave the workgroups that produce them (pnn_gemm_ring.hip, FUSE); a small kernel sums the column tiles' partials
             if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
@@ -973,6 +1085,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
+    if (const char* e = getenv("PNN_CHAIN")) c->opt_chain = atol(e);
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -1063,6 +1176,9 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
+    if (c->d_chain) (void)hipFree(c->d_chain);
+    if (c->d_chain_cnt) (void)hipFree(c->d_chain_cnt);
+    if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1094,6 +1210,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
+    else if (!strcmp(name, "chain")) c->opt_chain = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;

@@ -59,6 +59,17 @@ int tapgemm_ring_num_cfgs();
 TileCfg tapgemm_ring_cfg(int idx);
 size_t tapgemm_ring_lds_bytes(const TileCfg& t);
 bool tapgemm_ring_can_fuse(int idx);
+// A whole fully-connected net (its hidden layers + the fused output layer) in one launch: see fc_chain_kernel.
+struct ChainParams {
+    TapGemmParams layer[3];
+    int nlayers;
+    unsigned* counters;       // [3][gridDim.x], monotonic over launches
+    int* error;               // raised when a workgroup gives up waiting (host-visible memory)
+};
+bool fc_chain_has_cfg(int idx);
+// cp: host copy (validated), d_cp: the same block in device memory; target = gridDim.y * (chained launches so far incl. this one)
+hipError_t launch_fc_chain(const ChainParams& cp, const ChainParams* d_cp, unsigned target, int idx, hipStream_t s);
+hipError_t launch_xcc_probe(int gx, int gy, size_t lds_bytes, int* d_out, hipStream_t s);
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
                               hipStream_t s);
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)

@@ -68,7 +68,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
  * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
  * >= 1024 blocks through a fully-connected PNN with <= 64 outputs run the output layer inside the last hidden layer's
- * kernel; 0: separate launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
+ * kernel; 0: separate launches), "chain" (0, default; 1: such a pass runs its three hidden layers and the output
+ * layer as ONE launch whose workgroups hand over between layers through counters -- correct, tested, but measured no
+ * faster than the per-layer launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
  * _conv with n == 1, what HM issues -- are answered from a direct-mapped cache of that many MiB when the same input
  * bytes were predicted before: HM's rate-distortion search asks for the same block repeatedly; exact
  * match on the inputs, dropped whenever a model or an option changes),

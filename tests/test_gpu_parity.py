@@ -401,6 +401,29 @@ def test_batching_service_on_gpu(pnn, tmp_path):
     assert stats["requests"] == n and stats["largest_batch"] >= 2
 
 
+def test_chained_fc_kernel(pnn, oracle, precision):
+    """Option "chain": the hidden layers + output layer of a big FC pass in one launch with inter-layer handshakes between
+    the workgroups of a row tile.  Repeatable bit for bit (a missed handshake would show as run-to-run differences), and
+    equal to the oracle and to the per-layer launches within the float tolerance."""
+    if precision != "split_f16":
+        pytest.skip("split-precision path only")
+    w, n = 8, 4096
+    params = util.make_params(w, True, 71, out_gain=util.out_gain(w, True))
+    above, left = util.make_contexts(w, n, 72)
+    ctx = util.flatten_fc(above, left)
+    net = pnn.PredictionNeuralNetwork(n, w, True, params=params)
+    ref = net.predict(ctx).copy()
+    net.set_option("chain", 1)
+    first = net.predict(ctx).copy()
+    assert net.last_call_stats()["launches"] == 3                    # split + chained kernel + reduce (the context arrives as f32 here)
+    for _ in range(10):
+        assert np.array_equal(net.predict(ctx), first)
+    np.testing.assert_allclose(first, ref, rtol=0, atol=FLOAT_ATOL)
+    idx = np.random.RandomState(2).choice(n, 64, replace=False)
+    np.testing.assert_allclose(first[idx, ..., 0], oracle.fc_forward(params, w, ctx[idx]), rtol=0, atol=FLOAT_ATOL)
+    _check_pel(net.predict_pel(ctx)[idx], oracle.epilogue(oracle.fc_forward(params, w, ctx[idx]), util.MEAN))
+
+
 # ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
 def test_full_size_properties(pnn, oracle, w, is_fc, n):
