@@ -18,6 +18,7 @@
 //   Out-of-image taps, rows past M and chunks past the end of a one-tap layer's K are fetched from a zero page.
 // Same contract, parameter block, weight packing and per-output summation order as tapgemm_sp_kernel: bit-identical.
 #include "pnn_kernels.h"
+#include <type_traits>
 #include "pnn_device_common.h"
 
 namespace pnn {
@@ -426,51 +427,62 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     const unsigned long long de1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    // Two copies of the fully unrolled group loop, chosen once: the common case (split-f16 output only) without the f32 / HM
+    // branches inside.  The loop runs ONCE per launch from a cold instruction cache, so its time is set by its code
+    // footprint: with all three output kinds behind per-group branches it was ~20 KB and 7.9k cycles for 20 groups.
+    const bool act = p.act != 0;
+    auto groups = [&](auto direct_tag) {
+        constexpr bool kDirect = decltype(direct_tag)::value;        // f32 / HM outputs straight from the accumulator layout
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-        const int lrow = wm * (32 * RT) + rt * 32 + l31;
-        const int mg = mblk + lrow;
-        const bool rowok = mg < p.M;
-        const int mc = rowok ? mg : 0;
-        const int pbq = mc / SP;
-        const int rq = mc - pbq * SP;
-        const int piq = rq / p.SW, pjq = rq - piq * p.SW;
-        const int oy = piq * p.os + py, ox = pjq * p.os + px;
-        const size_t obase = (((size_t)pbq * p.OH + oy) * p.OW + ox) * p.Cout;
+        for (int rt = 0; rt < RT; rt++) {
+            const int lrow = wm * (32 * RT) + rt * 32 + l31;
+            const int mg = mblk + lrow;
+            const bool rowok = mg < p.M;
+            size_t obase = 0;
+            if (kDirect) {
+                const int mc = rowok ? mg : 0;
+                const int pbq = mc / SP;
+                const int rq = mc - pbq * SP;
+                const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+                const int oy = piq * p.os + py, ox = pjq * p.os + px;
+                obase = (((size_t)pbq * p.OH + oy) * p.OW + ox) * p.Cout;
+            }
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+            for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int nl = wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
-                const int n = n0 + nl;
-                const f32x4 bv = bvs[nt][g];
-                f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
-                if (p.act) {
-                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
-                }
+                for (int g = 0; g < 4; g++) {
+                    const int nl = wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+                    const int n = n0 + nl;
+                    const f32x4 bv = bvs[nt][g];
+                    f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bv;
+                    if (act) {
+                        v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    }
 #ifdef PNN_RING_NO_STORE       // ablation builds of tools/ring_prof.hip only
-                asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-                continue;
+                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                    continue;
 #endif
-                if (p.Yhi || fuse) {                  // same values and rounding as store_split4
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    h4 hi, lo;
+                    if (!kDirect || p.Yhi || fuse) {  // same values and rounding as store_split4
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        h4 hi, lo;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
-                    _Float16* dst = reinterpret_cast<_Float16*>(ring + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
-                    *reinterpret_cast<h4*>(dst) = hi;
-                    *reinterpret_cast<h4*>(dst + 16) = lo;
-                }
-                if (rowok && n < p.Cout) {
-                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
-                    if (p.Yi) {
-                        int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
-                                            hm_round(v[3], p.mean));
-                        *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                        for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+                        _Float16* dst = reinterpret_cast<_Float16*>(ring + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
+                        *reinterpret_cast<h4*>(dst) = hi;
+                        *reinterpret_cast<h4*>(dst + 16) = lo;
+                    }
+                    if (kDirect && rowok && n < p.Cout) {
+                        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                        if (p.Yi) {
+                            int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
+                                                hm_round(v[3], p.mean));
+                            *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                        }
                     }
                 }
-            }
-    }
+        }
+    };
+    if (p.Y || p.Yi) groups(std::true_type{}); else groups(std::false_type{});
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,7 +560,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
         d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = dq3 - dq2; d[3] = dr3 - dr0;
         unsigned long long* e = (unsigned long long*)p.Xlo + (1 << 18) + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 #ifdef PNN_RING_DIAG3
-        e[5] = dg3; e[6] = dq0;
+        e[5] = dg3; e[6] = dq0; e[7] = dr0;              // e[7]: start on the chip-wide 100 MHz clock (start / end spread over the grid)
 #endif
         e[0] = de1 - dq2; e[1] = de2 - de1; e[2] = de3 - de2; e[3] = de4 - de3; e[4] = dq3 - de4;
     }

@@ -59,6 +59,16 @@ int main(int argc, char** argv)
                 printf("      loader wave 4: starts %5.0f cycles after MFMA wave 0 | setup %5.0f | issue of D-1 stages %5.0f | wait for stage 0 %5.0f\n", l[0] / nwg, l[1] / nwg,
                        l[2] / nwg, l[3] / nwg);
             }
+            {
+                unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0, lmin = ~0ull, lmax = 0;
+                for (int w = 0; w < nwg; w++) {
+                    const unsigned long long st = he[8 * w + 7], life = h[4 * w + 3], en = st + life;
+                    s0 = st < s0 ? st : s0; s1 = st > s1 ? st : s1; e0 = en < e0 ? en : e0; e1 = en > e1 ? en : e1;
+                    lmin = life < lmin ? life : lmin; lmax = life > lmax ? life : lmax;
+                }
+                printf("      workgroup starts spread over %.1f us, ends over %.1f us, first start -> last end %.1f us, lifetime min %.1f / max %.1f us\n",
+                       (s1 - s0) / 100.0, (e1 - e0) / 100.0, (e1 - s0) / 100.0, lmin / 100.0, lmax / 100.0);
+            }
             printf("      stage barrier wait (MFMA wave 0): %5.0f cycles per stage\n", e[5] / nwg / nst);
 #endif
             printf("      epilogue: barrier A %5.0f | scale/bias/split -> LDS %5.0f | barrier B %5.0f | copy-out issue %5.0f | store drain %5.0f\n", e[0] / nwg, e[1] / nwg,
