@@ -91,6 +91,7 @@ struct pnn_ctx {
     std::vector<CacheEntry> cache[5];
     long opt_cache_mb = 0;                            // 0 = off
     long cache_hits = 0, cache_misses = 0;
+    char* h_pin = nullptr;                            // pinned, device-visible staging of the single-block host calls (zero-copy)
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
@@ -1176,6 +1177,7 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_chain) (void)hipFree(c->d_chain);
     if (c->d_chain_cnt) (void)hipFree(c->d_chain_cnt);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
@@ -1427,6 +1429,32 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (in_l && (rc = dev_reserve(c, c->stage_in[1], in_l))) return rc;
     if ((rc = dev_reserve(c, c->stage_out[0], (size_t)n * w2 * 4))) return rc;
     if (dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;
+    // Single-block calls (what HM issues): no copy engine at all -- the first kernel reads the inputs from pinned host
+    // memory and the last one writes the results there (two launches and ~12 us less per call than H2D + D2H copies).
+    constexpr size_t kPinIn = 16 << 10, kPinOut = 16 << 10;
+    if (n == 1 && in_a <= kPinIn && in_l <= kPinIn && w2 * 4 <= kPinOut) {
+        if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 2 * kPinIn + 2 * kPinOut, hipHostMallocDefault));
+        char* hp = c->h_pin;
+        memcpy(hp, above, in_a);
+        if (in_l) memcpy(hp + kPinIn, left, in_l);
+        float* p_out = (float*)(hp + 2 * kPinIn);
+        int32_t* p_dst = (int32_t*)(hp + 2 * kPinIn + kPinOut);
+        rc = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, 1, p_out, (dst || slot) ? p_dst : nullptr, s);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (out) memcpy(out, p_out, w2 * 4);
+        if (dst)
+            for (int y = 0; y < w; y++) memcpy(dst + (size_t)y * dst_stride, p_dst + (size_t)y * w, (size_t)w * 4);
+        if (slot) {
+            slot->in.resize(na + nl);
+            memcpy(slot->in.data(), above, na * 4);
+            if (nl) memcpy(slot->in.data() + na, left, nl * 4);
+            slot->out.assign(p_out, p_out + w2);
+            slot->pel.assign(p_dst, p_dst + w2);
+            slot->hash = hash; slot->valid = true;
+        }
+        return PNN_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(c->stage_in[0].p, above, in_a, hipMemcpyHostToDevice, s));
     if (in_l) HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
     if (slot && !dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;   // a cached entry serves both result kinds
