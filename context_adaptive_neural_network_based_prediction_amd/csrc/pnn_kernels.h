@@ -87,6 +87,7 @@ struct Conv1Params {
     const float* X; const float* W; const float* bias; float* Y;
     int B, IH, IW, s, k, pad, OH, OW, Cout;
     int split;   // 1: write Y as split activations [pixel][Cout/16][hi 16 x f16 | lo 16 x f16] for the split-precision GEMM
+    int band_rows;   // output rows per workgroup (set by the launcher)
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 

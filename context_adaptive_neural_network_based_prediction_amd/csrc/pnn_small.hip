@@ -22,12 +22,16 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
 {
     touch_kernargs<sizeof(Conv1Params)>();
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int PH = (p.OH - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
+    // blockIdx.y = band of p.band_rows output rows (small batches: one image is spread over several workgroups; a
+    // single workgroup per image took 72 us for a 64x192 portion at batch 1)
+    const int oy0 = blockIdx.y * p.band_rows;
+    const int oy1 = oy0 + p.band_rows < p.OH ? oy0 + p.band_rows : p.OH;
+    const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
     const long b = blockIdx.x;
     const float* xb = p.X + b * p.IH * p.IW;
     for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
         const int r = idx / PW, c = idx - r * PW;
-        const int iy = r - p.pad, ix = c - p.pad;
+        const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
         xs[idx] = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
     }
     const int CG = p.Cout >> 2;                       // lanes per pixel (8 or 16)
@@ -39,9 +43,9 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
     __syncthreads();
     const int npix = p.OH * p.OW;
     float* yb = p.Y + b * npix * p.Cout;
-    for (int pix = psub; pix < npix; pix += ppi) {
+    for (int pix = oy0 * p.OW + psub; pix < oy1 * p.OW; pix += ppi) {
         const int oy = pix / p.OW, ox = pix - oy * p.OW;
-        const float* xr = xs + (oy * p.s) * PW + ox * p.s;
+        const float* xr = xs + ((oy - oy0) * p.s) * PW + ox * p.s;
         f32x4 acc = bv;
 #pragma unroll
         for (int ky = 0; ky < K; ky++)
@@ -56,10 +60,15 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
 {
     if (p.B <= 0) return hipSuccess;
-    const size_t lds = (size_t)((p.OH - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
+    Conv1Params q = p;
+    int bands = 1;                                    // enough workgroups to fill the chip at small batch
+    while ((long)p.B * bands < 512 && bands * 2 <= p.OH) bands *= 2;
+    q.band_rows = (p.OH + bands - 1) / bands;
+    bands = (p.OH + q.band_rows - 1) / q.band_rows;
+    const size_t lds = (size_t)((q.band_rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
     if (lds > 64 * 1024 || (p.Cout != 32 && p.Cout != 64)) return hipErrorInvalidValue;
-    if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3(p.B), dim3(256), lds, s, p);
-    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3(p.B), dim3(256), lds, s, p);
+    if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3(p.B, bands), dim3(256), lds, s, q);
+    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3(p.B, bands), dim3(256), lds, s, q);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
