@@ -959,6 +959,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     MergerParams mp = m->merger.proto;
     mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
     mp.split = (sp && nt > 0) ? 1 : 0;
+    mp.one_order = c->opt_canonical ? 1 : 0;
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;
     int cur = 0;

@@ -104,6 +104,7 @@ struct MergerParams {
     const float* A; const float* L; const float* Wp; const float* bias /* [j][C] */; float* Y;
     int B, C, na, nl, nout;
     int split;   // 1: write Y in the split f16 activation layout
+    int one_order;   // 1: always the batch kernel (canonical_order: one summation order for every batch size)
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);
 
