@@ -17,6 +17,12 @@
 //   again by the reader; weights [KC][4 planes][BN] pieces, read lane-contiguous.
 //   Out-of-image taps, rows past M and chunks past the end of a one-tap layer's K are fetched from a zero page.
 // Same contract, parameter block, weight packing and per-output summation order as tapgemm_sp_kernel: bit-identical.
+//
+// What bounds it now (tools/ring_prof.hip, -DPNN_RING_DIAG3, FC 1200x1200, tile 128x160): a loader wave needs ~1300
+// cycles to ISSUE its 9 LDS-DMA instructions of a stage while the MFMA waves run (~800 with the MFMAs ablated: the DMA
+// writes and the fragment reads share the LDS), i.e. 28 B/clk of the CU's 64 B/clk vector-memory path; the MFMA waves
+// finish their 960 MFMA cycles in ~1070 and wait ~300-400 at the stage barrier.  Deeper rings do not help (D = 5 / 6
+// measured equal to D = 4 on the tiles where they fit): it is issue throughput, not latency.
 #include "pnn_kernels.h"
 #include <type_traits>
 #include "pnn_device_common.h"
@@ -226,13 +232,28 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
 #pragma unroll
         for (int s = 2; s < D - 1; s++)
             if (s < nstages) issue();
+#ifdef PNN_RING_DIAG3
+        unsigned long long dlw = 0, dlb = 0, dli = 0, dlt = __builtin_amdgcn_s_memtime();
+#define DL_STAMP(acc_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - dlt; dlt = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DL_STAMP(acc_) do {} while (0)
+#endif
         for (int s = 0; s < nstages; s++) {
             if (s + 1 < nstages) {                   // stage s+1 must have landed; later stages may stay in flight
                 if (s + D - 2 < nstages) wait_stages<D - 3, NI>(fewer); else wait_vm<0>();
             }
+            DL_STAMP(dlw);
             __builtin_amdgcn_s_barrier();            // barrier s
+            DL_STAMP(dlb);
             if (s + D - 1 < nstages) issue();        // into buffer (s-1) % D
+            DL_STAMP(dli);
         }
+#ifdef PNN_RING_DIAG3
+        if (p.Xlo && tid == 256) {
+            unsigned long long* e = (unsigned long long*)p.Xlo + (1 << 19) + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            e[4] = dlw; e[5] = dlb; e[6] = dli;
+        }
+#endif
         __builtin_amdgcn_s_barrier();                // epilogue barrier A (see below)
         if (fuse) {
             const f32x4* __restrict__ W2 = reinterpret_cast<const f32x4*>(p.W2p);

@@ -54,8 +54,9 @@ int main(int argc, char** argv)
             {
                 std::vector<unsigned long long> hl(8 * (size_t)nwg);
                 hipMemcpy(hl.data(), (char*)dd + 8 * (1 << 19), hl.size() * 8, hipMemcpyDeviceToHost);
-                double l[4] = {0, 0, 0, 0};
-                for (int w = 0; w < nwg; w++) { l[0] += (double)((long long)hl[8 * w] - (long long)he[8 * w + 6]); for (int k = 1; k < 4; k++) l[k] += (double)hl[8 * w + k]; }
+                double l[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int w = 0; w < nwg; w++) { l[0] += (double)((long long)hl[8 * w] - (long long)he[8 * w + 6]); for (int k = 1; k < 7; k++) l[k] += (double)hl[8 * w + k]; }
+                printf("      loader wave 4 per stage: waiting for its loads %5.0f | at the barrier %5.0f | issuing the next stage %5.0f\n", l[4] / nwg / nst, l[5] / nwg / nst, l[6] / nwg / nst);
                 printf("      loader wave 4: starts %5.0f cycles after MFMA wave 0 | setup %5.0f | issue of D-1 stages %5.0f | wait for stage 0 %5.0f\n", l[0] / nwg, l[1] / nwg,
                        l[2] / nwg, l[3] / nwg);
             }
