@@ -20,6 +20,8 @@
 
 using namespace pnn;
 
+namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
+
 namespace {
 
 constexpr int kHidden = 1200;                         // pnn/components.py:130-160
@@ -488,9 +490,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         HIPCHK(c, hipEventCreate(&r.e1));
         r.kind = tapgemm_cfg(cfg).rt == 0 ? 1 : 0;
         r.flops = 2.0 * (double)M * L.k_total * p.Cout;
-        HIPCHK(c, hipEventRecord(r.e0, s));
-        HIPCHK(c, launch_tapgemm(p, cfg, s));
-        HIPCHK(c, hipEventRecord(r.e1, s));
+        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
+        g_launch_events = &ev;
+        const hipError_t le = launch_tapgemm(p, cfg, s);
+        g_launch_events = nullptr;
+        HIPCHK(c, le);
         if (profile) {
             HIPCHK(c, hipEventSynchronize(r.e1));
             float ms = 0.f;
@@ -703,9 +707,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         HIPCHK(c, hipEventCreate(&r.e1));
         r.kind = cfg < nsp ? 2 : cfg < nsp + nci ? 3 : 4;
         r.flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
-        HIPCHK(c, hipEventRecord(r.e0, s));
-        HIPCHK(c, launch(cfg));
-        HIPCHK(c, hipEventRecord(r.e1, s));
+        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
+        g_launch_events = &ev;
+        const hipError_t le = launch(cfg);
+        g_launch_events = nullptr;
+        HIPCHK(c, le);
         if (profile) {
             HIPCHK(c, hipEventSynchronize(r.e1));
             float ms = 0.f;
@@ -872,9 +878,11 @@ int fc_chain_pass(pnn_ctx* c, Model* m, const void* S, float* P0, float* P1, lon
         HIPCHK(c, hipEventCreate(&r.e0));
         HIPCHK(c, hipEventCreate(&r.e1));
         r.kind = 4; r.flops = flops;
-        HIPCHK(c, hipEventRecord(r.e0, s));
-        HIPCHK(c, launch_fc_chain(cp, c->d_chain, target, cfg, s));
-        HIPCHK(c, hipEventRecord(r.e1, s));
+        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
+        g_launch_events = &ev;
+        const hipError_t le = launch_fc_chain(cp, c->d_chain, target, cfg, s);
+        g_launch_events = nullptr;
+        HIPCHK(c, le);
         c->launch_recs.push_back(r);
     } else {
         HIPCHK(c, launch_fc_chain(cp, c->d_chain, target, cfg, s));

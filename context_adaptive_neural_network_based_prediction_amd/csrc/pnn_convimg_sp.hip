@@ -286,7 +286,7 @@ static hipError_t launch_ci(const TapGemmParams& p, int G, hipStream_t s)
     }
     const long nimg = p.M / (p.SH * p.SW);
     dim3 grid((unsigned)((nimg + G - 1) / G), (p.Cout + BN - 1) / BN, p.ncls);
-    hipLaunchKernelGGL((convimg_sp_kernel<RT, NT, KC, WM>), grid, dim3(256), lds, s, p, G);
+    pnn_launch(convimg_sp_kernel<RT, NT, KC, WM>, grid, dim3(256), lds, s, p, G);
     return hipGetLastError();
 }
 

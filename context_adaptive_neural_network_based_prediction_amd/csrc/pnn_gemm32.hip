@@ -230,7 +230,7 @@ template <int RT, int NT, int KC>
 static hipError_t launch_tg32(const TapGemmParams& p, hipStream_t s)
 {
     dim3 grid((p.M + 128 * RT - 1) / (128 * RT), (p.Cout + 32 * NT - 1) / (32 * NT), p.ncls);
-    hipLaunchKernelGGL((tapgemm32_kernel<RT, NT, KC>), grid, dim3(256), 0, s, p);
+    pnn_launch(tapgemm32_kernel<RT, NT, KC>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -707,7 +707,7 @@ static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
         attr_set = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
-    hipLaunchKernelGGL((tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>), grid, dim3(512), lds, s, p);
+    pnn_launch(tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>, grid, dim3(512), lds, s, p);
     return hipGetLastError();
 }
 
@@ -768,7 +768,7 @@ static hipError_t launch_chain(const ChainParams& cp, const ChainParams* d_cp, u
     }
     const TapGemmParams& p = cp.layer[0];
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
-    hipLaunchKernelGGL((fc_chain_kernel<RT, NT, KC, WM, D>), grid, dim3(512), lds, s, d_cp, target);
+    pnn_launch(fc_chain_kernel<RT, NT, KC, WM, D>, grid, dim3(512), lds, s, d_cp, target);
     return hipGetLastError();
 }
 

@@ -324,7 +324,7 @@ static hipError_t launch_sp(const TapGemmParams& p, hipStream_t s)
 {
     constexpr int BM = 32 * RT * WM, BN = 32 * NT * (4 / WM);
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
-    hipLaunchKernelGGL((tapgemm_sp_kernel<RT, NT, KC, WM>), grid, dim3(256), 0, s, p);
+    pnn_launch(tapgemm_sp_kernel<RT, NT, KC, WM>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -2,9 +2,22 @@
 // (pnn_kernels.hip).  Not part of the public boundary -- see include/pnn_hip.h for that.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace pnn {
+
+// Per-launch timing (pnn_abi.cpp, option time_launches): when set, the GEMM launchers attach these events to the kernel
+// itself (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end -- what rocprofv3
+// reports -- instead of the record-to-record time of two hipEventRecord calls around the launch (~4 us more).
+struct LaunchEvents { hipEvent_t start, stop; };
+extern thread_local const LaunchEvents* g_launch_events;
+template <typename K, typename... A>
+inline void pnn_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args)
+{
+    if (g_launch_events) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, g_launch_events->start, g_launch_events->stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+}
 
 constexpr int kMaxTaps = 32;
 constexpr int kMaxClasses = 4;

@@ -360,7 +360,7 @@ static hipError_t launch_tg(const TapGemmParams& p, hipStream_t s)
 {
     dim3 grid((p.M + 64 * RT - 1) / (64 * RT), (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
     static const int lds_pad = getenv("PNN_LDS_PAD") ? atoi(getenv("PNN_LDS_PAD")) : 0;   // experiment: cap workgroups per CU
-    hipLaunchKernelGGL((tapgemm_kernel<RT, NT, KC>), grid, dim3(256), lds_pad, s, p);
+    pnn_launch(tapgemm_kernel<RT, NT, KC>, grid, dim3(256), lds_pad, s, p);
     return hipGetLastError();
 }
 
@@ -368,7 +368,7 @@ template <int NT>
 static hipError_t launch_sk(const TapGemmParams& p, hipStream_t s)
 {
     dim3 grid((p.M + 15) / 16, (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
-    hipLaunchKernelGGL((tapgemm_splitk_kernel<NT>), grid, dim3(256), 0, s, p);
+    pnn_launch(tapgemm_splitk_kernel<NT>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
