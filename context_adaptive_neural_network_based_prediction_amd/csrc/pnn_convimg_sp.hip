@@ -12,6 +12,10 @@
 //   output pixels (rows past G*SH*SW idle), all of them taken from the G staged input images.
 //   LDS: weights [2][KC][4 planes][BN] slots | images [(G*IH*IW + 1)][Cin/4 + 1] slots (16-B slots; the +1 slot of
 //   pitch keeps the 64-lane fragment reads conflict-free; the extra pixel is all zeros = SAME padding / idle rows).
+// Measured (tools/convimg_prof.hip, 3x3 conv 64 -> 64 on 1024 images of 8x24, tile 192 x 64): per workgroup ~9.5k cycles
+// to stage its 52 KB image, ~30k in the tap loop (1650 per 32-deep stage for 576 MFMA cycles, two workgroups per CU), ~10k in
+// the epilogue.  Staging by LDS-DMA with an XOR-swizzled layout was tried: same 9.3k cycles -- the 50 MB of activations of
+// all resident workgroups arrive as one burst at ~5.8 TB/s, it is memory bandwidth, not the copy loop.
 #include "pnn_kernels.h"
 #include <type_traits>
 #include "pnn_device_common.h"
@@ -25,6 +29,9 @@ template <int RT, int NT, int KC, int WM>
 __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, const int G)
 {
     touch_kernargs<sizeof(TapGemmParams) + 4>();   // see pnn_device_common.h
+#ifdef PNN_CI_DIAG              // coarse phase stamps of wave 0 (tools/convimg_prof.hip), written to p.Xlo
+    const unsigned long long dq0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int WN = 4 / WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int E = 4 * BN;
@@ -167,6 +174,9 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     load_b(0, b_stage);
     store_b(0, b_stage);
     __syncthreads();                                  // images + first weight stage visible
+#ifdef PNN_CI_DIAG
+    const unsigned long long dq1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < nstages; s++) {
         const int buf = s & 1;
         const bool more = s + 1 < nstages;
@@ -194,6 +204,11 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         __syncthreads();
     }
 
+#ifdef PNN_CI_DIAG
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long dq2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- epilogue (as tapgemm_sp_kernel) -------------------------------------------------------------------------
     const int py = p.py[cls], px = p.px[cls];
     // all bias values first: a load placed next to its use cannot be hoisted over the stores in between (the compiler
@@ -247,6 +262,14 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     if (p.Yhi && !p.Y && !p.Yi) groups(std::integral_constant<int, 0>{});
     else if (p.Y && !p.Yhi && !p.Yi) groups(std::integral_constant<int, 1>{});
     else groups(std::integral_constant<int, 2>{});
+#ifdef PNN_CI_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        const unsigned long long dq3 = __builtin_amdgcn_s_memtime();
+        d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = dq3 - dq2; d[3] = nstages;
+    }
+#endif
 }
 
 // X(rt, nt, kc, wm): workgroup rows 32*rt*wm, columns 32*nt*(4/wm)

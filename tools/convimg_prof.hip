@@ -1,0 +1,55 @@
+// Diagnostic (not part of the product): times convimg_sp_kernel on a synthetic 3x3 stride-1 convolution layer and prints
+// the coarse phase stamps of wave 0 (PNN_CI_DIAG).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPNN_CI_DIAG -Icontext_adaptive_neural_network_based_prediction_amd/csrc -Iinclude tools/convimg_prof.hip -o build_tmp/ci_prof
+//   ./build_tmp/ci_prof [images] [H] [W] [Cin] [Cout]
+#include "pnn_convimg_sp.hip"
+namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace pnn;
+
+int main(int argc, char** argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 1024, H = argc > 2 ? atoi(argv[2]) : 8, W = argc > 3 ? atoi(argv[3]) : 24;
+    const int Cin = argc > 4 ? atoi(argv[4]) : 64, Cout = argc > 5 ? atoi(argv[5]) : 64;
+    const int nchunk = 9 * Cin / 16, Npad = ((Cout + 15) / 16) * 16 + 160;
+    const size_t xb = (size_t)B * H * W * Cin * 4, wb = (size_t)nchunk * 4 * Npad * 16;
+    std::vector<_Float16> hx(xb / 2), hw(wb / 2);
+    srand(1);
+    for (auto& v : hx) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+    for (auto& v : hw) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+    void *dx, *dw, *dy, *dd, *dz; float* db;
+    hipMalloc(&dz, 4096); hipMemset(dz, 0, 4096);
+    hipMalloc(&dx, xb); hipMalloc(&dw, wb); hipMalloc(&dy, (size_t)B * H * W * Cout * 4); hipMalloc(&dd, 1 << 24); hipMalloc(&db, Npad * 4);
+    hipMemcpy(dx, hx.data(), xb, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice);
+    hipMemset(db, 0, Npad * 4);
+    TapGemmParams p{};
+    p.X = (const float*)dx; p.Xlo = dd; p.Wp = (const float*)dw; p.bias = db; p.Yhi = dy; p.out_scale = 1.f; p.zero = dz;
+    p.M = B * H * W; p.SH = H; p.SW = W; p.IH = H; p.IW = W; p.Cin = Cin; p.a = 1; p.OH = H; p.OW = W; p.Cout = Cout; p.os = 1; p.Npad = Npad; p.act = 1;
+    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 9; p.chunk_begin[0] = 0; p.chunk_begin[1] = nchunk;
+    for (int t = 0; t < 9; t++) p.tap[t] = pack_tap(t / 3 - 1, t % 3 - 1);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < convimg_sp_num_cfgs(); i++) {
+        const TileCfg t = convimg_sp_cfg(i);
+        const int rows = 32 * t.rt * t.wm, bn = 32 * t.nt * (4 / t.wm);
+        int G = rows / (H * W);
+        while (G > 0 && convimg_sp_lds_bytes(p, t, G) > (size_t)156 * 1024) --G;
+        if (G <= 0 || (Cin / 16) % t.kc) continue;
+        const int nwg = ((B + G - 1) / G) * ((Cout + bn - 1) / bn);
+        if (launch_convimg_sp(p, i, G, 0) != hipSuccess) { printf("cfg %d: launch failed\n", i); continue; }
+        hipEventRecord(e0);
+        for (int r = 0; r < 20; r++) launch_convimg_sp(p, i, G, 0);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(4 * (size_t)nwg);
+        hipMemcpy(h.data(), dd, h.size() * 8, hipMemcpyDeviceToHost);
+        double s[3] = {0, 0, 0};
+        for (int w = 0; w < nwg; w++) for (int k = 0; k < 3; k++) s[k] += (double)h[4 * w + k];
+        const double us = ms * 1e3 / 20, nst = (double)h[3];
+        printf("img{%d,%d,%d,wm%d} rows %3d (G=%d, %2.0f%% used) x %3d cols  %4d WGs  LDS %3zu KB  %6.1f us  %5.1f TF-eq | wave 0 avg: staging %6.0f cyc  loop %6.0f (%4.0f/stage, MFMA work %d)  epilogue %5.0f\n",
+               t.rt, t.nt, t.kc, t.wm, rows, G, 100.0 * G * H * W / rows, bn, nwg, convimg_sp_lds_bytes(p, t, G) >> 10, us, 2.0 * p.M * 9.0 * Cin * Cout / us / 1e6,
+               s[0] / nwg, s[1] / nwg, s[1] / nwg / nst, t.rt * t.nt * 3 * t.kc * 32, s[2] / nwg);
+    }
+    return 0;
+}
