@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
             v = *reinterpret_cast<const f32x4*>(p.X + (((bbase + li) * p.IH + iy) * p.IW + ix) * p.Cin + 4 * c4);
         xt[(li * C4 + c4) * NP + pix] = v;
     }
+    // the k x k x Cin weights behind the tiles: read per (tap, channel quad) as one broadcast ds_read_b128 in the inner
+    // loop (as wave-uniform scalar loads they cost a ~200-cycle round trip per iteration: 26 us for the 16x16 net at
+    // batch 1024, most of it waiting)
+    f32x4* wl = xt + NI * C4 * NP;
+    for (int idx = threadIdx.x; idx < K * K * C4; idx += 256) wl[idx] = reinterpret_cast<const f32x4*>(p.W)[idx];
     __syncthreads();
 
     // Thread -> (image, output pixel).  Stride 2: wave = parity class (py, px), lanes = NI images x (TO/2)^2
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
             if ((px + p.pad - kx) % s) continue;
             const int rx = (ox + p.pad - kx) / s - ix0;
             const f32x4* xp = xt + (size_t)li * C4 * NP + ry * TI + rx;
-            const f32x4* wp = reinterpret_cast<const f32x4*>(p.W + (size_t)(ky * K + kx) * p.Cin);   // uniform -> scalar loads
+            const f32x4* wp = wl + (ky * K + kx) * C4;
             for (int c4 = 0; c4 < C4; c4++) {
                 const f32x4 xv = xp[c4 * NP], wv = wp[c4];
                 acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
@@ -168,12 +173,13 @@ hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)
     const int TI = (TO - 1 + p.pad) / p.s - i0 + 1;
     const size_t per_img = (size_t)TI * TI * p.Cin * sizeof(float);
     int ni = p.s == 2 ? 64 / ((TO / 2) * (TO / 2)) : 256 / (TO * TO);
-    while (ni > 1 && ni * per_img > 60 * 1024) ni >>= 1;
-    if (ni < 1 || per_img > 64 * 1024) return hipErrorInvalidValue;
+    const size_t wbytes = (size_t)p.k * p.k * p.Cin * sizeof(float);          // the weights share the workgroup's LDS
+    while (ni > 1 && ni * per_img + wbytes > 60 * 1024) ni >>= 1;
+    if (ni < 1 || per_img + wbytes > 64 * 1024) return hipErrorInvalidValue;
     p.ni = ni;
     const int tiles = ((OH + TO - 1) / TO) * ((OH + TO - 1) / TO);
     dim3 grid((p.B + ni - 1) / ni, tiles);
-    hipLaunchKernelGGL(tconv_cout1_kernel, grid, dim3(256), ni * per_img, s, p);
+    hipLaunchKernelGGL(tconv_cout1_kernel, grid, dim3(256), ni * per_img + wbytes, s, p);
     return hipGetLastError();
 }
 
