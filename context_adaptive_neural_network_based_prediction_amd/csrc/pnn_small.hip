@@ -326,10 +326,59 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
     }
 }
 
+// FC rows in the split layout, four consecutive elements per thread (they share a context row: w and 3w are multiples
+// of 4): one 8-byte store of the hi halves and one of the lo halves instead of eight 2-byte stores, constant divisors.
+template <typename Pel, int W>
+__global__ __launch_bounds__(256) void gather_split4_kernel(const GatherParams p)
+{
+    touch_kernargs<sizeof(GatherParams)>();
+    constexpr int NA = 3 * W * W, PER = 5 * W * W, Q = PER / 4;
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= (unsigned)p.N * Q) return;
+    const unsigned tb = gid / Q;
+    const int r = (int)(gid - tb * Q) * 4;
+    const TbDev d = p.tbs[tb];
+    const Pel* plane = reinterpret_cast<const Pel*>(p.plane) + d.origin;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < NA) {
+        const int row = r / (3 * W), col = r - row * (3 * W);
+        const bool ok = col < W || ((d.above_mask >> ((col - W) / p.unit)) & 1u);   // a 4-pixel unit never straddles the 4 elements
+        if (ok) {
+            const Pel* src = plane + (long)(row - W) * d.stride + (col - W);
+            v = (f32x4){(float)src[0] - p.mean, (float)src[1] - p.mean, (float)src[2] - p.mean, (float)src[3] - p.mean};
+        }
+    } else {
+        const int rl = r - NA;
+        const int row = rl / W, col = rl - row * W;
+        if (row < d.left_units * p.unit) {
+            const Pel* src = plane + (long)row * d.stride + (col - W);
+            v = (f32x4){(float)src[0] - p.mean, (float)src[1] - p.mean, (float)src[2] - p.mean, (float)src[3] - p.mean};
+        }
+    }
+    store_split4(p.above, (size_t)tb * PER, r, v);
+}
+
+template <typename Pel>
+static bool launch_gather_split4(const GatherParams& p, hipStream_t s)
+{
+    if (p.unit != 4) return false;
+    const long threads = (long)p.N * (5 * p.w * p.w / 4);
+    if (threads >= 0x7fffffffL) return false;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    switch (p.w) {
+        case 4: hipLaunchKernelGGL((gather_split4_kernel<Pel, 4>), grid, block, 0, s, p); return true;
+        case 8: hipLaunchKernelGGL((gather_split4_kernel<Pel, 8>), grid, block, 0, s, p); return true;
+        case 16: hipLaunchKernelGGL((gather_split4_kernel<Pel, 16>), grid, block, 0, s, p); return true;
+        default: return false;
+    }
+}
+
 hipError_t launch_gather(const GatherParams& p, hipStream_t s)
 {
     const long total = (long)p.N * 5 * p.w * p.w;
     if (total <= 0) return hipSuccess;
+    if (p.split && (p.pel_bytes == 4 ? launch_gather_split4<int32_t>(p, s) : p.pel_bytes == 1 ? launch_gather_split4<uint8_t>(p, s) : false))
+        return hipGetLastError();
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
