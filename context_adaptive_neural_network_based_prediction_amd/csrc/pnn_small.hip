@@ -358,6 +358,38 @@ __global__ __launch_bounds__(256) void gather_split4_kernel(const GatherParams p
     store_split4(p.above, (size_t)tb * PER, r, v);
 }
 
+// The same for f32 outputs (above / left portions of the convolutional nets, or f32 FC rows): one 16-byte store per thread.
+template <typename Pel>
+__global__ __launch_bounds__(256) void gather_f32x4_kernel(const GatherParams p)
+{
+    touch_kernargs<sizeof(GatherParams)>();
+    const int w = p.w, na = 3 * w * w, q = 5 * w * w / 4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)p.N * q) return;
+    const long tb = gid / q;
+    const int r = (int)(gid - tb * q) * 4;
+    const TbDev d = p.tbs[tb];
+    const Pel* plane = reinterpret_cast<const Pel*>(p.plane) + d.origin;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < na) {
+        const int row = r / (3 * w), col = r - row * (3 * w);
+        const bool ok = col < w || ((d.above_mask >> ((col - w) / p.unit)) & 1u);
+        if (ok) {
+            const Pel* src = plane + (long)(row - w) * d.stride + (col - w);
+            v = (f32x4){(float)src[0] - p.mean, (float)src[1] - p.mean, (float)src[2] - p.mean, (float)src[3] - p.mean};
+        }
+        *reinterpret_cast<f32x4*>(p.above + tb * p.pitch_above + r) = v;
+    } else {
+        const int rl = r - na;
+        const int row = rl / w, col = rl - row * w;
+        if (row < d.left_units * p.unit) {
+            const Pel* src = plane + (long)row * d.stride + (col - w);
+            v = (f32x4){(float)src[0] - p.mean, (float)src[1] - p.mean, (float)src[2] - p.mean, (float)src[3] - p.mean};
+        }
+        *reinterpret_cast<f32x4*>(p.left + tb * p.pitch_left + rl) = v;
+    }
+}
+
 template <typename Pel>
 static bool launch_gather_split4(const GatherParams& p, hipStream_t s)
 {
@@ -379,6 +411,14 @@ hipError_t launch_gather(const GatherParams& p, hipStream_t s)
     if (total <= 0) return hipSuccess;
     if (p.split && (p.pel_bytes == 4 ? launch_gather_split4<int32_t>(p, s) : p.pel_bytes == 1 ? launch_gather_split4<uint8_t>(p, s) : false))
         return hipGetLastError();
+    if (!p.split && p.unit == 4 && p.pitch_above % 4 == 0 && p.pitch_left % 4 == 0 && ((uintptr_t)p.above & 15) == 0 && ((uintptr_t)p.left & 15) == 0 &&
+        (p.pel_bytes == 4 || p.pel_bytes == 1)) {
+        const long threads = (long)p.N * (5 * p.w * p.w / 4);
+        const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+        if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_f32x4_kernel<int32_t>, grid, block, 0, s, p);
+        else hipLaunchKernelGGL(gather_f32x4_kernel<uint8_t>, grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (p.pel_bytes == 4) hipLaunchKernelGGL(gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
