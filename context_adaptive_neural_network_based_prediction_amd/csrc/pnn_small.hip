@@ -6,6 +6,7 @@
 // Reference semantics: extraction_context.cpp:3-208 (gather), pnn/tfutils.py:75-139 (conv, SAME),
 // pnn/tfutils.py:8-73 + components.py:231-237 (merger), pnn/tfutils.py:395-462 (transposed conv, SAME),
 // TComPrediction.cpp:621-635 (epilogue).
+#include <algorithm>
 #include "pnn_kernels.h"
 #include "pnn_device_common.h"
 
@@ -160,10 +161,107 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
     }
 }
 
+// The same layer for Cin == 64 (every reference net ends in it: k = 5, s = 2, 64 -> 1) on the fp32 matrix cores.
+// Phase 1 is a GEMM: T[input pixel][tap] = sum_c x[pixel][c] * w[tap][c] with v_mfma_f32_32x32x2_f32 (M = 32 pixels per
+// wave tile, N = 25 taps padded to 32, K = 64 in 32 steps), T kept in LDS.  Phase 2 is the col2im: every output pixel
+// adds the <= 9 entries of T its parity class reaches.  Workgroup = one band of full-width input rows of one block, so
+// the pixel rows of a tile are contiguous in memory.  The LDS version above reads every x value from LDS once per tap
+// (1.6 KB of ds_read per output, 26 us for the 16x16 net at batch 1024); here x goes global -> registers -> MFMA once.
+// The K order inside the MFMA is a fixed permutation of the channels (lane half h, step 4q+i <-> channel 8q+4h+i), the
+// same for every batch size.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kTcTP = 33;                            // LDS pitch of a T row (32 taps + 1)
+template <int s, int K>                              // compile-time stride and kernel size: the parity tests of phase 2 fold
+__global__ __launch_bounds__(256) void tconv_cout1_mfma_kernel(const TConv1Params p)
+{
+    touch_kernargs<sizeof(TConv1Params)>();
+    extern __shared__ __attribute__((aligned(16))) float T[];        // [pixels of the band, padded to 32][kTcTP]
+    constexpr int KK = K * K;
+    const int OH = p.IH * s, OW = p.IW * s;
+    const int TOH = p.ni;                             // output rows per band (set by the launcher)
+    const long b = blockIdx.x;
+    const int oy0 = blockIdx.y * TOH;
+    const int lo_y = oy0 + p.pad - (K - 1);
+    int iy0 = lo_y >= 0 ? lo_y / s : -((-lo_y + s - 1) / s);
+    int iy1 = (oy0 + TOH - 1 + p.pad) / s;
+    if (iy0 < 0) iy0 = 0;
+    if (iy1 > p.IH - 1) iy1 = p.IH - 1;
+    const int npx = (iy1 - iy0 + 1) * p.IW;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int col = lane & 31, h = lane >> 5;
+    const int tiles = (npx + 31) >> 5;
+    if (wave < tiles) {
+        f32x4 wv[8];                                  // B operand: w[tap = col][channels 8q + 4h .. +3]
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            wv[q] = col < KK ? *reinterpret_cast<const f32x4*>(p.W + col * 64 + 8 * q + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* xb = p.X + ((b * p.IH + iy0) * (long)p.IW) * 64;
+        for (int t = wave; t < tiles; t += 4) {
+            int px = t * 32 + col;
+            if (px >= npx) px = npx - 1;              // padding rows of the last tile: recomputed, never read
+            const float* xr = xb + (long)px * 64 + 4 * h;
+            f32x4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) xv[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q][i], wv[q][i], acc, 0, 0, 0);
+            // acc[r]: pixel row 8 * (r / 4) + 4 * h + r % 4 of the tile, tap = col
+#pragma unroll
+            for (int r = 0; r < 16; r++) T[(t * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * kTcTP + col] = acc[r];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TOH * OW; idx += 256) {
+        const int oyl = idx / OW, ox = idx - oyl * OW;
+        const int oy = oy0 + oyl;
+        if (oy >= OH) break;
+        float v = 0.f;
+        // taps of this pixel's parity class: ky = ky0, ky0 + s, ... with (oy + pad - ky) % s == 0; the numerators are
+        // kept non-negative (+ s * K) so that / and % are shifts
+        const int ky0 = (oy + p.pad) % s, kx0 = (ox + p.pad) % s;
+#pragma unroll
+        for (int a = 0; a < (K + s - 1) / s; a++) {
+            const int ky = ky0 + a * s;
+            const int iy = (oy + p.pad - ky + s * K) / s - K;
+            if (ky >= K || iy < iy0 || iy > iy1) continue;   // band rows are clipped to the image: outside = zero input
+#pragma unroll
+            for (int c = 0; c < (K + s - 1) / s; c++) {
+                const int kx = kx0 + c * s;
+                const int ix = (ox + p.pad - kx + s * K) / s - K;
+                if (kx >= K || (unsigned)ix >= (unsigned)p.IW) continue;
+                v += T[((iy - iy0) * p.IW + ix) * kTcTP + ky * K + kx];
+            }
+        }
+        v += p.bias;
+        const size_t o = ((size_t)b * OH + oy) * OW + ox;
+        if (p.Y) p.Y[o] = v;
+        if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
+    }
+}
+
 hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)
 {
     TConv1Params p = pin;
     if (p.B <= 0) return hipSuccess;
+    if (p.Cin == 64 && ((p.s == 2 && p.k == 5) || (p.s == 1 && p.k == 3)) && p.pad <= p.k - 1) {
+        // band = as many output rows as keep T <= ~42 KB (320 input pixels): whole image up to 16x16 inputs
+        const int OH = p.IH * p.s;
+        int toh = OH;
+        auto band_px = [&](int t) { return ((t - 1 + p.pad) / p.s + (p.k - 1 - p.pad + p.s - 1) / p.s + 1) * p.IW; };
+        while (toh > p.s && band_px(toh) > 320 && toh % 2 == 0) toh /= 2;
+        const int npx = std::min(band_px(toh), p.IH * p.IW);
+        const size_t lds = (size_t)((npx + 31) / 32) * 32 * kTcTP * sizeof(float);
+        if (lds <= 64 * 1024) {
+            p.ni = toh;
+            const dim3 grid(p.B, (OH + toh - 1) / toh);
+            if (p.s == 2) hipLaunchKernelGGL((tconv_cout1_mfma_kernel<2, 5>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((tconv_cout1_mfma_kernel<1, 3>), grid, dim3(256), lds, s, p);
+            return hipGetLastError();
+        }
+    }
     if ((p.s != 1 && p.s != 2) || p.Cin % 4 || p.IH != p.IW) return hipErrorInvalidValue;
     const int OH = p.IH * p.s;
     const int TO = OH < 16 ? OH : 16;
@@ -189,50 +287,51 @@ hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)
 // MB blocks); lanes run over c, the innermost NHWC index, so every load and store is coalesced; W is
 // pre-arranged as [p][j][c].
 // ------------------------------------------------------------------------------------------------
-constexpr int kMergerMB = 2;
+template <int MB, int J>
 __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
 {
     touch_kernargs<sizeof(MergerParams)>();
+    constexpr int NJ = 16 / J;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(gid % p.C);
     const long r = gid / p.C;
-    const int jq = (int)(r & 3);
-    const long b0 = (r >> 2) * kMergerMB;
+    const int jq = (int)(r % NJ);
+    const long b0 = (r / NJ) * MB;
     if (b0 >= p.B) return;
-    float acc[kMergerMB][4];
+    float acc[MB][J];
 #pragma unroll
-    for (int m = 0; m < kMergerMB; m++)
+    for (int m = 0; m < MB; m++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[m][j] = 0.f;
-    long brow[kMergerMB];
+        for (int j = 0; j < J; j++) acc[m][j] = 0.f;
+    long brow[MB];
 #pragma unroll
-    for (int m = 0; m < kMergerMB; m++) brow[m] = (b0 + m < p.B) ? b0 + m : b0;
+    for (int m = 0; m < MB; m++) brow[m] = (b0 + m < p.B) ? b0 + m : b0;
     // two plain loops (above part, then left part) instead of a per-iteration select between the sources
     auto part = [&](const float* src, int np, int pbase) {
-#pragma unroll 8
+#pragma unroll 4
         for (int pp = 0; pp < np; pp++) {
-            float xv[kMergerMB];
+            float xv[MB];
 #pragma unroll
-            for (int m = 0; m < kMergerMB; m++) xv[m] = src[(brow[m] * np + pp) * p.C + c];
+            for (int m = 0; m < MB; m++) xv[m] = src[(brow[m] * np + pp) * p.C + c];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float wv = p.Wp[((size_t)(pbase + pp) * 16 + 4 * jq + j) * p.C + c];
+            for (int j = 0; j < J; j++) {
+                const float wv = p.Wp[((size_t)(pbase + pp) * 16 + J * jq + j) * p.C + c];
 #pragma unroll
-                for (int m = 0; m < kMergerMB; m++) acc[m][j] += xv[m] * wv;
+                for (int m = 0; m < MB; m++) acc[m][j] += xv[m] * wv;
             }
         }
     };
     part(p.A, p.na, 0);
     part(p.L, p.nl, p.na);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float bv = p.bias[(size_t)(4 * jq + j) * p.C + c];
+    for (int j = 0; j < J; j++) {
+        const float bv = p.bias[(size_t)(J * jq + j) * p.C + c];
 #pragma unroll
-        for (int m = 0; m < kMergerMB; m++)
+        for (int m = 0; m < MB; m++)
             if (b0 + m < p.B) {
                 const float v = leaky(acc[m][j] + bv);
-                if (p.split) store_split1(p.Y, ((size_t)(b0 + m) * 16 + 4 * jq + j) * p.C, c, v);
-                else p.Y[((b0 + m) * 16 + 4 * jq + j) * p.C + c] = v;
+                if (p.split) store_split1(p.Y, ((size_t)(b0 + m) * 16 + J * jq + j) * p.C, c, v);
+                else p.Y[((b0 + m) * 16 + J * jq + j) * p.C + c] = v;
             }
     }
 }
@@ -283,8 +382,18 @@ hipError_t launch_merger(const MergerParams& p, hipStream_t s)
         hipLaunchKernelGGL(merger_small_kernel, dim3((p.C + 63) / 64, 4, p.B), dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    const long threads = (long)((p.B + kMergerMB - 1) / kMergerMB) * 4 * p.C;
-    hipLaunchKernelGGL(merger_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
+    static int cfg = getenv("PNN_MERGER_CFG") ? atoi(getenv("PNN_MERGER_CFG")) : 0;
+#define MG(MB_, J_) { const long threads = (long)((p.B + MB_ - 1) / MB_) * (16 / J_) * p.C; \
+        hipLaunchKernelGGL((merger_kernel<MB_, J_>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p); }
+    switch (cfg) {
+    case 1: MG(4, 8) break;
+    case 2: MG(2, 16) break;
+    case 3: MG(4, 4) break;
+    case 4: MG(8, 4) break;
+    case 5: MG(4, 16) break;
+    case 6: MG(2, 8) break;
+    default: MG(2, 4) break;
+    }
     return hipGetLastError();
 }
 
