@@ -336,6 +336,83 @@ __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
     }
 }
 
+// The batch kernel on the fp32 matrix cores.  Per channel the merger is a [B x 80] x [80 x 16] product; with the channel
+// innermost in memory one tile is 16 blocks x 16 CHANNELS: lane (block bi = lane % 16, position slot lane / 16) loads
+// the 64 contiguous bytes x[b][p][c0 .. c0 + 15] and w[p][j = lane % 16][c0 .. c0 + 15], and channel i's 16x16x4 MFMA
+// takes element i of both -- 8 x 16-byte loads feed 16 MFMAs per 4 positions.
+// The layer is bound by memory LATENCY, not by arithmetic or L1 traffic (the scalar kernel above and a one-wave-per-tile
+// MFMA version both took 29-31 us for the 16x16 net at batch 1024, 42 MB of input: ten dependent round trips with only
+// ~4 MB in flight).  So the 20 position steps of a tile are split over the 4 waves of a workgroup, every wave issues
+// ALL its loads (5 steps x 8) before the first MFMA, and the partial sums meet in LDS in a fixed order.
+// Workgroups i, i + 8, ... run on one XCD (round-robin dispatch): they get the channel groups of the same blocks, so an
+// XCD's L2 fetches whole rows instead of 64-byte pieces of everyone's.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
+{
+    touch_kernargs<sizeof(MergerParams)>();
+    __shared__ f32x4 red[3][16][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ngc = p.C >> 4;
+    const long rest = blockIdx.x >> 3;
+    const int c0 = (int)(rest % ngc) * 16;
+    const long bg = (rest / ngc) * 8 + (blockIdx.x & 7);
+    if (bg * 16 >= p.B) return;
+    const int li = lane & 15, lk = lane >> 4;
+    long brow = bg * 16 + li;
+    if (brow >= p.B) brow = p.B - 1;
+    f32x4 xv[5][4], wv[5][4];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int p0 = 4 * (wave + 4 * t);            // first position of this step (wave-uniform): above part or left part
+        const float* xr = p0 < p.na ? p.A + ((size_t)brow * p.na + p0 + lk) * p.C + c0
+                                    : p.L + ((size_t)brow * p.nl + (p0 - p.na) + lk) * p.C + c0;
+        const float* wr = p.Wp + ((size_t)(p0 + lk) * 16 + li) * p.C + c0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            xv[t][q] = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+            wv[t][q] = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);               // every load is in flight before the first MFMA waits
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc[4 * q + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][q][i], wv[t][q][i], acc[4 * q + i], 0, 0, 0);
+    if (wave) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) red[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave) return;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (acc[i] + red[0][i][lane]) + (red[1][i][lane] + red[2][i][lane]);
+    // acc[i][r]: block bg * 16 + 4 * lk + r, output j = li, channel c0 + i
+    f32x4 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + (size_t)li * p.C + c0 + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long b = bg * 16 + 4 * lk + r;
+        const size_t pix = (size_t)b * 16 + li;
+        if (b < p.B) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = leaky(acc[4 * q + i][r] + bv[q][i]);
+                if (SPLIT) store_split4(p.Y, pix * p.C, c0 + 4 * q, v);
+                else *reinterpret_cast<f32x4*>(p.Y + pix * p.C + c0 + 4 * q) = v;
+            }
+        }
+    }
+}
+
 // Small batches (the in-loop single-block calls): the 80-position sum of one output is split over 4 threads (positions
 // p = pg, pg + 4, ...) and combined through LDS in a fixed order -- four times the threads, a quarter of the dependent
 // load chain (the batch kernel above took ~20 us for ONE block: its 80 steps are serial per thread).
@@ -382,18 +459,15 @@ hipError_t launch_merger(const MergerParams& p, hipStream_t s)
         hipLaunchKernelGGL(merger_small_kernel, dim3((p.C + 63) / 64, 4, p.B), dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    static int cfg = getenv("PNN_MERGER_CFG") ? atoi(getenv("PNN_MERGER_CFG")) : 0;
-#define MG(MB_, J_) { const long threads = (long)((p.B + MB_ - 1) / MB_) * (16 / J_) * p.C; \
-        hipLaunchKernelGGL((merger_kernel<MB_, J_>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p); }
-    switch (cfg) {
-    case 1: MG(4, 8) break;
-    case 2: MG(2, 16) break;
-    case 3: MG(4, 4) break;
-    case 4: MG(8, 4) break;
-    case 5: MG(4, 16) break;
-    case 6: MG(2, 8) break;
-    default: MG(2, 4) break;
+    if (p.C % 16 == 0 && p.na % 4 == 0 && p.na + p.nl == 80) {
+        const long bgs = ((p.B + 15) / 16 + 7) / 8 * 8;       // block groups, padded to the 8-way XCD interleave
+        const dim3 grid((unsigned)(bgs * (p.C / 16))), block(256);
+        if (p.split) hipLaunchKernelGGL(merger_mfma_kernel<true>, grid, block, 0, s, p);
+        else hipLaunchKernelGGL(merger_mfma_kernel<false>, grid, block, 0, s, p);
+        return hipGetLastError();
     }
+    const long threads = (long)((p.B + 1) / 2) * 4 * p.C;
+    hipLaunchKernelGGL((merger_kernel<2, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
