@@ -85,7 +85,12 @@ struct pnn_ctx {
     float mean = 0.f;
     hipStream_t stream = nullptr;
     Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf ws[4];                                     // P0, P1, F0, F1 (FC uses P0, P1)
+    DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
+    // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
+    // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
+    long opt_branch_streams = 1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf stage_in[2], stage_out[2], stage_tbs;
     // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
     // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.
@@ -759,6 +764,17 @@ long chunk_blocks(const pnn_ctx* c, const Model* m)
     return std::max(1L, std::min(n, 1L << 20));
 }
 
+// The branches of a conv pass overlap on two streams while one branch leaves most of the chip idle.  The fork/join costs
+// ~25 us of event traffic between the two queues (measured: single-block calls of the 16x16 net 88 -> 97 us, 32x32 157 ->
+// 147 us, 64x64 261 -> 220 us), so only the nets whose branches are longer than that take it, option "branch_streams" = 2
+// forces it.  Not under the per-launch timing modes, which assume one stream.
+bool branches_overlap(const pnn_ctx* c, const Model* m, long nb)
+{
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;
+    if (!c->opt_branch_streams || m->is_fc || profile || c->opt_time_launches) return false;
+    return nb * m->width * m->width <= 8192 && (m->width >= 32 || c->opt_branch_streams == 2);
+}
+
 int ensure_ws(pnn_ctx* c, const Model* m, long nb)
 {
     int rc;
@@ -769,6 +785,15 @@ int ensure_ws(pnn_ctx* c, const Model* m, long nb)
     } else {
         if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 48 * m->C * 4))) return rc;
         if ((rc = dev_reserve(c, c->ws[3], (size_t)nb * 32 * m->C * 4))) return rc;
+        if (branches_overlap(c, m, nb)) {
+            if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
+            if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
+            if (!c->side_stream) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+        }
     }
     return PNN_OK;
 }
@@ -944,7 +969,18 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     // tensors consumed by the merger / the last transposed convolution stay f32.
     const bool sp = pass_uses_split(c, m, nb);
     int rc;
+    const bool par = branches_overlap(c, m, nb) && c->side_stream && c->ws[4].bytes >= (size_t)nb * m->pmax * 4 &&
+                     c->ws[5].bytes >= (size_t)nb * m->pmax * 4;   // ensure_ws sized them for this pass's chunk
+    hipStream_t const main_stream = s;
+    if (par) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    }
     for (int br = 0; br < 2; br++) {
+        if (par) {
+            s = br == 0 ? main_stream : c->side_stream;
+            if (br == 1) { P[0] = (float*)c->ws[4].p; P[1] = (float*)c->ws[5].p; }
+        }
         const size_t nl = m->branch[br].size();
         Conv1Params f = m->first[br].proto;
         f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
@@ -962,6 +998,12 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             if (rc) return rc;
             cur ^= 1;
         }
+    }
+    if (par) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+        s = main_stream;
+        P[0] = (float*)c->ws[0].p; P[1] = (float*)c->ws[1].p;
     }
     const size_t nt = m->tconv.size();
     MergerParams mp = m->merger.proto;
@@ -1096,6 +1138,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_CHAIN")) c->opt_chain = atol(e);
+    if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -1186,6 +1229,9 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_chain) (void)hipFree(c->d_chain);
     if (c->d_chain_cnt) (void)hipFree(c->d_chain_cnt);
@@ -1222,6 +1268,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "chain")) c->opt_chain = value;
+    else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;

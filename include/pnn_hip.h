@@ -78,6 +78,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * split-precision GEMM kernels on the device and keeps the fastest -- all of them give bit-identical results, so only
  * the speed depends on it; 2, default: only for launches of >= 4 GFLOP, i.e. big batches, where it costs a few tens
  * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region),
+ * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
+ * calls -- run the two independent branches on two HIP streams, forked and joined by events; 2: every small conv
+ * pass; 0: one stream.  Results do not depend on it),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder

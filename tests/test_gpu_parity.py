@@ -424,6 +424,27 @@ def test_chained_fc_kernel(pnn, oracle, precision):
     _check_pel(net.predict_pel(ctx)[idx], oracle.epilogue(oracle.fc_forward(params, w, ctx[idx]), util.MEAN))
 
 
+@pytest.mark.parametrize("w", [16, 32, 64])
+def test_conv_branches_on_two_streams(pnn, oracle, w):
+    """Option "branch_streams": small conv passes run the two branches concurrently on two HIP streams (fork / join by
+    events, the left branch on its own buffer pair).  The result must not depend on it -- a missing dependency would show
+    as a difference or as run-to-run noise -- also when single-block and batched calls alternate on one context (the side
+    buffers are sized per pass)."""
+    params = util.make_params(w, False, 81, out_gain=util.out_gain(w, False))
+    above, left = util.make_contexts(w, 6, 82)
+    net = pnn.PredictionNeuralNetwork(6, w, False, params=params)
+    net.set_option("branch_streams", 0)
+    ref1 = [net.predict(above[i:i + 1], left[i:i + 1]).copy() for i in range(6)]
+    ref3 = net.predict(above[:3], left[:3]).copy()
+    for mode in (2, 1):
+        net.set_option("branch_streams", mode)
+        for rep in range(3):
+            for i in range(6):
+                assert np.array_equal(net.predict(above[i:i + 1], left[i:i + 1]), ref1[i]), (mode, rep, i)
+            assert np.array_equal(net.predict(above[:3], left[:3]), ref3), (mode, rep)
+    np.testing.assert_allclose(ref1[0][..., 0], oracle.conv_forward(params, w, above[:1], left[:1]), rtol=0, atol=FLOAT_ATOL)
+
+
 # ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
 def test_full_size_properties(pnn, oracle, w, is_fc, n):
