@@ -33,6 +33,38 @@ def test_abi_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+    """gfx950 erratum found in round 1 (tools/pkfma_probe.hip, csrc/Makefile): a v_pk_fma_f32 whose destination pair is
+    also its broadcast source pair can read a half that it has already overwritten while another wave on the SIMD issues
+    MFMAs -- rare one-pixel errors whenever a second stream or context shares the chip.  The library is therefore built
+    without packed-fp32 VALU code; this checks every code object embedded in the shipped .so."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM binutils not installed")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, _lib.LIB_PATH, os.devnull], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    n_objects = n_mfma = 0
+    for i, a in enumerate(starts):
+        piece = str(tmp_path / ("bundle%d.bin" % i))
+        open(piece, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = str(tmp_path / ("dev%d.co" % i))
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + piece, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--output=" + co], check=True)
+        if not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        asm = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+        n_objects += 1
+        n_mfma += len(re.findall(r"\bv_mfma_", asm))
+        bad = sorted(set(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", asm)))
+        assert not bad, "code object %d contains %s" % (i, bad)
+    assert n_objects >= 5 and n_mfma > 1000           # really looked at the kernels
+
+
 def test_service_header_symbols_exported():
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pnn_service.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(pnn_(?:service|client)_[a-z0-9_]+)\s*\(", header))

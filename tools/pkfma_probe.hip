@@ -1,0 +1,75 @@
+// Diagnostic (not part of the product): v_pk_fma_f32 whose destination pair is also its broadcast source pair
+// (vdst == src1 with op_sel picking the OTHER half) -- does it always read the old value?  Checked on the device against
+// scalar fmaf, alone and beside a dense-MFMA kernel on another stream.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pkfma_probe.hip -o build_tmp/pkfma_probe -lpthread
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <thread>
+#include <atomic>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void probe(unsigned* err, int rounds, unsigned seed)
+{
+    unsigned bad_a = 0, bad_b = 0;
+    unsigned s = seed + blockIdx.x * 977u + threadIdx.x * 131u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)(s >> 9) % 2001 - 1000) * 1e-3f; };
+    for (int r = 0; r < rounds; r++) {
+        f32x2 w = {rnd(), rnd()}, x = {rnd(), rnd()}, c = {rnd(), rnd()};
+        // form A (conv_cin1_kernel<5>): both halves take src1's HIGH half
+        f32x2 xa = x;
+        asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0]" : "+v"(xa) : "v"(w), "v"(c));
+        const float ea0 = __builtin_fmaf(w[0], x[1], c[0]), ea1 = __builtin_fmaf(w[1], x[1], c[1]);
+        // form B: both halves take src1's LOW half
+        f32x2 xb = x;
+        asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[1,0,1]" : "+v"(xb) : "v"(w), "v"(c));
+        const float eb0 = __builtin_fmaf(w[0], x[0], c[0]), eb1 = __builtin_fmaf(w[1], x[0], c[1]);
+        bad_a += (xa[0] != ea0) + (xa[1] != ea1);
+        bad_b += (xb[0] != eb0) + (xb[1] != eb1);
+    }
+    if (bad_a) atomicAdd(err, bad_a);
+    if (bad_b) atomicAdd(err + 1, bad_b);
+}
+
+__global__ __launch_bounds__(256) void mfma_partner(float* out, int iters)
+{
+    f32x16 acc[4];
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 16; i++) acc[k][i] = 0.f;
+    f16x8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x - i)); }
+    for (int it = 0; it < iters; it++)
+        for (int k = 0; k < 4; k++) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
+    float s = 0.f;
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 16; i++) s += acc[k][i];
+    if (s == 12345.f) out[0] = s;
+}
+
+int main(int argc, char** argv)
+{
+    const int partners = argc > 1 ? atoi(argv[1]) : 2, reps = argc > 2 ? atoi(argv[2]) : 500;
+    unsigned* derr; float* dp;
+    hipMalloc(&derr, 8); hipMemset(derr, 0, 8); hipMalloc(&dp, 64);
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> ts;
+    for (int t = 0; t < partners; t++)
+        ts.emplace_back([&]() {
+            hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            while (!stop) {
+                for (int k = 0; k < 8; k++) hipLaunchKernelGGL(mfma_partner, dim3(1024), dim3(256), 0, s, dp, 4000);
+                hipStreamSynchronize(s);
+            }
+        });
+    hipStream_t sv; hipStreamCreateWithFlags(&sv, hipStreamNonBlocking);
+    for (int r = 0; r < reps; r++) {
+        hipLaunchKernelGGL(probe, dim3(2048), dim3(256), 0, sv, derr, 2000, (unsigned)r * 7919u);
+        if (r % 8 == 7) hipStreamSynchronize(sv);
+    }
+    hipStreamSynchronize(sv);
+    stop = true;
+    for (auto& t : ts) t.join();
+    unsigned h[2]; hipMemcpy(h, derr, 8, hipMemcpyDeviceToHost);
+    printf("beside %d MFMA partner thread(s), %d launches x 2048 x 256 threads x 2000 rounds: form A (op_sel hi) %u wrong, form B (op_sel lo) %u wrong\n", partners, reps, h[0], h[1]);
+    return 0;
+}

@@ -1,0 +1,84 @@
+// Diagnostic (not part of the product): does tapgemm_ring_kernel stay correct -- and leave its neighbours alone -- when
+// workgroups of ANOTHER kernel share its CUs?  Stream A runs the ring GEMM, stream B a "canary" kernel whose workgroups
+// fill their LDS with a pattern, keep verifying it for a while and count mismatches; the GEMM output is compared with a
+// run on the idle chip.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icontext_adaptive_neural_network_based_prediction_amd/csrc tools/ring_cores.hip -o build_tmp/ring_cores
+//   ./build_tmp/ring_cores [M] [K] [N] [canary LDS KB] [canary threads]
+#include "pnn_gemm_ring.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace pnn;
+namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
+
+__global__ void canary_kernel(int words, int rounds, unsigned* errors)
+{
+    extern __shared__ unsigned cl[];
+    const unsigned seed = blockIdx.x * 2654435761u;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) cl[i] = seed + i;
+    __syncthreads();
+    unsigned bad = 0;
+    for (int r = 0; r < rounds; r++) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) {
+            const unsigned v = cl[i];
+            if (v != seed + i + r) { ++bad; }
+            cl[i] = seed + i + r + 1;
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(errors, bad);
+}
+
+int main(int argc, char** argv)
+{
+    const int M = argc > 1 ? atoi(argv[1]) : 1024, K = argc > 2 ? atoi(argv[2]) : 1200, N = argc > 3 ? atoi(argv[3]) : 1200;
+    const int ckb = argc > 4 ? atoi(argv[4]) : 24, cthreads = argc > 5 ? atoi(argv[5]) : 256;
+    const int nchunk = ((K / 16 + kChunkPad - 1) / kChunkPad) * kChunkPad, Npad = ((N + 15) / 16) * 16 + 160;
+    const size_t xb = (size_t)M * K * 4, wb = (size_t)nchunk * 4 * Npad * 16, yb = (size_t)M * N * 4;
+    std::vector<_Float16> hx(xb / 2), hw(wb / 2);
+    srand(1);
+    for (auto& v : hx) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+    for (auto& v : hw) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+    void *dx, *dw, *dy, *dz; float* db; unsigned* derr;
+    hipMalloc(&dx, xb); hipMalloc(&dw, wb); hipMalloc(&dy, yb); hipMalloc(&dz, 4096); hipMalloc(&db, Npad * 4); hipMalloc(&derr, 4);
+    hipMemcpy(dx, hx.data(), xb, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice);
+    hipMemset(dz, 0, 4096); hipMemset(db, 0, Npad * 4); hipMemset(derr, 0, 4);
+    TapGemmParams p{};
+    p.X = (const float*)dx; p.zero = dz; p.Wp = (const float*)dw; p.bias = db; p.Yhi = dy; p.out_scale = 1.f;
+    p.M = M; p.SH = p.SW = 1; p.IH = p.IW = 1; p.Cin = K; p.a = 1; p.OH = p.OW = 1; p.Cout = N; p.os = 1; p.Npad = Npad; p.act = 1;
+    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.chunk_begin[0] = 0; p.tap[0] = 0;
+    hipStream_t sa, sb;
+    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&canary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ckb * 1024);
+    std::vector<char> ref(yb), got(yb);
+    for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
+        const TileCfg t = tapgemm_ring_cfg(i);
+        hipMemset(dy, 0, yb);
+        if (launch_tapgemm_ring(p, i, sa) != hipSuccess) { printf("cfg %d: launch failed\n", i); continue; }
+        hipStreamSynchronize(sa);
+        hipMemcpy(ref.data(), dy, yb, hipMemcpyDeviceToHost);
+        int alone_bad = 0, bad = 0;
+        for (int r = 0; r < 20; r++) {                // idle chip: repeatable?
+            launch_tapgemm_ring(p, i, sa);
+            hipStreamSynchronize(sa);
+            hipMemcpy(got.data(), dy, yb, hipMemcpyDeviceToHost);
+            alone_bad += memcmp(ref.data(), got.data(), yb) != 0;
+        }
+        hipMemset(derr, 0, 4);
+        for (int r = 0; r < 100; r++) {
+            hipLaunchKernelGGL(canary_kernel, dim3(2048), dim3(cthreads), ckb * 1024, sb, ckb * 256, 40, derr);
+            launch_tapgemm_ring(p, i, sa);
+            launch_tapgemm_ring(p, i, sa);
+            hipStreamSynchronize(sa);
+            hipMemcpy(got.data(), dy, yb, hipMemcpyDeviceToHost);
+            bad += memcmp(ref.data(), got.data(), yb) != 0;
+            hipStreamSynchronize(sb);
+        }
+        unsigned cerr = 0;
+        hipMemcpy(&cerr, derr, 4, hipMemcpyDeviceToHost);
+        printf("ring{%d,%d,%d,wm%d,d%d} lds %3zu KB: alone %d/20 differ | beside the canary %d/100 differ, canary mismatches %u\n", t.rt, t.nt, t.kc, t.wm,
+               t.d, tapgemm_ring_lds_bytes(t) / 1024, alone_bad, bad, cerr);
+    }
+    return 0;
+}
