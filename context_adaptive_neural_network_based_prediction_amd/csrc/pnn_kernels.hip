@@ -14,6 +14,7 @@
 #include "pnn_kernels.h"
 #include "pnn_device_common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace pnn {
 
@@ -221,16 +222,21 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
 
 // ------------------------------------------------------------------------------------------------
 // Tap GEMM for SMALL M (last FC layer, batch-1 calls from inside HM): the four waves of a workgroup
-// share one 16-row x 16*NT-column tile and split K between them (wave w takes chunks w, w+4, ...).
+// share one 16-row x 16*NT-column tile and split K between them (wave w takes chunks w, w+NW, ...).
 // Nothing is shared before the end, so weights and activations stream straight into registers -- no
 // LDS staging, no barrier in the loop -- and one LDS reduction combines the four partial tiles.
+// Each wave's walk over its chunks is a chain of dependent L2 / MALL round trips with D chunks in flight, and the layer
+// takes (chunks per wave / D) round trips: layers with long K (the 32x32 / 64x64 nets: up to 400 chunks) take the
+// NW = 8, D = 8 instance -- twice the waves, twice the depth.  (Splitting K over WORKGROUPS with a last-arriver fix-up
+// was tried: the device-scope release / acquire it needs writes back and invalidates the XCD's whole L2, ~25 us per
+// launch -- single-block 64x64 call 223 -> 915 us.)
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams p)
+template <int NT, int NW, int D>
+__global__ __launch_bounds__(64 * NW) void tapgemm_splitk_kernel(const TapGemmParams p)
 {
     touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int BN = 16 * NT;
-    __shared__ f32x4 red[4][NT][64];
+    __shared__ f32x4 red[NW][NT][64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q = lane >> 4;
@@ -274,15 +280,14 @@ __global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams
     if (wave < nchunks) {                           // wave-uniform
         // This wave's chunks are wave, wave+4, ...  A ring of D register sets keeps D chunks in flight: each layer
         // of a small pass is a dependent chain of L2/MALL round trips, so depth -- not bandwidth -- sets its time.
-        constexpr int D = 4;
         f32x4 a_r[D], b_r[D][NT];
         int c_ld = wave;                            // load cursor (stays on this wave's last chunk once it gets there)
         int t = t0 + c_ld / cpt, cc = c_ld - (c_ld / cpt) * cpt;
         tap_setup(t);
         auto advance_ld = [&]() {
-            if (c_ld + 4 < nchunks) {
-                c_ld += 4;
-                cc += 4;
+            if (c_ld + NW < nchunks) {
+                c_ld += NW;
+                cc += NW;
                 if (cc >= cpt) {                    // the next chunk of this wave lies in a later tap
                     while (cc >= cpt) { cc -= cpt; ++t; }
                     tap_setup(t);
@@ -294,10 +299,10 @@ __global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams
             load_chunk(c_ld, cc, a_r[u], b_r[u]);
             advance_ld();
         }
-        for (int c = wave; c < nchunks; c += 4 * D) {
+        for (int c = wave; c < nchunks; c += NW * D) {
 #pragma unroll
             for (int u = 0; u < D; u++) {
-                if (c + 4 * u < nchunks) {          // wave-uniform
+                if (c + NW * u < nchunks) {         // wave-uniform
 #pragma unroll
                     for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -317,10 +322,11 @@ __global__ __launch_bounds__(256) void tapgemm_splitk_kernel(const TapGemmParams
     if (!mv) return;
     const int oy = pi * p.os + p.py[cls], ox = pj * p.os + p.px[cls];
     const size_t obase = (((size_t)pb * p.OH + oy) * p.OW + ox) * p.Cout;
-    for (int nt = wave; nt < NT; nt += 4) {
+    for (int nt = wave; nt < NT; nt += NW) {
         const int n = n0 + nt * 16 + (q << 2);
         if (n < p.Cout) {
             f32x4 v = (red[0][nt][lane] + red[1][nt][lane]) + (red[2][nt][lane] + red[3][nt][lane]);
+            if (NW == 8) v += (red[4][nt][lane] + red[5][nt][lane]) + (red[6][nt][lane] + red[7][nt][lane]);
             v += *reinterpret_cast<const f32x4*>(p.bias + n);
             if (p.act) {
                 v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
@@ -368,7 +374,11 @@ template <int NT>
 static hipError_t launch_sk(const TapGemmParams& p, hipStream_t s)
 {
     dim3 grid((p.M + 15) / 16, (p.Cout + 16 * NT - 1) / (16 * NT), p.ncls);
-    pnn_launch(tapgemm_splitk_kernel<NT>, grid, dim3(256), 0, s, p);
+    int chunks = 0;                                   // longest class
+    for (int k = 0; k < p.ncls; k++) chunks = std::max(chunks, (p.tap_begin[k + 1] - p.tap_begin[k]) * (p.Cin >> 4));
+    static const int force_nw = getenv("PNN_SK_WAVES") ? atoi(getenv("PNN_SK_WAVES")) : 0;
+    if (force_nw ? force_nw == 8 : chunks >= 64) pnn_launch(tapgemm_splitk_kernel<NT, 8, (NT <= 2 ? 8 : 4)>, grid, dim3(512), 0, s, p);
+    else pnn_launch(tapgemm_splitk_kernel<NT, 4, 4>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
