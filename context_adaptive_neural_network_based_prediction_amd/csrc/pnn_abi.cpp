@@ -118,6 +118,7 @@ struct pnn_ctx {
     unsigned* d_chain_cnt = nullptr;                  // [3][64] handshake counters, monotonic
     int* h_chain_err = nullptr;                       // host-visible: raised by a workgroup that gave up waiting
     unsigned chain_epoch = 0;
+    long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
@@ -613,8 +614,12 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
 // in LDS; `part` then receives the per-column-tile partial products [tiles][M][64] and *tiles_out their count (the caller
 // finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
 int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
-                long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr)
+                long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
+                const Conv1Params* first = nullptr)
 {
+    // `first` (optional): the Cin = 1 convolution that produces this layer's input Xhi.  It has NOT been launched: a
+    // convimg configuration computes it inside the kernel (no 50 MB round trip of the maps), any other configuration gets
+    // it launched here in front of the GEMM.
     TapGemmParams p = L.proto;
     if (next) {
         p.W2p = next->d_w_sp; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part;
@@ -647,6 +652,19 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
     };
     auto launch = [&](int code) {
+        if (first) {
+            if (code >= nsp && code < nsp + nci) {
+                const TileCfg t = convimg_sp_cfg(code - nsp);
+                const int g = convimg_images(p, t, one_tap);
+                if (c->opt_fuse_first && convimg_sp_can_fuse_first(p, t, g, first->s, first->k)) {
+                    TapGemmParams q = p;
+                    q.X0 = first->X; q.W0 = first->W; q.B0 = first->bias; q.s0 = first->s; q.k0 = first->k; q.pad0 = first->pad;
+                    return launch_convimg_sp(q, code - nsp, g, s);
+                }
+            }
+            const hipError_t e = launch_conv_cin1(*first, s);
+            if (e != hipSuccess) return e;
+        }
         if (code < nsp) return launch_tapgemm_sp(p, code, s);
         if (code < nsp + nci) {
             const TileCfg t = convimg_sp_cfg(code - nsp);
@@ -669,7 +687,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     if (tune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
         // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
-        const auto key = std::make_pair((const void*)((const char*)&L + (next ? 1 : 0)), M);
+        const auto key = std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M);
         auto it = c->tuned.find(key);
         if (it == c->tuned.end()) {
             hipEvent_t e0, e1;
@@ -988,12 +1006,16 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         int cur = 0;
         f.Y = nl == 0 ? F[br] : P[cur];
         f.split = (sp && nl > 0) ? 1 : 0;
-        HIPCHK(c, launch_conv_cin1(f, s));
-        c->stat_launches++;
+        const bool delegate = sp && nl > 0;           // run_gemm_sp of the next layer launches or absorbs this convolution
+        if (!delegate) {
+            HIPCHK(c, launch_conv_cin1(f, s));
+            c->stat_launches++;
+        }
         for (size_t i = 0; i < nl; i++) {
             const bool last = i + 1 == nl;
             float* dst = last ? F[br] : P[cur ^ 1];
-            if (sp) rc = run_gemm_sp(c, m->branch[br][i], P[cur], nullptr, last ? dst : nullptr, last ? nullptr : dst, nullptr, nullptr, nb, s);
+            if (sp) rc = run_gemm_sp(c, m->branch[br][i], P[cur], nullptr, last ? dst : nullptr, last ? nullptr : dst, nullptr, nullptr, nb, s, nullptr, nullptr,
+                                     nullptr, (i == 0 && delegate) ? &f : nullptr);
             else rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s);
             if (rc) return rc;
             cur ^= 1;
@@ -1137,6 +1159,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
+    if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
     if (const char* e = getenv("PNN_CHAIN")) c->opt_chain = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
@@ -1267,6 +1290,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
+    else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
     else if (!strcmp(name, "chain")) c->opt_chain = value;
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }

@@ -52,8 +52,53 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     const int PITCH = (p.Cin >> 2) + 1;
     const int nimg = (int)((long)p.M / SP - img0 < G ? (long)p.M / SP - img0 : G);   // images that exist
 
-    // ---- stage the images (contiguous in memory) and the zero pixel ------------------------------------------
-    {
+    // ---- stage the images and the zero pixel -------------------------------------------------------------------------
+    if (p.X0) {
+        // Fused first convolution of the branch: the maps are COMPUTED here from the raw f32 context (a few KB per image)
+        // instead of being written by conv_cin1_kernel and read back (50 MB each way at batch 1024 for the 16x16 net).
+        // Same arithmetic as conv_cin1_kernel (acc = bias; acc += x * w over ky, kx; LeakyReLU; split), so the two paths
+        // agree bit for bit.  Scratch for the raw tiles = the weight staging area, free until the tap loop starts.
+        float* raw = reinterpret_cast<float*>(Bs);
+        const int K0 = p.k0, S0 = p.s0, IH0 = p.IH * S0, IW0 = p.IW * S0;
+        const int PH = (p.IH - 1) * S0 + K0, PW = (p.IW - 1) * S0 + K0;
+        for (int idx = tid; idx < nimg * PH * PW; idx += 256) {
+            const int li = idx / (PH * PW), r0 = idx - li * PH * PW;
+            const int r = r0 / PW, c = r0 - r * PW;
+            const int iy = r - p.pad0, ix = c - p.pad0;
+            raw[idx] = ((unsigned)iy < (unsigned)IH0 && (unsigned)ix < (unsigned)IW0) ? p.X0[((size_t)(img0 + li) * IH0 + iy) * IW0 + ix] : 0.f;
+        }
+        __syncthreads();
+        const int CG = p.Cin >> 2;
+        const int cg = tid % CG, ppi = 256 / CG;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.B0 + 4 * cg);
+        auto conv0 = [&](auto k_tag) {                 // the k x k weights of this thread's four channels live in registers
+            constexpr int K = decltype(k_tag)::value;
+            f32x4 w[K * K];
+#pragma unroll
+            for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W0 + (size_t)t * p.Cin + 4 * cg);
+            for (int pix = tid / CG; pix < nimg * NPIN; pix += ppi) {
+                const int li = pix / NPIN, q = pix - li * NPIN;
+                const int oy = q / p.IW, ox = q - oy * p.IW;
+                const float* xr = raw + li * PH * PW + (oy * S0) * PW + ox * S0;
+                f32x4 acc = bv;
+#pragma unroll
+                for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
+                acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { hi[i] = (_Float16)acc[i]; lo[i] = (_Float16)(acc[i] - (float)hi[i]); }
+                _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (cg >> 2) * 32 + (cg & 3) * 4;
+                *reinterpret_cast<h4*>(dst) = hi;
+                *reinterpret_cast<h4*>(dst + 16) = lo;
+            }
+        };
+        if (K0 == 5) conv0(std::integral_constant<int, 5>{}); else conv0(std::integral_constant<int, 3>{});
+        for (int idx = tid; idx < PITCH; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                              // the scratch becomes the weight staging area again
+    } else {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.X) + (size_t)img0 * NPIN * (p.Cin >> 2);
         const int c4n = p.Cin >> 2;
         const int total = nimg * NPIN * c4n;
@@ -287,6 +332,14 @@ int convimg_sp_num_cfgs() { return (int)(sizeof(kCfgsCi) / sizeof(kCfgsCi[0])); 
 TileCfg convimg_sp_cfg(int idx) { return kCfgsCi[idx]; }
 
 // LDS bytes of configuration `t` staging G images of this layer (0 if it cannot run: too big / bad shape).
+bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0)
+{
+    const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
+    const size_t scratch_floats = 2 * (size_t)t.kc * 4 * bn * 4;               // the weight staging area
+    const size_t ph = (size_t)(p.IH - 1) * s0 + k0, pw = (size_t)(p.IW - 1) * s0 + k0;
+    return (k0 == 3 || k0 == 5) && p.Cin % 16 == 0 && 256 % (p.Cin / 4) == 0 && (size_t)G * ph * pw <= scratch_floats;
+}
+
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)
 {
     const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);

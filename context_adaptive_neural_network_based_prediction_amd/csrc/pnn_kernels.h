@@ -37,6 +37,10 @@ struct TapGemmParams {
     // ring kernel, fused next fully-connected layer (<= 64 outputs): its split-packed weights, their Npad, the number of
     // packed 16-deep chunks, and the partial-product buffer [column tiles][M][64] (see pnn_gemm_ring.hip)
     const float* W2p; int Npad2; int K2chunks; float* part;
+    // convimg kernel, fused FIRST convolution of a branch (Cin = 1 -> this layer's Cin channels, stride s0, kernel k0 x k0,
+    // SAME padding with pad0 before, LeakyReLU): X0 != NULL makes the kernel compute its input maps from the raw f32
+    // context X0 [images][IH * s0][IW * s0] instead of reading them from X (see pnn_convimg_sp.hip)
+    const float* X0; const float* W0; const float* B0; int s0, k0, pad0;
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
@@ -89,6 +93,7 @@ hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s); 
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
+bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0);   // the raw context tiles fit the weight staging area
 hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s);   // G images per workgroup, resident in LDS
 hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s);
 int tapgemm_num_cfgs();

@@ -78,6 +78,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * split-precision GEMM kernels on the device and keeps the fastest -- all of them give bit-identical results, so only
  * the speed depends on it; 2, default: only for launches of >= 4 GFLOP, i.e. big batches, where it costs a few tens
  * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region),
+ * "fuse_first" (1, default: a convolutional net's second layer, when it runs on the LDS-resident-image kernel, computes
+ * the branch's first (one-input-channel) convolution itself instead of reading it back from memory; 0: separate launch.
+ * Bit-identical either way),
  * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
  * calls -- run the two independent branches on two HIP streams, forked and joined by events; 2: every small conv
  * pass; 0: one stream.  Results do not depend on it),

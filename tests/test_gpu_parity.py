@@ -424,6 +424,30 @@ def test_chained_fc_kernel(pnn, oracle, precision):
     _check_pel(net.predict_pel(ctx)[idx], oracle.epilogue(oracle.fc_forward(params, w, ctx[idx]), util.MEAN))
 
 
+@pytest.mark.parametrize("w,n", [(16, 1024), (8, 2048), (32, 96)])
+def test_fused_first_convolution_bit_identical(pnn, precision, w, n):
+    """Option "fuse_first" (default on): an LDS-resident-image kernel computes its branch's first (Cin = 1) convolution itself
+    instead of reading conv_cin1_kernel's output back.  Same arithmetic in the same order, so predictions must not change
+    by a bit -- at a batch with several workgroups per CU in flight (the prototype of this fusion was not repeatable
+    there until the packed-fp32 erratum was understood), on repeated and on permuted batches."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    params = util.make_params(w, False, 91, out_gain=util.out_gain(w, False))
+    above, left = util.make_contexts(w, n, 92)
+    net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
+    net.set_option("autotune", 0)
+    net.set_option("fuse_first", 0)
+    ref = net.predict(above, left).copy()
+    net.set_option("fuse_first", 1)
+    for _ in range(5):
+        assert np.array_equal(net.predict(above, left), ref)
+    perm = np.random.RandomState(0).permutation(n)
+    assert np.array_equal(net.predict(above[perm], left[perm]), ref[perm])
+    net.set_option("autotune", 1)                                     # whichever configuration the tuner picks
+    for _ in range(3):
+        assert np.array_equal(net.predict(above, left), ref)
+
+
 def test_contexts_sharing_the_gpu_stay_repeatable(pnn):
     """Three contexts in three host threads on one GPU (two big FC passes = matrix-core kernels, one conv net = VALU-heavy
     first layers): every call must reproduce the context's first result bit for bit.  Before the library was built
