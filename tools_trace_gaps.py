@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (one gather_kernel launch to the
+"""Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (one gather launch to the
 next), the kernels in launch order with their duration and the idle gap in front of each."""
 import csv, glob, sys
 d = sys.argv[1]
@@ -8,7 +8,7 @@ for f in glob.glob(d + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("pnn::", "").replace("void ", "")[:40]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith("gather_kernel")]
+starts = [i for i, r in enumerate(rows) if r[2].startswith("gather")]
 # the timed steps are the longest run of equally long gather-to-gather segments: take the 6 segments before the last 2
 segs = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 pick = [s for s in segs if s[1] - s[0] == min(b - a for a, b in segs)][-8:-2]
