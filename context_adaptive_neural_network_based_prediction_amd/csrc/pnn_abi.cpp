@@ -838,7 +838,8 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
 {
     if (c->opt_precision != 1) return false;
     if (c->opt_canonical) return true;
-    return nb >= (m->is_fc ? 512 : 200);
+    if (m->is_fc) return nb >= 512;
+    return nb >= 200 || nb * m->width * m->width >= 51200;   // enough rows for the 128-row split tiles: 200 blocks of 16x16, 13 of 64x64
 }
 
 // The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
