@@ -88,6 +88,7 @@ struct pnn_ctx {
     DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
     // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
     // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
+    long opt_split_min_px = -1;                       // tuning aid: conv passes take the split-precision kernels from this many block pixels on (-1: built-in rule)
     long opt_branch_streams = 1;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -839,7 +840,10 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     if (c->opt_precision != 1) return false;
     if (c->opt_canonical) return true;
     if (m->is_fc) return nb >= 512;
-    return nb >= 200 || nb * m->width * m->width >= 51200;   // enough rows for the 128-row split tiles: 200 blocks of 16x16, 13 of 64x64
+    if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
+    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure): the
+    // split kernels' 128-row tiles need ~62k block pixels (16x16: 245 blocks, 32x32: 62), ~90k for the 8x8 and 64x64 nets
+    return nb * m->width * m->width >= ((m->width == 16 || m->width == 32) ? 62000 : 90000);
 }
 
 // The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
@@ -1294,6 +1298,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
     else if (!strcmp(name, "chain")) c->opt_chain = value;
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
+    else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;

@@ -81,6 +81,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * "fuse_first" (1, default: a convolutional net's second layer, when it runs on the LDS-resident-image kernel, computes
  * the branch's first (one-input-channel) convolution itself instead of reading it back from memory; 0: separate launch.
  * Bit-identical either way),
+ * "split_min_px" (-1, default: built-in rule; >= 0: with precision 1, passes through a convolutional net use the
+ * split-precision kernels from this many block pixels (blocks x w^2) on and the exact-f32 kernels below -- tuning aid),
  * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
  * calls -- run the two independent branches on two HIP streams, forked and joined by events; 2: every small conv
  * pass; 0: one stream.  Results do not depend on it),
