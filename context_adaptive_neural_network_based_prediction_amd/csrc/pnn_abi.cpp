@@ -536,10 +536,14 @@ static int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap
 // (A cost model with workgroup counts and residency was tried against the autotuner's per-configuration timings of
 // the conv-16/32 layers and picked WORSE tiles overall -- 0.58 vs 0.54 ms per conv-16 pass; the three kernel families
 // are within 10-15 % of each other on most layers, so big passes are simply autotuned, see run_gemm_sp.)
+// Mid-size passes (tens of blocks: the batching service, small pictures) do not fill the chip with the big tiles: below two
+// workgroups per CU the cost grows with the idle share, which takes the choice down to the 64-row tile where the tuner
+// ends up too (16x16 net, 100 blocks: 471 -> ~300 us per pass).
 static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 {
     int best = -1;
-    double best_cost = 1e300;
+    double best_cost = 1e300, best_fit = 1e300;
+    const long nimg = p.M / (p.SH * p.SW);
     for (int i = 0; i < convimg_sp_num_cfgs(); i++) {
         const TileCfg t = convimg_sp_cfg(i);
         const int g = convimg_images(p, t, one_tap);
@@ -548,10 +552,12 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
         const long tn = (p.Cout + bn - 1) / bn;
         const double pad = (double)rows * (tn * bn) / ((double)g * p.SH * p.SW * p.Cout);
         const double reuse = 1.0 + 0.5 / t.rt + 0.5 / t.nt;          // LDS fragment reads per MFMA
-        const double cost = pad * reuse;
-        if (cost < best_cost) { best_cost = cost; best = i; }
+        const double wgs = (double)((nimg + g - 1) / g) * tn * p.ncls;
+        const double fill = wgs >= 512.0 ? 1.0 : 512.0 / wgs;
+        const double cost = pad * reuse * fill;
+        if (cost < best_cost) { best_cost = cost; best_fit = pad * reuse; best = i; }
     }
-    return best_cost <= 1.6 ? best : -1;
+    return best_fit <= 1.6 ? best : -1;
 }
 
 // Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
@@ -559,7 +565,18 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 // cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
 static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
 {
-    if (!fused && (!one_tap || (double)M * p.Cout < 2.0e6 || p.Cin < 256)) return -1;
+    if (!fused && !one_tap) {
+        // convolution layers that leave the chip under-filled (the 32x32 / 64x64 nets at tens of blocks, maps too big for
+        // the LDS-resident-image kernel): with K >= 1600 the 64 x 128 ring tile beats the 64 x 64 register-staged tile by
+        // 10-45 % (tuner logs, M = 192 ... 4608); the caller prefers a convimg tile when one fits
+        if (k_total < 1600.0 || (double)((M + 63) / 64) * ((p.Cout + 127) / 128) * p.ncls > 512.0) return -1;
+        for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
+            const TileCfg t = tapgemm_ring_cfg(i);
+            if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 2 && t.d == 4) return i;
+        }
+        return -1;
+    }
+    if (!fused && ((double)M * p.Cout < 2.0e6 || p.Cin < 256)) return -1;
     int best = -1;
     double best_cost = 1e300;
     for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
@@ -678,7 +695,8 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
         const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
-        if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
+        if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
+        else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
     }
     // autotune: 1 = every split GEMM, 2 (default) = only launches of >= 4 GFLOP, where trying all configurations once
@@ -841,9 +859,10 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     if (c->opt_canonical) return true;
     if (m->is_fc) return nb >= 512;
     if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
-    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure): the
-    // split kernels' 128-row tiles need ~62k block pixels (16x16: 245 blocks, 32x32: 62), ~90k for the 8x8 and 64x64 nets
-    return nb * m->width * m->width >= ((m->width == 16 || m->width == 32) ? 62000 : 90000);
+    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
+    // build_tmp-style sweeps): 8x8 net ~350 blocks, 16x16 ~115, 32x32 ~38, 64x64 ~15
+    const long px = nb * m->width * m->width;
+    return px >= (m->width <= 8 ? 24000 : m->width == 16 ? 30000 : m->width == 32 ? 40000 : 62000);
 }
 
 // The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
