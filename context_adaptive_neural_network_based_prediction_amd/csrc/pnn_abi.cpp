@@ -857,8 +857,8 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
 {
     if (c->opt_precision != 1) return false;
     if (c->opt_canonical) return true;
-    if (m->is_fc) return nb >= 512;
     if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
+    if (m->is_fc) return nb >= 512;
     // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
     // build_tmp-style sweeps): 8x8 net ~350 blocks, 16x16 ~115, 32x32 ~38, 64x64 ~15
     const long px = nb * m->width * m->width;
