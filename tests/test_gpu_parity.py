@@ -53,7 +53,10 @@ def test_fc_matches_oracle(pnn, oracle, w, n):
         assert want.min() + util.MEAN < 0 and want.max() + util.MEAN > 255, "test must exercise both clamps"
 
 
-@pytest.mark.parametrize("w,n", [(4, 1), (4, 130), (8, 1), (8, 77), (16, 1), (16, 40), (32, 5), (64, 2)])
+# (8, 400), (16, 130), (32, 48), (64, 16): mid-size passes just above the f32 / split-precision crossover, where the
+# rule-based tile choice (small LDS-resident-image tile, 64x128 ring tile) differs from the big-batch one
+@pytest.mark.parametrize("w,n", [(4, 1), (4, 130), (8, 1), (8, 77), (16, 1), (16, 40), (32, 5), (64, 2),
+                                 (8, 400), (16, 130), (32, 48), (64, 16)])
 def test_conv_matches_oracle(pnn, oracle, w, n):
     params = util.make_params(w, False, seed=20 + w, out_gain=util.out_gain(w, False))
     above, left = util.make_contexts(w, n, seed=w * 1000 + n + 1)
