@@ -13,7 +13,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void probe(unsigned* err, int rounds, unsigned seed)
 {
-    unsigned bad_a = 0, bad_b = 0;
+    unsigned bad_a = 0, bad_b = 0, bad_c = 0, bad_d = 0;
     unsigned s = seed + blockIdx.x * 977u + threadIdx.x * 131u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)(s >> 9) % 2001 - 1000) * 1e-3f; };
     for (int r = 0; r < rounds; r++) {
@@ -28,9 +28,19 @@ __global__ __launch_bounds__(256) void probe(unsigned* err, int rounds, unsigned
         const float eb0 = __builtin_fmaf(w[0], x[0], c[0]), eb1 = __builtin_fmaf(w[1], x[0], c[1]);
         bad_a += (xa[0] != ea0) + (xa[1] != ea1);
         bad_b += (xb[0] != eb0) + (xb[1] != eb1);
+        // the 64-bit integer VALU forms that remain in the library's code (address arithmetic), destination == source
+        unsigned long long q = ((unsigned long long)s << 32) | (s * 2654435761u), q0 = q, add = ((unsigned long long)(s >> 7) << 29) | 0xfffffff0u;
+        asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(q) : "v"(add));
+        bad_c += q != ((q0 << 3) + add);
+        unsigned long long m = q0;
+        const unsigned ma = s | 0x80000001u, mb = (s >> 3) | 0x40000000u;
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(m) : "v"(ma), "v"(mb) : "vcc");
+        bad_d += m != (unsigned long long)ma * mb + q0;
     }
     if (bad_a) atomicAdd(err, bad_a);
     if (bad_b) atomicAdd(err + 1, bad_b);
+    if (bad_c) atomicAdd(err + 2, bad_c);
+    if (bad_d) atomicAdd(err + 3, bad_d);
 }
 
 __global__ __launch_bounds__(256) void mfma_partner(float* out, int iters)
@@ -50,7 +60,7 @@ int main(int argc, char** argv)
 {
     const int partners = argc > 1 ? atoi(argv[1]) : 2, reps = argc > 2 ? atoi(argv[2]) : 500;
     unsigned* derr; float* dp;
-    hipMalloc(&derr, 8); hipMemset(derr, 0, 8); hipMalloc(&dp, 64);
+    hipMalloc(&derr, 16); hipMemset(derr, 0, 16); hipMalloc(&dp, 64);
     std::atomic<bool> stop{false};
     std::vector<std::thread> ts;
     for (int t = 0; t < partners; t++)
@@ -69,7 +79,8 @@ int main(int argc, char** argv)
     hipStreamSynchronize(sv);
     stop = true;
     for (auto& t : ts) t.join();
-    unsigned h[2]; hipMemcpy(h, derr, 8, hipMemcpyDeviceToHost);
-    printf("beside %d MFMA partner thread(s), %d launches x 2048 x 256 threads x 2000 rounds: form A (op_sel hi) %u wrong, form B (op_sel lo) %u wrong\n", partners, reps, h[0], h[1]);
+    unsigned h[4]; hipMemcpy(h, derr, 16, hipMemcpyDeviceToHost);
+    printf("beside %d MFMA partner thread(s), %d launches x 2048 x 256 threads x 2000 rounds: v_pk_fma_f32 in place, form A (op_sel hi) %u wrong, form B (op_sel lo) %u wrong; "
+           "v_lshl_add_u64 in place %u wrong, v_mad_u64_u32 in place %u wrong\n", partners, reps, h[0], h[1], h[2], h[3]);
     return 0;
 }

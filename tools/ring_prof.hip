@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 using namespace pnn;
+namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
 
 int main(int argc, char** argv)
 {
