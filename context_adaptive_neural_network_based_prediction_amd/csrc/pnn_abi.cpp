@@ -569,7 +569,7 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
         // convolution layers that leave the chip under-filled (the 32x32 / 64x64 nets at tens of blocks, maps too big for
         // the LDS-resident-image kernel): with K >= 1600 the 64 x 128 ring tile beats the 64 x 64 register-staged tile by
         // 10-45 % (tuner logs, M = 192 ... 4608); the caller prefers a convimg tile when one fits
-        if (k_total < 1600.0 || (double)((M + 63) / 64) * ((p.Cout + 127) / 128) * p.ncls > 512.0) return -1;
+        if (k_total < 1600.0 || (double)((M + 63) / 64) * ((p.Cout + 127) / 128) * p.ncls > 256.0) return -1;
         for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
             const TileCfg t = tapgemm_ring_cfg(i);
             if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 2 && t.d == 4) return i;
