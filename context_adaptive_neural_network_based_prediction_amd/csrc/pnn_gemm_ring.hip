@@ -41,6 +41,17 @@ __device__ __forceinline__ void glds16(const void* g, f32x4* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The same through a buffer descriptor: 32-bit per-lane offset (half the address traffic of a 64-bit flat address), and an
+// offset past the descriptor's size delivers zeros -- padding rows, out-of-image taps and the K tail need no zero page.
+__device__ __forceinline__ void blds16(const __amdgpu_buffer_rsrc_t& r, unsigned off, f32x4* l)
+{
+#ifdef PNN_RING_NO_LOAD
+    asm volatile("" ::"v"(off), "s"(l));
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, off, 0, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
@@ -156,27 +167,30 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 lj[r] = (int)(q - (unsigned)li[r] * (unsigned)p.SW);
             }
         }
-        const char* asrc[NLA];                          // source of this lane's piece for chunk 0 of the issue-side tap (or the zero page)
-        bool aok[NLA];
+        // byte offset of this lane's piece for chunk 0 of the issue-side tap in the activation buffer; bit 31 set = no source
+        // (row past M, tap outside the image): beyond the descriptor's size, the DMA writes zeros
+        unsigned aoff[NLA];
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffffu, 0x00020000);
         auto tap_setup = [&](int tp) {
             const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
 #pragma unroll
             for (int r = 0; r < NLA; r++) {
                 const int iy = li[r] * p.a + dy, ix = lj[r] * p.a + dx;
-                aok[r] = lv[r] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-                const size_t pix = ((size_t)lb[r] * p.IH + iy) * p.IW + ix;
-                asrc[r] = aok[r] ? Xb + pix * ((size_t)p.Cin << 2) + (lpiece[r] << 4) : Zb + (lpiece[r] << 4);
+                const bool ok = lv[r] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                const unsigned pix = (unsigned)((lb[r] * p.IH + iy) * p.IW + ix);
+                aoff[r] = ok ? ((pix * (unsigned)p.Cin) << 2) + (unsigned)(lpiece[r] << 4) : 0x80000000u;
             }
         };
-        const f32x4* bsrc[NLB];
+        unsigned boff[NLB];
 #pragma unroll
         for (int r = 0; r < NLB; r++) {
             const int L = 64 * (wave + 4 * r) + lane;
             const int j = L / E, e = L - j * E;
             const int qq = e / BN, nn = e - qq * BN;
-            bsrc[r] = Wg + (size_t)(j * 4 + qq) * p.Npad + n0 + nn;
+            boff[r] = (unsigned)(((j * 4 + qq) * p.Npad + n0 + nn) << 4);
         }
-        const size_t bstride = (size_t)KC * 4 * p.Npad;   // pieces per stage in the packed weights
+        const unsigned bstride = (unsigned)(KC * 4 * p.Npad) << 4;   // bytes per stage in the packed weights
         int it = t0, icc = 0, istage = 0;               // issue-side position
         int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
         tap_setup(p.tap[t0]);
@@ -186,12 +200,11 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
             for (int r = 0; r < NLA; r++) {
                 // a one-tap layer's last stage may run past K (the weights there are zero padding): take zeros, not the next row
                 const bool past = icc + (lpiece[r] >> 2) >= cpt;
-                const char* src = (aok[r] && !past) ? asrc[r] + ((size_t)icc << 6) : Zb + (lpiece[r] << 4);
-                glds16(src, dst + 64 * (wave + 4 * r));
+                blds16(xrsrc, (aoff[r] | (past ? 0x80000000u : 0u)) + ((unsigned)icc << 6), dst + 64 * (wave + 4 * r));
             }
 #pragma unroll
             for (int r = 0; r < NLB; r++)
-                if (wave + 4 * r < NBI) glds16(bsrc[r] + (size_t)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));   // wave-uniform
+                if (wave + 4 * r < NBI) blds16(wrsrc, boff[r] + (unsigned)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));   // wave-uniform
             ++istage;
             icc += KC;
             if (icc >= cpt && it + 1 < t1) {             // wave-uniform

@@ -46,7 +46,7 @@ int main(int argc, char** argv)
     hipMemset(dz, 0, 4096); hipMemset(db, 0, Npad * 4); hipMemset(derr, 0, 4);
     TapGemmParams p{};
     p.X = (const float*)dx; p.zero = dz; p.Wp = (const float*)dw; p.bias = db; p.Yhi = dy; p.out_scale = 1.f;
-    p.M = M; p.SH = p.SW = 1; p.IH = p.IW = 1; p.Cin = K; p.a = 1; p.OH = p.OW = 1; p.Cout = N; p.os = 1; p.Npad = Npad; p.act = 1;
+    p.M = M; p.SH = p.SW = 1; p.IH = p.IW = 1; p.Cin = K; p.a = 1; p.OH = p.OW = 1; p.Cout = N; p.os = 1; p.Npad = Npad; p.act = 1; p.x_bytes = (unsigned)xb;
     p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.chunk_begin[0] = 0; p.tap[0] = 0;
     hipStream_t sa, sb;
     hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
