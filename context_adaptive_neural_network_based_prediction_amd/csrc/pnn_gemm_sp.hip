@@ -107,22 +107,23 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
 #pragma unroll
         for (int r = 0; r < NLA; r++) As[buf][((tid + 256 * r) / PPR) * APITCH + lpiece] = src[r];
     };
-    const f32x4* bsrc[NLD];
+    unsigned bsrc[NLD];                              // byte offsets into the packed weights (buffer loads: a 32-bit offset per lane
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffffu, 0x00020000);   // issues faster than a 64-bit flat address, see pnn_gemm_ring.hip)
     int bdst[NLD];
 #pragma unroll
     for (int r = 0; r < NLD; r++) {
         int e = tid + 256 * r;
         if (E % 256 != 0) e = e < E ? e : E - 1;
         const int qq = e / BN, nn = e - qq * BN;
-        bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+        bsrc[r] = (unsigned)((qq * p.Npad + n0 + nn) << 4);
         bdst[r] = e;
     }
-    const size_t bstride = (size_t)4 * p.Npad;
+    const unsigned bstride = (unsigned)(4 * p.Npad) << 4;   // bytes per packed chunk
     auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
 #pragma unroll
         for (int j = 0; j < KC; j++)
 #pragma unroll
-            for (int r = 0; r < NLD; r++) dst[j][r] = bsrc[r][(size_t)(stage * KC + j) * bstride];
+            for (int r = 0; r < NLD; r++) dst[j][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, bsrc[r] + (unsigned)(stage * KC + j) * bstride, 0, 0));
     };
     auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
 #pragma unroll

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
                 dst[j][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt], cj << 6, 0));
         }
     };
-    const f32x4* bsrc[NLD];                         // this thread's slots of a staged weight chunk
+    unsigned bsrc[NLD];                              // byte offsets into the packed weights (buffer loads: a 32-bit offset per lane
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffffu, 0x00020000);   // issues faster than a 64-bit flat address, see pnn_gemm_ring.hip)
     int bdst[NLD];
 #pragma unroll
     for (int r = 0; r < NLD; r++) {
@@ -107,15 +108,15 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p)
         int e = tid + 256 * r;
         if (E % 256 != 0) e = e < E ? e : E - 1;
         const int qq = e / BN, nn = e - qq * BN;
-        bsrc[r] = Wg + (size_t)qq * p.Npad + n0 + nn;
+        bsrc[r] = (unsigned)((qq * p.Npad + n0 + nn) << 4);
         bdst[r] = e;
     }
-    const size_t bstride = (size_t)4 * p.Npad;      // float4 per 16-deep chunk
+    const unsigned bstride = (unsigned)(4 * p.Npad) << 4;   // bytes per packed chunk      // float4 per 16-deep chunk
     auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
 #pragma unroll
         for (int j = 0; j < KC; j++)
 #pragma unroll
-            for (int r = 0; r < NLD; r++) dst[j][r] = bsrc[r][(size_t)(stage * KC + j) * bstride];
+            for (int r = 0; r < NLD; r++) dst[j][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, bsrc[r] + (unsigned)(stage * KC + j) * bstride, 0, 0));
     };
     auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
 #pragma unroll
@@ -253,9 +254,12 @@ __global__ __launch_bounds__(64 * NW) void tapgemm_splitk_kernel(const TapGemmPa
     const int cpt = p.Cin >> 4;
     const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
     const int nchunks = (t1 - t0) * cpt;
-    const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad
-                                   + (size_t)q * p.Npad + n0 + l15;
-    const size_t bstride = (size_t)4 * p.Npad;
+    // weights through a buffer descriptor: uniform base + 32-bit lane offset (a 64-bit flat address per lane costs the wave
+    // about twice the issue time, measured on the ring kernel's loaders)
+    const __amdgpu_buffer_rsrc_t wrsrc_sk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad), 0, 0xffffffffu, 0x00020000);
+    const unsigned woff = (unsigned)((q * p.Npad + n0 + l15) << 4);
+    const unsigned bstride = (unsigned)(4 * p.Npad) << 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
 
     f32x4 acc[NT];
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(64 * NW) void tapgemm_splitk_kernel(const TapGemmPa
     auto load_chunk = [&](int chunk, int cc, f32x4& a, f32x4 (&b)[NT]) {
         a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff, cc << 6, 0));
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) b[nt] = Wg[(size_t)chunk * bstride + nt * 16];
+        for (int nt = 0; nt < NT; nt++)
+            b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc_sk, woff + (unsigned)chunk * bstride + (unsigned)(nt << 8), 0, 0));
     };
 
     if (wave < nchunks) {                           // wave-uniform
