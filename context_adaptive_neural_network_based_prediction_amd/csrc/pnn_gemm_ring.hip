@@ -122,6 +122,9 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     constexpr int W2OFF = BM * OPP, W2CH = BN / 16, W2PCS = W2CH * 4 * 64;
     static_assert(!FUSE || (WM == 4 && (size_t)W2OFF + W2PCS <= (size_t)D * SS && W2PCS % 256 == 0), "fused layer needs WM = 4 and room behind the tile");
     const bool fuse = FUSE && p.W2p != nullptr;      // FUSE instantiations also run plain layers (fc_chain_kernel)
+    // (Handing the tile to the loader waves one 32-column block at a time, so that the copy-out runs under the conversion,
+    // was built and measured: epilogue 8.8k -> 7.9k cycles in tools/ring_prof.hip, but FC-8 and conv-16 passes 1 % SLOWER
+    // -- five more workgroup-wide barriers and a third copy of the unrolled group loop in the instruction cache.)
     auto copy_out = [&]() {
         if (!p.Yhi) return;
         const int cpy = p.py[cls], cpx = p.px[cls];
