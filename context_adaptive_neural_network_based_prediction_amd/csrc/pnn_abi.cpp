@@ -588,8 +588,10 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
         const int resident = tapgemm_ring_lds_bytes(t) > (size_t)80 * 1024 ? 1 : 2;
         const double stages = std::ceil((k_total / 16.0 / p.ncls) / (double)t.kc);
         const double mfma = 96.0 * t.rt * t.nt * t.kc;
-        const double slow = t.kc == 1 ? 2.0 : (resident == 2 ? 1.25 : (t.d >= 4 ? 1.45 : 2.1));   // 16-deep stages fetch half lines: measured 2x
-        const double wg = 9000.0 + 55.0 * t.rt * t.nt * 4 + stages * mfma * slow;
+        // stage time / MFMA time and the fixed part, from tools/ring_prof.hip with the buffer-descriptor loaders (FC 1200x1200,
+        // M = 4096): D >= 4 rings 1.14-1.19, three-deep rings 1.5-1.9, 16-deep stages 1.3; start-up + epilogue 7-13k cycles
+        const double slow = t.kc == 1 ? 1.35 : (resident == 2 ? 1.25 : (t.d >= 4 ? 1.17 : 1.6));
+        const double wg = 5000.0 + 1400.0 * t.rt * t.nt + stages * mfma * slow;
         const double rounds = std::ceil(nwg / (256.0 * resident));
         const double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);   // two co-resident workgroups share the CU's MFMA pipes
         if (cost < best_cost) { best_cost = cost; best = i; }
