@@ -566,13 +566,23 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
 {
     if (!fused && !one_tap) {
-        // convolution layers that leave the chip under-filled (the 32x32 / 64x64 nets at tens of blocks, maps too big for
-        // the LDS-resident-image kernel): with K >= 1600 the 64 x 128 ring tile beats the 64 x 64 register-staged tile by
-        // 10-45 % (tuner logs, M = 192 ... 4608); the caller prefers a convimg tile when one fits
-        if (k_total < 1600.0 || (double)((M + 63) / 64) * ((p.Cout + 127) / 128) * p.ncls > 256.0) return -1;
+        // Convolution layers.  With the buffer-descriptor loaders the ring kernel is the fastest of the three families on
+        // every layer with >= 128 output channels (tuner logs of the 16x16 / 32x32 nets at 300 ... 1024 blocks: 15-30 % ahead
+        // of the register-staged and the LDS-resident-image kernels); the 64-output-channel 3x3 layers stay with the
+        // LDS-resident-image kernel.  Tile: 128 columns, the tallest of 192 / 128 / 64 rows that still gives >= 192
+        // workgroups (one round of the chip), else 64 rows.  Under-filled long-K layers of any width take the 64-row tile.
+        const bool wide = p.Cout % 128 == 0 && k_total / p.ncls >= 1152.0;
+        const double col_tiles = (double)((p.Cout + 127) / 128) * p.ncls;
+        const bool underfilled = k_total >= 1600.0 && (double)((M + 63) / 64) * col_tiles <= 256.0;
+        if (!wide && !underfilled) return -1;
+        int rt = 1, wm = 2, d = 4;                    // 64 x 128
+        if (wide) {
+            if ((double)((M + 191) / 192) * col_tiles >= 192.0) { rt = 3; d = 3; }        // 192 x 128
+            else if ((double)((M + 127) / 128) * col_tiles >= 192.0) rt = 2;              // 128 x 128
+        }
         for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
             const TileCfg t = tapgemm_ring_cfg(i);
-            if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 2 && t.d == 4) return i;
+            if (t.rt == rt && t.nt == 2 && t.kc == 2 && t.wm == wm && t.d == d) return i;
         }
         return -1;
     }
@@ -697,7 +707,9 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
         const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
-        if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
+        const bool ring_conv = !one_tap && ri >= 0 && p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0;   // see choose_cfg_ring
+        if (ring_conv && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
+        else if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
         else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
     }
@@ -862,9 +874,9 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
     if (m->is_fc) return nb >= 512;
     // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
-    // build_tmp-style sweeps): 8x8 net ~350 blocks, 16x16 ~115, 32x32 ~38, 64x64 ~15
+    // sweeps of both paths around the crossover): 8x8 net ~280 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
     const long px = nb * m->width * m->width;
-    return px >= (m->width <= 8 ? 24000 : m->width == 16 ? 30000 : m->width == 32 ? 40000 : 62000);
+    return px >= (m->width <= 16 ? 18000 : m->width == 32 ? 35000 : 70000);
 }
 
 // The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
