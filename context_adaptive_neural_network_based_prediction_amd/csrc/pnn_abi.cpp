@@ -551,11 +551,14 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
         const long rows = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
         const long tn = (p.Cout + bn - 1) / bn;
         const double pad = (double)rows * (tn * bn) / ((double)g * p.SH * p.SW * p.Cout);
-        const double reuse = 1.0 + 0.5 / t.rt + 0.5 / t.nt;          // LDS fragment reads per MFMA
+        // tile height: 128 rows is the sweet spot (tuner logs of the 8x8 / 16x16 nets, K = 576, 64 output channels): taller
+        // tiles stage more images per workgroup -- more LDS, fewer co-resident workgroups, a longer serial staging phase
+        // (384 rows: 81 us where 128 rows take 49) --, the 64-row tile pays more start-up per MFMA
+        const double height = rows <= 64 ? 1.15 : rows <= 128 ? 1.0 : rows <= 192 ? 1.05 : rows <= 256 ? 1.25 : rows <= 384 ? 1.6 : 2.0;
         const double wgs = (double)((nimg + g - 1) / g) * tn * p.ncls;
         const double fill = wgs >= 512.0 ? 1.0 : 512.0 / wgs;
-        const double cost = pad * reuse * fill;
-        if (cost < best_cost) { best_cost = cost; best_fit = pad * reuse; best = i; }
+        const double cost = pad * height * fill;
+        if (cost < best_cost) { best_cost = cost; best_fit = pad * height; best = i; }
     }
     return best_fit <= 1.6 ? best : -1;
 }
@@ -874,9 +877,9 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
     if (m->is_fc) return nb >= 512;
     // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
-    // sweeps of both paths around the crossover): 8x8 net ~280 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
+    // sweeps of both paths around the crossover): 8x8 net ~150 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
     const long px = nb * m->width * m->width;
-    return px >= (m->width <= 16 ? 18000 : m->width == 32 ? 35000 : 70000);
+    return px >= (m->width <= 8 ? 10000 : m->width == 16 ? 18000 : m->width == 32 ? 35000 : 70000);
 }
 
 // The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
