@@ -427,6 +427,33 @@ def test_chained_fc_kernel(pnn, oracle, precision):
     _check_pel(net.predict_pel(ctx)[idx], oracle.epilogue(oracle.fc_forward(params, w, ctx[idx]), util.MEAN))
 
 
+def _random_size_cases():
+    rng = np.random.RandomState(7)
+    cases = []
+    for w, fc, hi in ((4, True, 1500), (8, True, 1500), (4, False, 900), (8, False, 700), (16, False, 260), (32, False, 70), (64, False, 22)):
+        cases += [(w, fc, int(rng.randint(1, hi + 1))) for _ in range(2)]
+    # one block either side of the rule that switches between the exact-f32 and the split-precision kernels
+    cases += [(8, False, 156), (8, False, 157), (16, False, 70), (16, False, 71), (32, False, 34), (32, False, 35),
+              (64, False, 17), (64, False, 18), (8, True, 511), (8, True, 513)]
+    return cases
+
+
+@pytest.mark.parametrize("w,is_fc,n", _random_size_cases())
+def test_random_batch_sizes_match_oracle(pnn, oracle, w, is_fc, n):
+    """Random (ragged) batch sizes for every net, and the sizes around the kernel-family switch: whatever tile rule a
+    size lands on, float predictions stay within FLOAT_ATOL of the oracle and the HM epilogue within one LSB."""
+    params = util.make_params(w, is_fc, 100 + w + n, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 200 + n)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    if is_fc:
+        x = util.flatten_fc(above, left)
+        got, want, pel = net.predict(x), oracle.fc_forward(params, w, x), net.predict_pel(x)
+    else:
+        got, want, pel = net.predict(above, left), oracle.conv_forward(params, w, above, left), net.predict_pel(above, left)
+    np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=FLOAT_ATOL)
+    _check_pel(pel, oracle.epilogue(want, util.MEAN))
+
+
 @pytest.mark.parametrize("w,n", [(16, 1024), (8, 2048), (32, 96)])
 def test_fused_first_convolution_bit_identical(pnn, precision, w, n):
     """Option "fuse_first" (default on): an LDS-resident-image kernel computes its branch's first (Cin = 1) convolution itself
