@@ -92,6 +92,11 @@ float pnn_mean(const pnn_ctx* ctx);
  * pair needs; 0 (default) lets small batches use the faster split-K kernel, whose float result can differ in
  * the last bits, i.e. by one LSB on an exact .5 tie). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
+/* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
+ * PNN_CONVIMG, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_CHAIN, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
+ * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
+ * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
 int pnn_num_split_configs(void);
 /* Hits / misses of the "cache_mb" prediction cache since the option was last set. */
