@@ -23,6 +23,11 @@
 // writes and the fragment reads share the LDS), i.e. 28 B/clk of the CU's 64 B/clk vector-memory path; the MFMA waves
 // finish their 960 MFMA cycles in ~1070 and wait ~300-400 at the stage barrier.  Deeper rings do not help (D = 5 / 6
 // measured equal to D = 4 on the tiles where they fit): it is issue throughput, not latency.
+//
+// Later findings: most of that issue cost was the 64-bit flat address per lane -- the loaders now go
+// through buffer descriptors (blds16 below) and issue a stage in ~640 cycles; the 128x160 stage takes 1097 cycles.  With
+// that, EIGHT loader waves on the small tiles (64x128, 128x64: few registers, three waves per SIMD fit) gain only 2-6 %
+// (stage 653 -> 639, 725 -> 677 cycles for 384 of MFMA work): the CU takes ~38 B/clk of LDS-DMA however many waves ask.
 #include "pnn_kernels.h"
 #include <type_traits>
 #include "pnn_device_common.h"
