@@ -65,6 +65,17 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
     assert n_objects >= 5 and n_mfma > 1000           # really looked at the kernels
 
 
+def test_every_option_is_documented_in_the_header():
+    """pnn_set_option's names (csrc/pnn_abi.cpp) and the option list in include/pnn_hip.h must not drift apart."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "context_adaptive_neural_network_based_prediction_amd", "csrc", "pnn_abi.cpp")).read()
+    hdr = open(os.path.join(root, "include", "pnn_hip.h")).read()
+    names = sorted(set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', src)))
+    assert len(names) >= 14, names
+    missing = [n for n in names if '"%s"' % n not in hdr]
+    assert not missing, "options without documentation in pnn_hip.h: %s" % missing
+
+
 def test_service_header_symbols_exported():
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pnn_service.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(pnn_(?:service|client)_[a-z0-9_]+)\s*\(", header))
