@@ -22,7 +22,7 @@ class TbDev(ctypes.Structure):
                 ("left_units", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-BACKEND = ctypes.CFUNCTYPE(ci, vp, ci, f32p, f32p, ci, i32p)   # pnn_service_backend of include/pnn_service.h
+BACKEND = ctypes.CFUNCTYPE(ci, vp, ci, f32p, f32p, ci, i32p, f32p)   # pnn_service_backend of include/pnn_service.h
 
 # include/pnn_service.h (cross-process batching service); same conventions
 SERVICE_SIGNATURES = {
@@ -30,6 +30,7 @@ SERVICE_SIGNATURES = {
     "pnn_service_run": (ci, [ctypes.c_char_p, vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
     "pnn_client_connect": (ci, [ctypes.POINTER(vp), ctypes.c_char_p]),
     "pnn_client_predict_pel": (ci, [vp, ci, f32p, f32p, i32p, ci]),
+    "pnn_client_predict_f32": (ci, [vp, ci, f32p, f32p, f32p]),
     "pnn_client_close": (None, [vp]),
 }
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),
     "pnn_predict_conv": (ci, [vp, ci, f32p, f32p, ci, f32p]),
     "pnn_predict_pel": (ci, [vp, ci, f32p, f32p, ci, i32p, ci]),
+    "pnn_predict_f32_pel": (ci, [vp, ci, f32p, f32p, ci, f32p, i32p]),
     "pnn_extract_context": (ci, [i32p, f32p, f32p, u8p] + [ci] * 8 + [ctypes.c_float]),
     "pnn_parse_model_table": (ci, [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                    ctypes.POINTER(ctypes.c_char_p), ci]),

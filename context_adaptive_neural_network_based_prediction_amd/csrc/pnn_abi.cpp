@@ -1203,6 +1203,8 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
     if (const char* e = getenv("PNN_CHAIN")) c->opt_chain = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
+    if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
+    if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -1638,6 +1640,15 @@ int pnn_predict_pel(pnn_ctx* c, int width, const float* above, const float* left
     if (!dst || dst_stride < width) return fail(c, PNN_E_ARG, "bad destination");
     if (n > 1 && dst_stride != width) return fail(c, PNN_E_ARG, "strided destination needs n == 1");
     return host_predict(c, m, above, left, n, nullptr, dst, dst_stride);
+}
+
+int pnn_predict_f32_pel(pnn_ctx* c, int width, const float* above, const float* left, int n, float* out, int32_t* dst)
+{
+    int rc;
+    Model* m = model_for(c, width, -1, &rc);
+    if (!m) return rc;
+    if (!out && !dst) return fail(c, PNN_E_ARG, "`out` and `dst` are both NULL");
+    return host_predict(c, m, above, left, n, out, dst, width);
 }
 
 int pnn_parse_model_table(const char* path, int* widths, int* is_pair, int* channels, const char** paths, int max_entries)

@@ -1,12 +1,19 @@
 // Cross-process batching service (include/pnn_service.h): Unix-domain socket server that coalesces the single-block
 // PNN requests of many encoder processes into batched calls, and the matching client stub.  Plain POSIX, no HIP here.
+//
+// The server is one thread and never blocks on a client: sockets are non-blocking, every client has its own receive and
+// send buffer, a request is queued for the GPU only once its last byte has arrived, and a client whose reply cannot be
+// written for kStallMs (it stopped reading) or that sends a malformed header is dropped without disturbing the others.
+// The batching window is timed with ppoll (microsecond resolution).
 #include "pnn_service.h"
 
 #include <errno.h>
+#include <fcntl.h>
 #include <poll.h>
 #include <string.h>
 #include <sys/socket.h>
 #include <sys/un.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -16,11 +23,15 @@
 
 namespace {
 
-constexpr uint32_t kMagic = 0x314e4e50u;   // "PNN1"
-struct ReqHeader { uint32_t magic; int32_t width; uint32_t n_above, n_left; };   // followed by the floats
-struct RspHeader { int32_t rc; uint32_t n_pel; };                                // followed by n_pel int32
+constexpr uint32_t kMagic = 0x324e4e50u;   // "PNN2"
+constexpr uint32_t kWantF32 = 1u;          // flags bit 0: reply with the float prediction (frozen-graph output) instead of Pel
+constexpr long kStallMs = 5000;            // a reply that cannot be delivered for this long drops its client
+struct ReqHeader { uint32_t magic; int32_t width; uint32_t n_above, n_left, flags; };   // followed by the floats
+struct RspHeader { int32_t rc; uint32_t n_vals; };                                       // followed by n_vals int32 / float
 
-bool read_all(int fd, void* buf, size_t n)
+using Clock = std::chrono::steady_clock;
+
+bool read_all(int fd, void* buf, size_t n)      // client side only (blocking socket)
 {
     char* p = static_cast<char*>(buf);
     while (n) {
@@ -32,7 +43,7 @@ bool read_all(int fd, void* buf, size_t n)
     return true;
 }
 
-bool write_all(int fd, const void* buf, size_t n)
+bool write_all(int fd, const void* buf, size_t n)   // client side only
 {
     const char* p = static_cast<const char*>(buf);
     while (n) {
@@ -45,7 +56,23 @@ bool write_all(int fd, const void* buf, size_t n)
 
 bool valid_width(int w) { return w == 4 || w == 8 || w == 16 || w == 32 || w == 64; }
 
-struct Pending { int fd; std::vector<float> above, left; };
+bool valid_header(const ReqHeader& h)
+{
+    if (h.magic != kMagic || !valid_width(h.width) || (h.flags & ~kWantF32)) return false;
+    const uint32_t w2 = (uint32_t)(h.width * h.width);
+    return (h.n_above == 5 * w2 && h.n_left == 0) || (h.n_above == 3 * w2 && h.n_left == 2 * w2);
+}
+
+struct Client {
+    int fd = -1;
+    std::vector<char> rx;            // bytes of the request being received
+    std::vector<char> tx;            // reply bytes not yet accepted by the socket
+    size_t tx_off = 0;
+    Clock::time_point tx_since;      // when tx became non-empty
+    bool in_flight = false;          // a complete request of this client is queued or being computed
+};
+
+struct Pending { int fd; bool want_f32; std::vector<float> above, left; };
 
 int make_addr(const char* path, sockaddr_un* a)
 {
@@ -56,14 +83,20 @@ int make_addr(const char* path, sockaddr_un* a)
     return PNN_OK;
 }
 
-int ctx_backend(void* user, int width, const float* above, const float* left, int n, int32_t* dst)
+void set_nonblocking(int fd)
 {
-    return pnn_predict_pel(static_cast<pnn_ctx*>(user), width, above, left, n, dst, width);
+    const int fl = fcntl(fd, F_GETFL, 0);
+    if (fl >= 0) fcntl(fd, F_SETFL, fl | O_NONBLOCK);
+}
+
+int ctx_backend(void* user, int width, const float* above, const float* left, int n, int32_t* dst, float* out_f32)
+{
+    return pnn_predict_f32_pel(static_cast<pnn_ctx*>(user), width, above, left, n, out_f32, dst);
 }
 
 }  // namespace
 
-struct pnn_client { int fd; std::vector<int32_t> pel; };
+struct pnn_client { int fd; std::vector<char> buf; };
 
 extern "C" {
 
@@ -77,72 +110,127 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     if (lfd < 0) return PNN_E_IO;
     unlink(socket_path);
     if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 256) < 0) { close(lfd); return PNN_E_IO; }
-    std::vector<int> clients;
-    long served = 0, calls = 0, largest = 0, accepted = 0;
-    // pending requests per (width, has_left): a batch shares one model
+    set_nonblocking(lfd);
+    std::map<int, Client> clients;
+    long served = 0, calls = 0, largest = 0, accepted = 0, dropped = 0;
+    // complete requests per (width, has_left): a batch shares one model
     std::map<std::pair<int, int>, std::vector<Pending>> pending;
     size_t n_pending = 0;
+
     auto drop = [&](int fd) {
+        for (auto& kv : pending) {
+            auto& v = kv.second;
+            const size_t before = v.size();
+            v.erase(std::remove_if(v.begin(), v.end(), [fd](const Pending& p) { return p.fd == fd; }), v.end());
+            n_pending -= before - v.size();
+        }
         close(fd);
-        clients.erase(std::remove(clients.begin(), clients.end(), fd), clients.end());
+        clients.erase(fd);
+        ++dropped;
     };
-    auto take = [&](int fd) {                        // one request from a readable client; false = client gone / bad request
-        ReqHeader h;
-        if (!read_all(fd, &h, sizeof h)) return false;
-        const long w2 = (long)h.width * h.width;
-        if (h.magic != kMagic || !valid_width(h.width) || !((h.n_above == 5 * w2 && h.n_left == 0) || (h.n_above == 3 * w2 && h.n_left == 2 * w2)))
-            return false;
-        Pending p;
-        p.fd = fd;
-        p.above.resize(h.n_above);
-        p.left.resize(h.n_left);
-        if (!read_all(fd, p.above.data(), h.n_above * 4) || (h.n_left && !read_all(fd, p.left.data(), h.n_left * 4))) return false;
-        pending[{h.width, h.n_left ? 1 : 0}].push_back(std::move(p));
-        ++n_pending;
+    // Moves whatever the socket holds into the client's buffer; queues the request when it is complete.
+    // false = client gone or protocol violation.
+    auto receive = [&](Client& c) {
+        for (;;) {
+            size_t want = sizeof(ReqHeader);
+            if (c.rx.size() >= sizeof(ReqHeader)) {
+                ReqHeader h;
+                memcpy(&h, c.rx.data(), sizeof h);
+                if (!valid_header(h)) return false;
+                want = sizeof h + ((size_t)h.n_above + h.n_left) * 4;
+                if (c.rx.size() == want) {
+                    if (c.in_flight) return false;            // one outstanding request per client
+                    Pending p;
+                    p.fd = c.fd; p.want_f32 = (h.flags & kWantF32) != 0;
+                    p.above.resize(h.n_above); p.left.resize(h.n_left);
+                    memcpy(p.above.data(), c.rx.data() + sizeof h, (size_t)h.n_above * 4);
+                    if (h.n_left) memcpy(p.left.data(), c.rx.data() + sizeof h + (size_t)h.n_above * 4, (size_t)h.n_left * 4);
+                    pending[{h.width, h.n_left ? 1 : 0}].push_back(std::move(p));
+                    ++n_pending;
+                    c.in_flight = true;
+                    c.rx.clear();
+                    return true;
+                }
+            }
+            const size_t have = c.rx.size();
+            c.rx.resize(want);
+            const ssize_t r = recv(c.fd, c.rx.data() + have, want - have, 0);
+            if (r <= 0) {
+                c.rx.resize(have);
+                if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) return true;   // rest comes later
+                return false;                                 // closed or broken
+            }
+            c.rx.resize(have + (size_t)r);
+        }
+    };
+    auto flush = [&](Client& c) {                             // false = broken
+        while (c.tx_off < c.tx.size()) {
+            const ssize_t r = send(c.fd, c.tx.data() + c.tx_off, c.tx.size() - c.tx_off, MSG_NOSIGNAL);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                if (errno == EAGAIN || errno == EWOULDBLOCK) return true;
+                return false;
+            }
+            c.tx_off += (size_t)r;
+        }
+        c.tx.clear(); c.tx_off = 0;
         return true;
     };
-    auto poll_once = [&](int timeout_ms) {           // accept + read whatever is ready; returns number of requests taken
-        std::vector<pollfd> fds(clients.size() + 1);
-        fds[0] = {lfd, POLLIN, 0};
-        for (size_t i = 0; i < clients.size(); i++) fds[i + 1] = {clients[i], POLLIN, 0};
-        const int r = poll(fds.data(), fds.size(), timeout_ms);
-        if (r <= 0) return 0;
-        int took = 0;
+    auto poll_once = [&](long timeout_us) {
+        std::vector<pollfd> fds;
+        fds.reserve(clients.size() + 1);
+        fds.push_back({lfd, POLLIN, 0});
+        for (auto& kv : clients) {
+            short ev = 0;
+            if (!kv.second.in_flight) ev |= POLLIN;           // an answered client may send its next request
+            if (!kv.second.tx.empty()) ev |= POLLOUT;
+            fds.push_back({kv.first, ev, 0});
+        }
+        timespec ts{timeout_us / 1000000, (timeout_us % 1000000) * 1000};
+        const int r = ppoll(fds.data(), fds.size(), &ts, nullptr);
         std::vector<int> gone;
-        for (size_t i = 1; i < fds.size(); i++) {
-            if (!(fds[i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
-            bool has_request = false;                // a client with a request in flight sends nothing more until it is answered
-            for (auto& kv : pending)
-                for (const Pending& p : kv.second) has_request |= p.fd == fds[i].fd;
-            if (has_request) { if (fds[i].revents & (POLLHUP | POLLERR)) gone.push_back(fds[i].fd); continue; }
-            if (take(fds[i].fd)) ++took; else gone.push_back(fds[i].fd);
-        }
-        if (fds[0].revents & POLLIN) {
-            const int cfd = accept(lfd, nullptr, nullptr);
-            if (cfd >= 0) { clients.push_back(cfd); ++accepted; }
-        }
-        for (int fd : gone) {
-            for (auto& kv : pending) {
-                auto& v = kv.second;
-                const size_t before = v.size();
-                v.erase(std::remove_if(v.begin(), v.end(), [fd](const Pending& p) { return p.fd == fd; }), v.end());
-                n_pending -= before - v.size();
+        if (r > 0) {
+            for (size_t i = 1; i < fds.size(); i++) {
+                if (!fds[i].revents) continue;
+                Client& c = clients[fds[i].fd];
+                bool ok = true;
+                if (fds[i].revents & POLLOUT) ok = flush(c);
+                if (ok && (fds[i].revents & POLLIN)) ok = receive(c);
+                else if (ok && (fds[i].revents & (POLLHUP | POLLERR | POLLNVAL))) ok = false;
+                if (!ok) gone.push_back(fds[i].fd);
             }
-            drop(fd);
+            if (fds[0].revents & POLLIN) {
+                for (;;) {
+                    const int cfd = accept(lfd, nullptr, nullptr);
+                    if (cfd < 0) break;
+                    set_nonblocking(cfd);
+                    Client c;
+                    c.fd = cfd;
+                    clients.emplace(cfd, std::move(c));
+                    ++accepted;
+                }
+            }
         }
-        return took;
+        const auto now = Clock::now();
+        for (auto& kv : clients)
+            if (!kv.second.tx.empty() && std::chrono::duration_cast<std::chrono::milliseconds>(now - kv.second.tx_since).count() > kStallMs)
+                gone.push_back(kv.first);
+        std::sort(gone.begin(), gone.end());
+        gone.erase(std::unique(gone.begin(), gone.end()), gone.end());
+        for (int fd : gone) drop(fd);
     };
-    std::vector<float> above, left;
+
+    std::vector<float> above, left, out;
     std::vector<int32_t> dst;
     while (!*stop) {
-        poll_once(n_pending ? 0 : 50);
+        poll_once(n_pending ? 0 : 50000);
         if (!n_pending) continue;
         if (window_us > 0 && (long)n_pending < max_batch) {   // give stragglers a moment to join the batch
-            const auto t0 = std::chrono::steady_clock::now();
+            const auto t0 = Clock::now();
             for (;;) {
-                const long left_us = window_us - (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-                if (left_us <= 0 || (long)n_pending >= max_batch) break;
-                poll_once((int)std::max<long>(1, left_us / 1000));
+                const long left_us = window_us - (long)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
+                if (left_us <= 0 || (long)n_pending >= max_batch || *stop) break;
+                poll_once(left_us);
             }
         }
         for (auto& kv : pending) {
@@ -152,29 +240,46 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
             while (!v.empty()) {
                 const size_t n = std::min<size_t>(v.size(), (size_t)max_batch);
                 const size_t na = v[0].above.size(), nl = v[0].left.size();
-                above.resize(n * na); left.resize(n * nl); dst.resize(n * w2);
+                bool any_f32 = false, any_pel = false;
+                above.resize(n * na); left.resize(n * nl);
                 for (size_t i = 0; i < n; i++) {
                     memcpy(above.data() + i * na, v[i].above.data(), na * 4);
                     if (nl) memcpy(left.data() + i * nl, v[i].left.data(), nl * 4);
+                    (v[i].want_f32 ? any_f32 : any_pel) = true;
                 }
-                const int rc = backend(user, w, above.data(), nl ? left.data() : nullptr, (int)n, dst.data());
+                if (any_pel) dst.resize(n * w2);
+                if (any_f32) out.resize(n * w2);
+                const int rc = backend(user, w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
+                                       any_f32 ? out.data() : nullptr);
                 ++calls;
                 largest = std::max<long>(largest, (long)n);
                 for (size_t i = 0; i < n; i++) {
-                    const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
-                    const bool ok = write_all(v[i].fd, &rh, sizeof rh) && (rc != 0 || write_all(v[i].fd, dst.data() + i * w2, w2 * 4));
-                    if (!ok) drop(v[i].fd);
+                    auto it = clients.find(v[i].fd);
                     ++served;
+                    if (it == clients.end()) continue;
+                    Client& c = it->second;
+                    const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
+                    if (c.tx.empty()) c.tx_since = Clock::now();
+                    const char* hp = reinterpret_cast<const char*>(&rh);
+                    c.tx.insert(c.tx.end(), hp, hp + sizeof rh);
+                    if (rc == 0) {
+                        const char* pp = v[i].want_f32 ? reinterpret_cast<const char*>(out.data() + i * w2)
+                                                       : reinterpret_cast<const char*>(dst.data() + i * w2);
+                        c.tx.insert(c.tx.end(), pp, pp + w2 * 4);
+                    }
+                    c.in_flight = false;
+                    if (!flush(c)) { close(c.fd); clients.erase(it); ++dropped; }
                 }
                 v.erase(v.begin(), v.begin() + (long)n);
                 n_pending -= n;
             }
         }
     }
-    for (int fd : clients) close(fd);
+    for (auto& kv : clients) close(kv.first);
     close(lfd);
     unlink(socket_path);
     if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted; }
+    (void)dropped;
     return PNN_OK;
 }
 
@@ -197,21 +302,38 @@ int pnn_client_connect(pnn_client** out, const char* socket_path)
     return PNN_OK;
 }
 
-int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const float* left, int32_t* dst, int dst_stride)
+static int client_call(pnn_client* c, int width, const float* above, const float* left, uint32_t flags, void* vals)
 {
-    if (!c || !above || !dst || !valid_width(width) || dst_stride < width) return PNN_E_ARG;
     const uint32_t w2 = (uint32_t)(width * width);
-    const ReqHeader h{kMagic, width, left ? 3 * w2 : 5 * w2, left ? 2 * w2 : 0u};
-    if (!write_all(c->fd, &h, sizeof h) || !write_all(c->fd, above, (size_t)h.n_above * 4) || (left && !write_all(c->fd, left, (size_t)h.n_left * 4)))
-        return PNN_E_IO;
+    const ReqHeader h{kMagic, width, left ? 3 * w2 : 5 * w2, left ? 2 * w2 : 0u, flags};
+    // one send per request: the server sees the whole request in one readable event
+    c->buf.resize(sizeof h + ((size_t)h.n_above + h.n_left) * 4);
+    memcpy(c->buf.data(), &h, sizeof h);
+    memcpy(c->buf.data() + sizeof h, above, (size_t)h.n_above * 4);
+    if (left) memcpy(c->buf.data() + sizeof h + (size_t)h.n_above * 4, left, (size_t)h.n_left * 4);
+    if (!write_all(c->fd, c->buf.data(), c->buf.size())) return PNN_E_IO;
     RspHeader r;
     if (!read_all(c->fd, &r, sizeof r)) return PNN_E_IO;
     if (r.rc != 0) return r.rc;
-    if (r.n_pel != w2) return PNN_E_IO;
-    c->pel.resize(w2);
-    if (!read_all(c->fd, c->pel.data(), (size_t)w2 * 4)) return PNN_E_IO;
-    for (int y = 0; y < width; y++) memcpy(dst + (size_t)y * dst_stride, c->pel.data() + (size_t)y * width, (size_t)width * 4);
+    if (r.n_vals != w2) return PNN_E_IO;
+    return read_all(c->fd, vals, (size_t)w2 * 4) ? PNN_OK : PNN_E_IO;
+}
+
+int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const float* left, int32_t* dst, int dst_stride)
+{
+    if (!c || !above || !dst || !valid_width(width) || dst_stride < width) return PNN_E_ARG;
+    if (dst_stride == width) return client_call(c, width, above, left, 0u, dst);
+    std::vector<int32_t> pel((size_t)width * width);
+    const int rc = client_call(c, width, above, left, 0u, pel.data());
+    if (rc) return rc;
+    for (int y = 0; y < width; y++) memcpy(dst + (size_t)y * dst_stride, pel.data() + (size_t)y * width, (size_t)width * 4);
     return PNN_OK;
+}
+
+int pnn_client_predict_f32(pnn_client* c, int width, const float* above, const float* left, float* out)
+{
+    if (!c || !above || !out || !valid_width(width)) return PNN_E_ARG;
+    return client_call(c, width, above, left, kWantF32, out);
 }
 
 void pnn_client_close(pnn_client* c)

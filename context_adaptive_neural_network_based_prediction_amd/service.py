@@ -29,14 +29,19 @@ class Server:
         self.rc = None
         path = socket_path.encode()
         if backend is not None:
-            def trampoline(user, width, above, left, n, dst):
+            def trampoline(user, width, above, left, n, dst, out_f32):
                 w2 = width * width
                 na = (3 if left else 5) * w2
                 a = np.ctypeslib.as_array(above, shape=(n, na))
                 l = np.ctypeslib.as_array(left, shape=(n, 2 * w2)) if left else None
-                out = np.ctypeslib.as_array(dst, shape=(n, width, width))
                 try:
-                    out[...] = backend(width, a, l)
+                    # a stand-in backend returns the Pel blocks, or (Pel blocks, float predictions)
+                    res = backend(width, a, l)
+                    pel, f32 = res if isinstance(res, tuple) else (res, np.asarray(res, np.float32))
+                    if dst:
+                        np.ctypeslib.as_array(dst, shape=(n, width, width))[...] = pel
+                    if out_f32:
+                        np.ctypeslib.as_array(out_f32, shape=(n, width, width))[...] = f32
                     return 0
                 except Exception:                      # nothing may propagate into the C loop
                     return -1
@@ -85,6 +90,17 @@ class Client:
             raise _lib.PnnError("service returned %d" % rc)
         return dst
 
+    def predict_f32(self, width, above, left=None):
+        """The float prediction, as `Session::Run` returns it (mean not re-added)."""
+        a = np.ascontiguousarray(above, np.float32)
+        l = None if left is None else np.ascontiguousarray(left, np.float32)
+        out = np.empty((width, width), np.float32)
+        rc = self._L.pnn_client_predict_f32(self._c, width, a.ctypes.data_as(_lib.f32p), None if l is None else l.ctypes.data_as(_lib.f32p),
+                                            out.ctypes.data_as(_lib.f32p))
+        if rc != 0:
+            raise _lib.PnnError("service returned %d" % rc)
+        return out
+
     def close(self):
         if self._c:
             self._L.pnn_client_close(self._c)
@@ -104,12 +120,21 @@ def main():
     L = _lib.lib()
     ctx = ctypes.c_void_p()
     _lib.check(L.pnn_create(ctypes.byref(ctx), args.table.encode(), args.pair, ctypes.c_float(args.mean), args.device))
-    stop = ctypes.c_int(0)
-    stats = (ctypes.c_long * 4)()
-    try:
-        L.pnn_service_run(args.socket.encode(), ctx, args.max_batch, args.window_us, ctypes.byref(stop), stats)
-    finally:
-        L.pnn_destroy(ctx)
+    # a block must get the same prediction whatever batch it travels in (encoder behind the service, decoder alone)
+    _lib.check(L.pnn_set_option(ctx, b"canonical_order", 1), ctx)
+    import signal
+    import time
+    srv = Server(args.socket, ctx=ctx, max_batch=args.max_batch, window_us=args.window_us)
+    done = threading.Event()
+    for sig in (signal.SIGTERM, signal.SIGINT):       # handlers run in this (main) thread; the C loop runs in the server's thread
+        signal.signal(sig, lambda *_: done.set())
+    print("pnn service: listening on %s" % args.socket, flush=True)
+    while not done.is_set() and srv.rc is None:
+        time.sleep(0.05)
+    st = srv.stop()
+    print("pnn service: %(requests)d requests in %(backend_calls)d batched calls (largest batch %(largest_batch)d), %(clients)d clients" % st,
+          flush=True)
+    L.pnn_destroy(ctx)
 
 
 if __name__ == "__main__":

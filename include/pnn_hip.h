@@ -114,6 +114,10 @@ int pnn_predict_conv(pnn_ctx* ctx, int width, const float* above, const float* l
 int pnn_predict_pel(pnn_ctx* ctx, int width, const float* above, const float* left, int n, int32_t* dst,
                     int dst_stride);
 
+/* Both results of one pass: the float prediction (as pnn_predict_fc / pnn_predict_conv) into `out` [n][w][w] and the
+ * HM-epilogue Pel values (as pnn_predict_pel, dense) into `dst` [n][w][w]; either may be NULL. */
+int pnn_predict_f32_pel(pnn_ctx* ctx, int width, const float* above, const float* left, int n, float* out, int32_t* dst);
+
 /* == extract_context_portions (extraction_context.cpp:3-208), same argument order and error behaviour
  * (returns -1 on NULL pointers, n_avail <= 0, unavailable corner unit). Pure host code. */
 int pnn_extract_context(const int32_t* roi_origin, float* above, float* left, const uint8_t* neighbor_flags,

@@ -17,8 +17,11 @@ extern "C" {
 #endif
 
 /* What the server calls for a batch: n blocks of one width, inputs stacked as pnn_predict_pel takes them
- * (FC widths: `above` = [n][5w^2] flattened contexts, `left` = NULL), dst = [n][w][w].  Returns 0 or a negative code. */
-typedef int (*pnn_service_backend)(void* user, int width, const float* above, const float* left, int n, int32_t* dst);
+ * (FC widths: `above` = [n][5w^2] flattened contexts, `left` = NULL).  dst = [n][w][w] Pel values after the HM epilogue,
+ * out_f32 = [n][w][w] float predictions as the frozen graph returns them (mean not re-added); either may be NULL when no
+ * client of the batch asked for that kind.  Returns 0 or a negative code. */
+typedef int (*pnn_service_backend)(void* user, int width, const float* above, const float* left, int n, int32_t* dst,
+                                   float* out_f32);
 
 /* Serves `socket_path` until *stop becomes non-zero (checked at least every 50 ms).  max_batch: largest batch handed to
  * the backend; window_us: after the first pending request the server waits up to this long for more before it
@@ -26,7 +29,9 @@ typedef int (*pnn_service_backend)(void* user, int width, const float* above, co
  * calls, largest batch, clients accepted. */
 int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend, void* user, int max_batch, int window_us,
                             volatile int* stop, long* stats);
-/* The same with backend = pnn_predict_pel on `ctx` (is_fc per width as the loaded models say). */
+/* The same with backend = pnn_predict_f32_pel on `ctx` (is_fc per width as the loaded models say).  The server never
+ * blocks on one client: a client that stalls in the middle of a request, stops reading its replies or sends a malformed
+ * header is dropped and the others go on. */
 int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats);
 
 /* Client side: what an encoder process links instead of owning a GPU context. */
@@ -35,6 +40,9 @@ int pnn_client_connect(pnn_client** out, const char* socket_path);
 /* == pnn_predict_pel(ctx, width, above, left, 1, dst, dst_stride) executed by the server (left = NULL for FC widths,
  * where `above` is the [5w^2] flattened context). */
 int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const float* left, int32_t* dst, int dst_stride);
+/* == Session::Run on the server: the float prediction [w][w] (what the TensorFlow look-alike of pnn_tf_compat.h binds when
+ * PNN_SERVICE_SOCKET is set, so that an UNMODIFIED HM process is served by the batching service). */
+int pnn_client_predict_f32(pnn_client* c, int width, const float* above, const float* left, float* out);
 void pnn_client_close(pnn_client* c);
 
 #ifdef __cplusplus

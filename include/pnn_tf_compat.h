@@ -1,7 +1,8 @@
 // pnn_tf_compat.h -- header-only look-alike of the TensorFlow C++ API subset that the reference's HM side uses
 // (SURVEY.md Appendix C), implemented on the C ABI of pnn_hip.h.  With `-I<repo>/include/tf_compat` in front
-// of the include path, the reference's hevc/hm_common/c++/source_common/integration_prediction_neural_network.{h,cpp}
-// and the PNN branch of TComPrediction.cpp / TComPattern.cpp compile unchanged and run on libpnn_hip.so:
+// of the include path (it also shadows python2.7/Python.h, the other dependency of TComPrediction.h:45-47), the
+// reference's hevc/hm_common/c++/source_common/*.cpp and both modified HM-16.15 trees compile UNCHANGED and link with
+// libpnn_hip.so alone -- tools/hm/Makefile does exactly that, tests/test_hm.py runs the resulting encoders / decoders:
 //
 //   tensorflow::Tensor(DT_FLOAT, {1, 80}).flat<float>().data() / .dims() / .shape().dim_size(i)
 //   tensorflow::GraphDef + ReadBinaryProto(Env::Default(), path, &graph_def)   -> remembers the model path
@@ -12,13 +13,25 @@
 //
 // Reference call sites: integration_prediction_neural_network.cpp:3-69, TComPrediction.cpp:564-622,
 // TComPattern.cpp:344-360.  Paths listed in the model table must point at `.pnnw` files.
+//
+// HM constructs its sessions with default SessionOptions, so a deployment is configured through the environment:
+//   PNN_DEVICE=<n>            HIP device of this process's sessions (default 0)
+//   PNN_SERVICE_SOCKET=<path> do not own a GPU context: send every Run to the batching service at that socket
+//                             (include/pnn_service.h) -- many encoder processes then share one GPU in batched launches
+//   PNN_CACHE_MB=<n>          per-session prediction cache (repeated identical Runs of HM's RD search), default 64
+//   PNN_STATS=1               print Run / cache-hit counts per session on stderr when the session is destroyed
+// Sessions always run with canonical_order = 1: a block's prediction does not depend on the batch it travels in, so an
+// encoder behind the batching service and a stand-alone decoder reconstruct the same picture.
 #ifndef PNN_TF_COMPAT_H
 #define PNN_TF_COMPAT_H
 
 #include "pnn_hip.h"
+#include "pnn_service.h"
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <iostream>
 #include <memory>
@@ -117,8 +130,9 @@ inline Status ReadBinaryProto(Env*, const std::string& path, GraphDef* graph_def
 }
 
 struct SessionOptions {
-    int pnn_device = 0;          // HIP device index
+    int pnn_device = -1;         // HIP device index; -1: $PNN_DEVICE, else 0
     float pnn_mean = 0.f;        // only used by the fused Pel entry points; the float Run() path never adds the mean
+    long pnn_cache_mb = -1;      // -1: $PNN_CACHE_MB, else 64
 };
 
 class Session {
@@ -132,17 +146,47 @@ public:
 
 class PnnSession : public Session {
 public:
-    explicit PnnSession(const SessionOptions& o) : opts_(o), ctx_(nullptr), width_(0), is_fc_(0) {}
-    ~PnnSession() override { if (ctx_) pnn_destroy(ctx_); }
+    explicit PnnSession(const SessionOptions& o) : opts_(o), ctx_(nullptr), client_(nullptr), width_(0), is_fc_(0), runs_(0) {}
+    ~PnnSession() override
+    {
+        if (std::getenv("PNN_STATS") && width_) {
+            long hits = 0, misses = 0;
+            if (ctx_) pnn_cache_stats(ctx_, &hits, &misses);
+            std::fprintf(stderr, "[pnn] session width %d (%s%s): %ld Run calls, %ld answered from the cache\n", width_,
+                         is_fc_ ? "fully-connected" : "convolutional", client_ ? ", via service" : "", runs_, hits);
+        }
+        if (ctx_) pnn_destroy(ctx_);
+        if (client_) pnn_client_close(client_);
+    }
     pnn_ctx* pnn_context() const { return ctx_; }
 
     Status Create(const GraphDef& graph) override
     {
         if (ctx_) { pnn_destroy(ctx_); ctx_ = nullptr; }
-        int rc = pnn_create_empty(&ctx_, opts_.pnn_mean, opts_.pnn_device);
+        if (client_) { pnn_client_close(client_); client_ = nullptr; }
+        width_ = 0;
+        if (const char* sock = std::getenv("PNN_SERVICE_SOCKET")) {
+            // served remotely: only the model's header is needed here (width, kind)
+            struct { char magic[4]; uint32_t version, width, is_fc; } h;
+            FILE* f = std::fopen(graph.pnn_model_path.c_str(), "rb");
+            if (!f) return errors::NotFound(graph.pnn_model_path, "; No such file or directory");
+            const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "PNNW", 4);
+            std::fclose(f);
+            if (!ok) return errors::InvalidArgument(graph.pnn_model_path, " is not a PNNW file");
+            if (pnn_client_connect(&client_, sock) != PNN_OK) return errors::Internal("no PNN batching service at ", sock);
+            width_ = (int)h.width; is_fc_ = (int)h.is_fc;
+            return Status::OK();
+        }
+        int dev = opts_.pnn_device;
+        if (dev < 0) { const char* e = std::getenv("PNN_DEVICE"); dev = e ? std::atoi(e) : 0; }
+        int rc = pnn_create_empty(&ctx_, opts_.pnn_mean, dev);
         if (rc != PNN_OK) return errors::Internal(pnn_last_error(nullptr));
         rc = pnn_load_model_file(ctx_, graph.pnn_model_path.c_str());
         if (rc != PNN_OK) return errors::InvalidArgument(pnn_last_error(ctx_));
+        long cache_mb = opts_.pnn_cache_mb;
+        if (cache_mb < 0) { const char* e = std::getenv("PNN_CACHE_MB"); cache_mb = e ? std::atol(e) : 64; }
+        pnn_set_option(ctx_, "canonical_order", 1);
+        pnn_set_option(ctx_, "cache_mb", cache_mb);
         for (int w = 4; w <= 64; w *= 2) {
             int fc = 0;
             if (pnn_model_info(ctx_, w, &fc, nullptr, nullptr) == PNN_OK) { width_ = w; is_fc_ = fc; }
@@ -153,7 +197,7 @@ public:
     Status Run(const std::vector<std::pair<string, Tensor> >& inputs, const std::vector<string>& output_tensor_names,
                const std::vector<string>&, std::vector<Tensor>* outputs) override
     {
-        if (!ctx_) return errors::Internal("Session::Run before Session::Create");
+        if (!ctx_ && !client_) return errors::Internal("Session::Run before Session::Create");
         if (!outputs || output_tensor_names.size() != 1) return errors::InvalidArgument("exactly one fetch is supported");
         const Tensor* ctx = nullptr; const Tensor* above = nullptr; const Tensor* left = nullptr;
         for (const auto& kv : inputs) {
@@ -164,24 +208,33 @@ public:
         }
         const string& fetch = output_tensor_names[0];
         const int w = width_;
-        int rc;
+        const int64 w2 = (int64)w * w;
+        int rc = PNN_OK;
+        ++runs_;
         if (is_fc_) {
             if (!ctx || fetch.find("fully_connected/node_output") != 0) return errors::NotFound("FetchOutputs node ", fetch, ": not found");
-            if (ctx->NumElements() % (5 * w * w)) return errors::InvalidArgument("node_flattened_context must be [N, ", 5 * w * w, "]");
-            const int n = (int)(ctx->NumElements() / (5 * w * w));
+            if (ctx->NumElements() % (5 * w2)) return errors::InvalidArgument("node_flattened_context must be [N, ", 5 * w2, "]");
+            const int n = (int)(ctx->NumElements() / (5 * w2));
             Tensor out(DT_FLOAT, TensorShape({n, w, w, 1}));
-            rc = pnn_predict_fc(ctx_, w, ctx->flat<float>().data(), n, out.flat<float>().data());
-            if (rc != PNN_OK) return errors::Internal(pnn_last_error(ctx_));
+            const float* x = ctx->flat<float>().data();
+            float* y = out.flat<float>().data();
+            if (client_) for (int i = 0; i < n && rc == PNN_OK; i++) rc = pnn_client_predict_f32(client_, w, x + i * 5 * w2, nullptr, y + i * w2);
+            else rc = pnn_predict_fc(ctx_, w, x, n, y);
+            if (rc != PNN_OK) return errors::Internal(client_ ? "the PNN batching service failed" : pnn_last_error(ctx_));
             outputs->assign(1, out);
         } else {
             if (!above || !left || fetch.find("convolutional/merger/transpose_convolution_") != 0)
                 return errors::NotFound("FetchOutputs node ", fetch, ": not found");
-            if (above->NumElements() % (3 * w * w) || left->NumElements() / (2 * w * w) != above->NumElements() / (3 * w * w))
+            if (above->NumElements() % (3 * w2) || left->NumElements() / (2 * w2) != above->NumElements() / (3 * w2))
                 return errors::InvalidArgument("node_portion_above / node_portion_left have the wrong shape for width ", w);
-            const int n = (int)(above->NumElements() / (3 * w * w));
+            const int n = (int)(above->NumElements() / (3 * w2));
             Tensor out(DT_FLOAT, TensorShape({n, w, w, 1}));
-            rc = pnn_predict_conv(ctx_, w, above->flat<float>().data(), left->flat<float>().data(), n, out.flat<float>().data());
-            if (rc != PNN_OK) return errors::Internal(pnn_last_error(ctx_));
+            const float* a = above->flat<float>().data();
+            const float* l = left->flat<float>().data();
+            float* y = out.flat<float>().data();
+            if (client_) for (int i = 0; i < n && rc == PNN_OK; i++) rc = pnn_client_predict_f32(client_, w, a + i * 3 * w2, l + i * 2 * w2, y + i * w2);
+            else rc = pnn_predict_conv(ctx_, w, a, l, n, y);
+            if (rc != PNN_OK) return errors::Internal(client_ ? "the PNN batching service failed" : pnn_last_error(ctx_));
             outputs->assign(1, out);
         }
         return Status::OK();
@@ -190,7 +243,9 @@ public:
 private:
     SessionOptions opts_;
     pnn_ctx* ctx_;
+    pnn_client* client_;
     int width_, is_fc_;
+    long runs_;
 };
 
 inline Session* NewSession(const SessionOptions& options) { return new PnnSession(options); }

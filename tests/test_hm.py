@@ -1,0 +1,167 @@
+"""The reference's two modified HM-16.15 codecs, compiled UNCHANGED against this repository's boundary
+(tools/hm/Makefile: include/tf_compat in place of TensorFlow 1.9 + CPython 2.7, libpnn_hip.so in place of their libraries).
+
+CPU tests: the build recipe works where the reference checkout exists, the four binaries need neither TensorFlow nor
+libpython, the CPython shadow header reads a pickled float the way `loading.load_via_pickle` does, and an encoder started
+without a GPU fails as loudly as the reference does when a graph cannot be loaded (no CPU fallback).
+GPU tests (BASELINE.json configs[3] / [4] in small): encode one seeded synthetic 4:0:0 picture with seeded random-init
+models, decode the bitstream, and require the decoder's picture to equal the encoder's reconstruction bit for bit --
+in-process and with several concurrent encoders behind the batching service.
+"""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HM = os.path.join(ROOT, "tools", "hm")
+sys.path.insert(0, HM)
+import run_hm  # noqa: E402
+
+VARIANTS = ("substitution", "switch")
+HAVE_REF = os.path.isdir("/root/reference/hevc/hm_16_15_substitution/source")
+
+
+def _binaries():
+    return [os.path.join(HM, "_build", v, "TApp%sStatic" % k) for v in VARIANTS for k in ("Encoder", "Decoder")]
+
+
+@pytest.fixture(scope="module")
+def hm_built():
+    if HAVE_REF:
+        subprocess.check_call(["make", "-s", "-C", HM, "-j8"])
+    missing = [b for b in _binaries() if not os.path.exists(b)]
+    if missing:
+        pytest.skip("HM binaries not built (tools/hm/Makefile needs the reference checkout): %s" % missing[0])
+    return True
+
+
+def test_hm_links_without_tensorflow_or_python(hm_built):
+    for b in _binaries():
+        needed = subprocess.check_output(["readelf", "-d", b]).decode()
+        libs = [l.split("[")[1].split("]")[0] for l in needed.splitlines() if "(NEEDED)" in l]
+        assert "libpnn_hip.so" in libs
+        assert not [l for l in libs if "tensorflow" in l or "python" in l or "protobuf" in l or "nsync" in l], libs
+        syms = subprocess.check_output(["nm", "-D", "--undefined-only", b]).decode()
+        assert " Py" not in syms and "tensorflow" not in syms        # the CPython / TF names are all header-only look-alikes
+        for name in ("pnn_create_empty", "pnn_load_model_file", "pnn_predict_fc", "pnn_predict_conv", "pnn_client_predict_f32"):
+            assert name in syms, "%s does not bind %s" % (os.path.basename(b), name)
+        out = subprocess.run([b, "--help"], capture_output=True, text=True)
+        assert "HM software" in out.stdout
+
+
+def test_hm_options_of_the_reference_are_kept(hm_built):
+    """The three command-line options the reference added (TAppEncCfg.cpp:1096-1098, TAppDecCfg.cpp:99-101)."""
+    for b in _binaries():
+        out = subprocess.run([b, "--help"], capture_output=True, text=True).stdout
+        for opt in ("PathToAdditionalDirectory", "PathToMeanTraining", "PathToFilePathsToGraphsOutput"):
+            assert opt in out
+
+
+def test_python_shadow_reads_the_mean_like_pickle(tmp_path):
+    """include/tf_compat/python2.7/Python.h through the call sequence HM makes: every pickle protocol of a float, the
+    reference's own byte string, a text file; and the error paths (missing module / attribute / file, not a float)."""
+    exe = str(tmp_path / "py_shadow")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I" + os.path.join(ROOT, "include", "tf_compat"),
+                           os.path.join(ROOT, "tests", "py_shadow_sample.cpp"), "-o", exe])
+    mean = 117.8952234192841
+    cases = {}
+    for proto in range(0, pickle.HIGHEST_PROTOCOL + 1):
+        p = tmp_path / ("mean_p%d.pkl" % proto)
+        p.write_bytes(pickle.dumps(mean, protocol=proto))
+        cases[str(p)] = mean
+    ref_bytes = tmp_path / "mean_ref.pkl"
+    ref_bytes.write_bytes(b"\x80\x02G@]yKW+\x1c\x10.")              # sets/results/training_set/means/luminance/mean_training.pkl
+    cases[str(ref_bytes)] = mean
+    txt = tmp_path / "mean.txt"
+    txt.write_text("117.8952234192841\n")
+    cases[str(txt)] = mean
+    neg = tmp_path / "neg.pkl"
+    neg.write_bytes(pickle.dumps(-1.0, protocol=2))                 # the value PyFloat_AsDouble also uses as its error code
+    cases[str(neg)] = -1.0
+    for path, want in cases.items():
+        r = subprocess.run([exe, "loading", "load_via_pickle", path], capture_output=True, text=True)
+        assert r.returncode == 0, (path, r.stderr)
+        assert float(r.stdout) == want, (path, r.stdout)
+    bad = tmp_path / "list.pkl"
+    bad.write_bytes(pickle.dumps([1.0, 2.0], protocol=2))
+    for argv, msg in ((["nosuch", "load_via_pickle", str(txt)], "ImportError"), (["loading", "nosuch", str(txt)], "AttributeError"),
+                      (["loading", "load_via_pickle", str(tmp_path / "absent.pkl")], "IOError"),
+                      (["loading", "load_via_pickle", str(bad)], "UnpicklingError")):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr, (argv, r.returncode, r.stderr)
+
+
+def test_hm_without_gpu_fails_like_a_missing_graph(hm_built, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    table, mean_path = run_hm.make_models(str(tmp_path / "models"), only_widths=(4,))
+    with pytest.raises(RuntimeError) as e:
+        run_hm.encode_decode("substitution", run_hm.make_frame(64, 64, 0), 32, table, mean_path, str(tmp_path))
+    assert "no CPU fallback" in str(e.value) and "Assertion" in str(e.value)
+
+
+def _check(res, variant):
+    assert res["decoder_equals_encoder"], res
+    assert not res["decoder_hash_error"], res
+    assert res["psnr_rec_db"] > 25.0, res
+    enc, dec = res["enc_pnn"], res["dec_pnn"]
+    assert set(enc) == {4, 8, 16, 32, 64}, enc                      # five sessions, as TComPrediction.cpp:126-129
+    assert all(enc[w]["runs"] > 0 for w in (4, 8, 16, 32, 64)), enc  # the fast search tries the PNN mode at every CU size
+    assert sum(v["runs"] for v in dec.values()) > 0, "the encoder never selected the PNN mode: %r" % (res,)
+    assert sum(v["runs"] for v in dec.values()) < sum(v["runs"] for v in enc.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_hm_encode_decode_roundtrip_on_gpu(hm_built, variant, tmp_path):
+    """configs[3] in small: the unmodified HM encoder of the reference, PNN on the MI355X through the TensorFlow
+    look-alike, one 256x192 4:0:0 picture at QP 32 (intra_main_rext settings); the decoder must rebuild the encoder's
+    reconstruction exactly (every PNN block it decodes was predicted by the same kernels in the same order)."""
+    table, mean_path = run_hm.make_models(str(tmp_path / "models"))
+    res = run_hm.encode_decode(variant, run_hm.make_frame(192, 256, 3), 32, table, mean_path, str(tmp_path))
+    print(res)
+    _check(res, variant)
+    assert sum(v["cache_hits"] for v in res["enc_pnn"].values()) > 0   # the RD search repeats identical calls
+
+
+@pytest.mark.gpu
+def test_hm_concurrent_encodes_through_the_batching_service(hm_built, tmp_path):
+    """configs[4] in small: four encoder processes share the GPU through ONE batching-service process
+    (PNN_SERVICE_SOCKET; their single-block requests are coalesced into batched launches); each bitstream is then decoded
+    by a stand-alone decoder that owns its own context -- the pictures must still match bit for bit, i.e. a block's
+    prediction does not depend on the batch it travelled in (canonical_order)."""
+    from concurrent.futures import ThreadPoolExecutor
+    table, mean_path = run_hm.make_models(str(tmp_path / "models"))
+    sock = str(tmp_path / "pnn.sock")
+    srv = subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
+                            "--table", table, "--max-batch", "64", "--window-us", "100"], cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    try:
+        assert "listening" in srv.stdout.readline()
+        frames = [run_hm.make_frame(128, 192, 20 + j) for j in range(4)]
+
+        def job(j):
+            return run_hm.encode_decode("switch", frames[j], 32, table, mean_path, str(tmp_path), tag=str(j),
+                                        env={"PNN_SERVICE_SOCKET": sock}, decoder_env={})
+        with ThreadPoolExecutor(4) as ex:
+            results = list(ex.map(job, range(4)))
+    finally:
+        srv.terminate()
+        tail = srv.stdout.read()
+        srv.wait(20)
+    print(tail)
+    for r in results:
+        print(r)
+        assert r["decoder_equals_encoder"] and not r["decoder_hash_error"], r
+        assert all("via service" in v["kind"] for v in r["enc_pnn"].values())
+        assert all("via service" not in v["kind"] for v in r["dec_pnn"].values())
+    import re
+    m = re.search(r"(\d+) requests in (\d+) batched calls \(largest batch (\d+)\), (\d+) clients", tail)
+    assert m, tail
+    requests, calls, largest, clients = map(int, m.groups())
+    assert clients == 20 and requests > 0                           # 4 encoders x 5 sessions
+    assert calls < requests and largest >= 2                         # requests of concurrent encoders were coalesced
