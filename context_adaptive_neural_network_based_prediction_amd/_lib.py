@@ -31,6 +31,7 @@ SERVICE_SIGNATURES = {
     "pnn_client_connect": (ci, [ctypes.POINTER(vp), ctypes.c_char_p]),
     "pnn_client_predict_pel": (ci, [vp, ci, f32p, f32p, i32p, ci]),
     "pnn_client_predict_f32": (ci, [vp, ci, f32p, f32p, f32p]),
+    "pnn_client_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_client_close": (None, [vp]),
 }
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "pnn_mean": (ctypes.c_float, [vp]),
     "pnn_set_option": (ci, [vp, ctypes.c_char_p, ctypes.c_long]),
     "pnn_num_split_configs": (ci, []),
+    "pnn_check_range": (ci, [vp, vp, ctypes.POINTER(ctypes.c_long)]),
     "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),
     "pnn_predict_conv": (ci, [vp, ci, f32p, f32p, ci, f32p]),

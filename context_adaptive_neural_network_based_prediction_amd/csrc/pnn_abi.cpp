@@ -7,6 +7,7 @@
 // pnn/components.py:10-261, and predict_by_batch_via_pnn (pnn/batching.py:7-88).
 #include "../../include/pnn_hip.h"
 #include "pnn_kernels.h"
+#include "pnn_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -21,12 +22,12 @@
 using namespace pnn;
 
 namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
+namespace { thread_local std::string g_create_error; }
+namespace pnn { void set_create_error(const std::string& msg) { g_create_error = msg; } }
 
 namespace {
 
 constexpr int kHidden = 1200;                         // pnn/components.py:130-160
-thread_local std::string g_create_error;
-
 int strides_for(int w, int* st)                       // pnn/PredictionNeuralNetwork.py:126-132
 {
     switch (w) {
@@ -106,19 +107,6 @@ struct pnn_ctx {
     long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
-    // fc_chain_kernel (pnn_gemm_ring.hip): the three hidden layers + output layer of an FC net in one launch.  OFF by
-    // default: measured 0.118 ms against 0.115 ms for the per-layer launches (FC 8x8, batch 4096) -- the ~5 us by which a
-    // kernel's duration exceeds its workgroups' lifetime is start skew and stragglers, which the inter-layer handshake
-    // waits for just the same, not dispatch cost that a fused launch would save.
-    long opt_chain = 0;
-    int chain_state = 0;                              // 0: placement not probed yet, 1: usable, -1: disabled for this context
-    int num_cus = 0;
-    ChainParams h_chain;                              // what d_chain holds
-    bool h_chain_valid = false;
-    ChainParams* d_chain = nullptr;
-    unsigned* d_chain_cnt = nullptr;                  // [3][64] handshake counters, monotonic
-    int* h_chain_err = nullptr;                       // host-visible: raised by a workgroup that gave up waiting
-    unsigned chain_epoch = 0;
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
@@ -128,6 +116,11 @@ struct pnn_ctx {
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
     struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
     std::vector<LaunchRec> launch_recs;
+    // Range guard of the split-precision path (pnn_device_common.h): kernels raise *h_range (pinned host memory) when a
+    // split-f16 activation leaves the f16 range.  Host entry points then repeat the pass on the exact-f32 kernels; device
+    // entry points report PNN_E_RANGE at the next call / pnn_check_range.
+    int* h_range = nullptr;
+    long range_fallbacks = 0;
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
@@ -663,7 +656,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         if (dev_reserve(c, c->stage_tbs, (size_t)64 << 20)) return PNN_E_NOMEM;
         p.Xlo = c->stage_tbs.p;
     } p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
-    p.mean = c->mean; p.out_scale = L.sp_inv_scale;
+    p.mean = c->mean; p.out_scale = L.sp_inv_scale; p.range_flag = c->h_range;
     const long M = nblocks * p.SH * p.SW;
     if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
     p.M = (int)M;
@@ -882,102 +875,6 @@ bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
     return px >= (m->width <= 8 ? 10000 : m->width == 16 ? 18000 : m->width == 32 ? 35000 : 70000);
 }
 
-// The hidden layers + fused output layer of a big FC pass as ONE launch (fc_chain_kernel).  Returns PNN_OK, an error, or 1
-// when this batch cannot use it (tile grid larger than the chip, row tiles not a multiple of the 8 XCDs, ...).
-int fc_chain_pass(pnn_ctx* c, Model* m, const void* S, float* P0, float* P1, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
-{
-    if (!c->num_cus) {
-        int n = 0;
-        HIPCHK(c, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->num_cus = n;
-    }
-    int cfg = -1, gx = 0, gy = 0;
-    for (int i = 0; i < tapgemm_ring_num_cfgs() && cfg < 0; i++) {
-        if (!fc_chain_has_cfg(i) || !tapgemm_ring_can_fuse(i)) continue;
-        const TileCfg t = tapgemm_ring_cfg(i);
-        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
-        const long tx = (nb + bm - 1) / bm, ty = (m->fc[1].proto.Cout + bn - 1) / bn;
-        if (tx % 8 == 0 && tx <= 64 && tx * ty <= c->num_cus) { cfg = i; gx = (int)tx; gy = (int)ty; }
-    }
-    if (cfg < 0) return 1;
-    for (int l = 0; l < 3; l++)                       // the hidden layers share the tile grid
-        if (m->fc[l].proto.Cout != m->fc[1].proto.Cout || m->fc[l].proto.ncls != 1) return 1;
-    if (c->h_chain_err && *c->h_chain_err) {          // a previous chained launch gave up waiting: its result was not valid
-        c->chain_state = -1;
-        *c->h_chain_err = 0;
-        return fail(c, PNN_E_HIP, "a chained FC launch timed out at its inter-layer handshake; chained launches are now disabled for this context");
-    }
-    if (c->chain_state == 0) {                        // once: allocate, and check that the workgroups (x, *) share an XCD
-        HIPCHK(c, hipMalloc((void**)&c->d_chain, sizeof(ChainParams)));
-        HIPCHK(c, hipMalloc((void**)&c->d_chain_cnt, 3 * 64 * sizeof(unsigned)));
-        HIPCHK(c, hipMemset(c->d_chain_cnt, 0, 3 * 64 * sizeof(unsigned)));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocDefault));
-        *c->h_chain_err = 0;
-        int* d_probe = nullptr;
-        HIPCHK(c, hipMalloc((void**)&d_probe, (size_t)gx * gy * sizeof(int)));
-        HIPCHK(c, launch_xcc_probe(gx, gy, tapgemm_ring_lds_bytes(tapgemm_ring_cfg(cfg)), d_probe, s));
-        std::vector<int> xcc((size_t)gx * gy);
-        HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, hipMemcpy(xcc.data(), d_probe, xcc.size() * sizeof(int), hipMemcpyDeviceToHost));
-        (void)hipFree(d_probe);
-        bool same = true;
-        for (int x = 0; x < gx; x++)
-            for (int y = 1; y < gy; y++) same &= xcc[(size_t)y * gx + x] == xcc[x];
-        c->chain_state = same ? 1 : -1;
-        if (getenv("PNN_DEBUG")) fprintf(stderr, "[pnn] chained FC kernel: %dx%d workgroups, column groups on one XCD each: %s\n", gx, gy, same ? "yes" : "NO -> disabled");
-        if (!same) return 1;
-    }
-    int rc;
-    if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
-    ChainParams cp;
-    memset(&cp, 0, sizeof cp);
-    const GemmLayer* Ls[3] = {&m->fc[0], &m->fc[1], &m->fc[2]};
-    const void* Xs[3] = {S, P0, P1};
-    void* Ys[3] = {P0, P1, nullptr};
-    double flops = 0;
-    for (int l = 0; l < 3; l++) {
-        TapGemmParams p = Ls[l]->proto;
-        p.X = (const float*)Xs[l]; p.Wp = Ls[l]->d_w_sp; p.bias = Ls[l]->d_bias; p.Yhi = Ys[l];
-        p.mean = c->mean; p.out_scale = Ls[l]->sp_inv_scale; p.M = (int)nb; p.zero = c->d_zero;
-        p.x_bytes = (unsigned)std::min<double>(4.0 * (double)nb * p.Cin, 2147483647.0);
-        flops += 2.0 * (double)nb * Ls[l]->k_total * p.Cout;
-        cp.layer[l] = p;
-    }
-    const GemmLayer& Lo = m->fc[3];
-    cp.layer[2].W2p = Lo.d_w_sp; cp.layer[2].Npad2 = Lo.proto.Npad; cp.layer[2].K2chunks = Lo.proto.chunk_begin[1];
-    cp.layer[2].part = (float*)c->ws[3].p;
-    flops += 2.0 * (double)nb * Lo.k_total * Lo.proto.Cout;
-    cp.nlayers = 3; cp.counters = c->d_chain_cnt; cp.error = c->h_chain_err;
-    if (!c->h_chain_valid || memcmp(&cp, &c->h_chain, sizeof cp)) {
-        HIPCHK(c, hipStreamSynchronize(s));           // the block a running launch reads must not change under it
-        HIPCHK(c, hipMemcpy(c->d_chain, &cp, sizeof cp, hipMemcpyHostToDevice));
-        c->h_chain = cp;
-        c->h_chain_valid = true;
-    }
-    const unsigned target = (unsigned)gy * ++c->chain_epoch;
-    static const bool debug = getenv("PNN_DEBUG") != nullptr;
-    if (debug) fprintf(stderr, "[pnn] fc-chain M=%ld: 3 hidden layers + output layer in one launch, ring cfg %d, grid %dx%d\n", nb, cfg, gx, gy);
-    if (c->opt_time_launches) {
-        pnn_ctx::LaunchRec r;
-        HIPCHK(c, hipEventCreate(&r.e0));
-        HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = 4; r.flops = flops;
-        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
-        g_launch_events = &ev;
-        const hipError_t le = launch_fc_chain(cp, c->d_chain, target, cfg, s);
-        g_launch_events = nullptr;
-        HIPCHK(c, le);
-        c->launch_recs.push_back(r);
-    } else {
-        HIPCHK(c, launch_fc_chain(cp, c->d_chain, target, cfg, s));
-    }
-    c->stat_gemm_launches++; c->stat_launches++;
-    c->stat_gemm_flops += flops;
-    HIPCHK(c, launch_fuse_reduce((const float*)c->ws[3].p, gy, (int)nb, Lo.proto.Cout, Lo.d_bias, Lo.sp_inv_scale, c->mean, d_out, d_dst, s));
-    c->stat_launches++;
-    return PNN_OK;
-}
-
 int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
 {
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
@@ -987,16 +884,12 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
         const long nin = nb * 5L * m->width * m->width;
         const void* S = d_ctx;                        // already in the split layout when the gather wrote it
         if (!ctx_is_split) {
-            HIPCHK(c, launch_split(d_ctx, nin, c->ws[2].p, nullptr, s));
+            HIPCHK(c, launch_split(d_ctx, nin, c->ws[2].p, nullptr, c->h_range, s));
             c->stat_launches++;
             S = c->ws[2].p;
         }
         const int n_out = m->fc[3].proto.Cout;
         const bool fuse_ok = c->opt_fuse_last && c->opt_ring && !c->opt_canonical && c->opt_sp_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && nb >= 1024;
-        if (fuse_ok && c->opt_chain && c->chain_state >= 0) {
-            rc = fc_chain_pass(c, m, S, P0, P1, nb, d_out, d_dst, s);
-            if (rc != 1) return rc;                   // 1: this batch does not fit the chained kernel, use the per-layer launches
-        }
         if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
         if (fuse_ok) {
@@ -1043,7 +936,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         const size_t nl = m->branch[br].size();
         Conv1Params f = m->first[br].proto;
         f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
-        f.B = (int)nb;
+        f.B = (int)nb; f.range_flag = c->h_range;
         int cur = 0;
         f.Y = nl == 0 ? F[br] : P[cur];
         f.split = (sp && nl > 0) ? 1 : 0;
@@ -1073,6 +966,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
     mp.split = (sp && nt > 0) ? 1 : 0;
     mp.one_order = c->opt_canonical ? 1 : 0;
+    mp.range_flag = c->h_range;
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;
     int cur = 0;
@@ -1092,6 +986,16 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
 
 void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; c->stat_gemm_flops = 0; }
 
+// Device (asynchronous) entry points cannot wait for their own pass; a pass that left the f16 range is reported by the
+// next call on the context (and by pnn_check_range, which waits for the stream).
+int pending_range_error(pnn_ctx* c)
+{
+    if (!c->h_range || !*c->h_range) return PNN_OK;
+    *c->h_range = 0;
+    return fail(c, PNN_E_RANGE, "an earlier asynchronous pass produced activations outside the f16 range of the split-precision "
+                                "kernels (|v| >= 65504): its predictions are invalid; repeat it with pnn_set_option(ctx, \"precision\", 0)");
+}
+
 // Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
 int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
             int32_t* d_dst, hipStream_t s, bool ctx_is_split = false)
@@ -1107,68 +1011,6 @@ int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d
         rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, ctx_is_split, nb, o, di, s)
                       : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
         if (rc) return rc;
-    }
-    return PNN_OK;
-}
-
-bool read_file(const std::string& path, std::vector<char>* out)
-{
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out->resize(sz > 0 ? sz : 0);
-    const size_t got = sz > 0 ? fread(out->data(), 1, sz, f) : 0;
-    fclose(f);
-    return got == (size_t)std::max(sz, 0L);
-}
-
-struct TableEntry { int width, is_pair, channel; std::string path; };
-
-// hevc/hm_common/c++/source_common/tools.cpp:52-111 (+ split_string :127-152): fields split on runs of
-// delimiters, lines made of whitespace only are skipped, keys parsed like std::stoul (leading blanks
-// skipped, trailing text ignored), the path trimmed of surrounding whitespace.
-int parse_table(const char* path, std::vector<TableEntry>* out, std::string* err)
-{
-    std::vector<char> data;
-    if (!path || !read_file(path, &data)) { *err = std::string("The file at \"") + (path ? path : "(null)") + "\" cannot be opened."; return PNN_E_IO; }
-    const std::string text(data.begin(), data.end());
-    size_t pos = 0;
-    const char* ws = " \t\f\v\n\r";
-    while (pos <= text.size()) {
-        size_t eol = text.find('\n', pos);
-        if (eol == std::string::npos) eol = text.size();
-        std::string line = text.substr(pos, eol - pos);
-        pos = eol + 1;
-        if (line.find_first_not_of(ws) == std::string::npos) { if (eol == text.size()) break; continue; }
-        std::vector<std::string> f;
-        size_t i = 0;
-        while (i <= line.size()) {
-            size_t j = line.find_first_of(",;", i);
-            if (j == std::string::npos) { f.push_back(line.substr(i)); break; }
-            f.push_back(line.substr(i, j - i));
-            i = line.find_first_not_of(",;", j);
-            if (i == std::string::npos) break;
-        }
-        if (f.size() < 4) { *err = "model table line with fewer than 4 fields: " + line; return PNN_E_IO; }
-        TableEntry e;
-        char* endp = nullptr;
-        const char* s0 = f[0].c_str();
-        e.width = (int)strtoul(s0, &endp, 10);
-        if (endp == s0) { *err = "model table: bad width in line: " + line; return PNN_E_IO; }
-        const char* s1 = f[1].c_str();
-        e.is_pair = strtoul(s1, &endp, 10) != 0;
-        if (endp == s1) { *err = "model table: bad is_pair in line: " + line; return PNN_E_IO; }
-        const char* s2 = f[2].c_str();
-        e.channel = (int)strtoul(s2, &endp, 10);
-        if (endp == s2) { *err = "model table: bad channel in line: " + line; return PNN_E_IO; }
-        std::string v = f[3];
-        const size_t a = v.find_first_not_of(ws);
-        const size_t b = v.find_last_not_of(ws);
-        e.path = a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
-        out->push_back(e);
-        if (eol == text.size()) break;
     }
     return PNN_OK;
 }
@@ -1201,10 +1043,14 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
-    if (const char* e = getenv("PNN_CHAIN")) c->opt_chain = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
     if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
+    if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
+        pnn_destroy(c);
+        return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
+    }
+    *c->h_range = 0;
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -1299,9 +1145,7 @@ void pnn_destroy(pnn_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
-    if (c->d_chain) (void)hipFree(c->d_chain);
-    if (c->d_chain_cnt) (void)hipFree(c->d_chain_cnt);
-    if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
+    if (c->h_range) (void)hipHostFree(c->h_range);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1334,7 +1178,6 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
-    else if (!strcmp(name, "chain")) c->opt_chain = value;
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
@@ -1385,6 +1228,7 @@ int pnn_predict_fc_device(pnn_ctx* c, int width, const float* d_ctx, int n, floa
     if (!m) return rc;
     if (n < 0 || (n > 0 && (!d_ctx || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = pending_range_error(c))) return rc;
     reset_stats(c);
     hipStream_t s = (hipStream_t)stream;
     return run_net(c, m, d_ctx, 5L * width * width, nullptr, 0, n, d_out, nullptr, s);
@@ -1397,33 +1241,10 @@ int pnn_predict_conv_device(pnn_ctx* c, int width, const float* d_above, const f
     if (!m) return rc;
     if (n < 0 || (n > 0 && (!d_above || !d_left || !d_out))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = pending_range_error(c))) return rc;
     reset_stats(c);
     hipStream_t s = (hipStream_t)stream;
     return run_net(c, m, d_above, 3L * width * width, d_left, 2L * width * width, n, d_out, nullptr, s);
-}
-
-int pnn_make_tb_desc(pnn_tb_dev* out, int64_t origin, int32_t stride, const uint8_t* flags, int n_avail, int above_units,
-                     int left_units)
-{
-    if (!out || !flags) { fprintf(stderr, "`out` or `neighbor_flags` is NULL.\n"); return -1; }
-    if (n_avail <= 0) { fprintf(stderr, "`iNumIntraNeighbor` is not strictly positive.\n"); return -1; }   // extraction_context.cpp:42-47
-    if (above_units > 32 || left_units < 0 || above_units < 0) return -1;
-    out->origin = origin; out->stride = stride; out->reserved = 0;
-    if (n_avail == above_units + left_units + 1) {               // extraction_context.cpp:56: dense copy of everything
-        out->above_mask = above_units >= 32 ? 0xffffffffu : ((1u << above_units) - 1u);
-        out->left_units = left_units;
-        return 0;
-    }
-    if (!flags[left_units]) {                                     // extraction_context.cpp:133-139
-        fprintf(stderr, "The neighbouring unit above and on the left side of the current TB is not available.\n");
-        return -1;
-    }
-    uint32_t mask = 0;
-    for (int i = 0; i < above_units; i++) if (flags[left_units + 1 + i]) mask |= 1u << i;
-    int cnt = 0;
-    for (int i = 0; i < left_units; i++) cnt += flags[i] != 0;   // rows compact upwards, extraction_context.cpp:189-205
-    out->above_mask = mask; out->left_units = cnt;
-    return 0;
 }
 
 int pnn_gather_device(pnn_ctx* c, int width, int unit, const void* d_plane, int pel_bytes, const pnn_tb_dev* d_tbs, int n,
@@ -1450,6 +1271,7 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
     if (!m) return rc;
     if (n < 0 || (n > 0 && (!d_plane || !d_tbs || (!d_dst && !d_out_f32)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = pending_range_error(c))) return rc;
     reset_stats(c);
     hipStream_t s = (hipStream_t)stream;
     const long w2 = (long)width * width;
@@ -1566,6 +1388,16 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         rc = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, 1, p_out, (dst || slot) ? p_dst : nullptr, s);
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(s));
+        if (*c->h_range) {                            // left the f16 range: the same pass on the exact-f32 kernels
+            *c->h_range = 0;
+            c->range_fallbacks++;
+            const long keep = c->opt_precision;
+            c->opt_precision = 0;
+            rc = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, 1, p_out, (dst || slot) ? p_dst : nullptr, s);
+            c->opt_precision = keep;
+            if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
         if (out) memcpy(out, p_out, w2 * 4);
         if (dst)
             for (int y = 0; y < w; y++) memcpy(dst + (size_t)y * dst_stride, p_dst + (size_t)y * w, (size_t)w * 4);
@@ -1587,6 +1419,18 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     rc = run_net(c, m, (const float*)c->stage_in[0].p, m->is_fc ? 5 * w2 : 3 * w2, (const float*)c->stage_in[1].p, 2 * w2, n,
                  d_out, d_dst, s);
     if (rc) return rc;
+    if (c->opt_precision == 1) {                      // the guard costs one synchronisation; the copies below wait for the stream anyway
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (*c->h_range) {                            // left the f16 range: the same pass on the exact-f32 kernels
+            *c->h_range = 0;
+            c->range_fallbacks++;
+            c->opt_precision = 0;
+            rc = run_net(c, m, (const float*)c->stage_in[0].p, m->is_fc ? 5 * w2 : 3 * w2, (const float*)c->stage_in[1].p, 2 * w2, n,
+                         d_out, d_dst, s);
+            c->opt_precision = 1;
+            if (rc) return rc;
+        }
+    }
     if (out) HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n * w2 * 4, hipMemcpyDeviceToHost, s));
     if (dst) {
         if (dst_stride == w) HIPCHK(c, hipMemcpyAsync(dst, d_dst, (size_t)n * w2 * 4, hipMemcpyDeviceToHost, s));
@@ -1604,6 +1448,15 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     HIPCHK(c, hipStreamSynchronize(s));
     if (slot) { slot->hash = hash; slot->valid = true; }
     return PNN_OK;
+}
+
+int pnn_check_range(pnn_ctx* c, void* stream, long* host_fallbacks)
+{
+    if (!c) return PNN_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (host_fallbacks) *host_fallbacks = c->range_fallbacks;
+    return pending_range_error(c);
 }
 
 int pnn_cache_stats(pnn_ctx* c, long* hits, long* misses)
@@ -1649,23 +1502,6 @@ int pnn_predict_f32_pel(pnn_ctx* c, int width, const float* above, const float* 
     if (!m) return rc;
     if (!out && !dst) return fail(c, PNN_E_ARG, "`out` and `dst` are both NULL");
     return host_predict(c, m, above, left, n, out, dst, width);
-}
-
-int pnn_parse_model_table(const char* path, int* widths, int* is_pair, int* channels, const char** paths, int max_entries)
-{
-    static thread_local std::vector<TableEntry> keep;
-    keep.clear();
-    std::string err;
-    const int rc = parse_table(path, &keep, &err);
-    if (rc) { g_create_error = err; fprintf(stderr, "%s\n", err.c_str()); return rc; }
-    const int n = std::min((int)keep.size(), max_entries);
-    for (int i = 0; i < n; i++) {
-        if (widths) widths[i] = keep[i].width;
-        if (is_pair) is_pair[i] = keep[i].is_pair;
-        if (channels) channels[i] = keep[i].channel;
-        if (paths) paths[i] = keep[i].path.c_str();
-    }
-    return n;
 }
 
 }  // extern "C"

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         const int CG = p.Cin >> 2;
         const int cg = tid % CG, ppi = 256 / CG;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.B0 + 4 * cg);
+        float amax0 = 0.f;                             // range guard (pnn_device_common.h)
         auto conv0 = [&](auto k_tag) {                 // the k x k weights of this thread's four channels live in registers
             constexpr int K = decltype(k_tag)::value;
             f32x4 w[K * K];
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                 h4 hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { hi[i] = (_Float16)acc[i]; lo[i] = (_Float16)(acc[i] - (float)hi[i]); }
+                amax0 = amax4(amax0, acc);
                 _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (cg >> 2) * 32 + (cg & 3) * 4;
                 *reinterpret_cast<h4*>(dst) = hi;
                 *reinterpret_cast<h4*>(dst + 16) = lo;
             }
         };
         if (K0 == 5) conv0(std::integral_constant<int, 5>{}); else conv0(std::integral_constant<int, 3>{});
+        report_range(p.range_flag, amax0);
         for (int idx = tid; idx < PITCH; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                              // the scratch becomes the weight staging area again
     } else {
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     // Three copies of the unrolled group loop, chosen once (split-f16 only / f32 only / any mix): the loop runs once per
     // launch from a cold instruction cache, so its time follows its code footprint (ring kernel: 7.9k -> 4.1k cycles).
     const bool act = p.act != 0;
+    float amax = 0.f;                                // range guard of the split outputs (pnn_device_common.h)
     auto groups = [&](auto kind_tag) {
         constexpr int kKind = decltype(kind_tag)::value;             // 0: split only, 1: f32 only, 2: general
 #pragma unroll
@@ -289,12 +293,12 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                             v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
                         }
                         if (kKind == 0) {
-                            store_split4(p.Yhi, obase, n, v);
+                            store_split4(p.Yhi, obase, n, v, amax);
                         } else if (kKind == 1) {
                             *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
                         } else {
                             if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
-                            if (p.Yhi) store_split4(p.Yhi, obase, n, v);
+                            if (p.Yhi) store_split4(p.Yhi, obase, n, v, amax);
                             if (p.Yi) {
                                 int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
                                                     hm_round(v[3], p.mean));

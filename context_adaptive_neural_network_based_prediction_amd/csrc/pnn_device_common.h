@@ -32,10 +32,26 @@ __device__ __forceinline__ int hm_round(float p, float mean)
     return (int)roundf(v);
 }
 
+// Range guard of the split-precision path.  An activation v is carried as hi = (f16) v, lo = (f16)(v - hi); |v| >= 65520
+// would make hi infinite and lo NaN, and the HM epilogue would turn that NaN into 255 without a trace.  Every kernel that
+// writes split activations therefore tracks max |v| of what it converts and raises the context's flag (host-visible
+// memory) when the f16 range is left; pnn_abi.cpp then repeats the pass on the exact-f32 kernels (host entry points) or
+// reports PNN_E_RANGE (device entry points, pnn_check_range).  Cost: one v_max_f32 per converted value.
+constexpr float kF16Max = 65504.f;
+__device__ __forceinline__ float amax4(float m, f32x4 v)
+{
+    return fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fmaxf(fabsf(v[1]), fabsf(v[2])), fabsf(v[3])));
+}
+__device__ __forceinline__ void report_range(int* flag, float amax)
+{
+    if (flag && !(amax < kF16Max)) *flag = 1;
+}
+
 // Split activation layout of the split-precision GEMM: element (pixel, channel n) of a [pixels][C] tensor lives at
 // f16 index 2*pixel*C + (n/16)*32 + n%16 (hi) and +16 (lo); x = hi + lo with hi = (f16) x, lo = (f16)(x - hi).
-__device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, int n, f32x4 v)
+__device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, int n, f32x4 v, float& amax)
 {
+    amax = amax4(amax, v);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 hi, lo;
 #pragma unroll
@@ -45,8 +61,9 @@ __device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, i
     *reinterpret_cast<h4*>(dst + 16) = lo;
 }
 
-__device__ __forceinline__ void store_split1(void* base, size_t pixel_times_c, int n, float v)
+__device__ __forceinline__ void store_split1(void* base, size_t pixel_times_c, int n, float v, float& amax)
 {
+    amax = fmaxf(amax, fabsf(v));
     const _Float16 hi = (_Float16)v;
     _Float16* dst = reinterpret_cast<_Float16*>(base) + 2 * pixel_times_c + (n >> 4) * 32 + (n & 15);
     dst[0] = hi;

@@ -70,7 +70,7 @@ __device__ __forceinline__ void wait_stages(bool fewer)
     if (fewer) wait_vm<STAGES * (HI - 1)>(); else wait_vm<STAGES * HI>();
 }
 
-// One layer's tile on this workgroup: the whole kernel body, callable several times in a row (fc_chain_kernel below).
+// One layer's tile on this workgroup: the whole kernel body, callable several times in a row .
 // The parameter block is read through the CONSTANT address space (the kernel-argument segment, or a device buffer that
 // does not change during the launch): every field, also the runtime-indexed tap tables, is then a scalar load; through a
 // generic pointer the fields of a layer chosen at run time end up in vector registers (256 VGPRs + 77 spilled).
@@ -126,7 +126,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     // ([chunk][4 planes][64 columns] pieces) are fetched behind the output tile by the loader waves.
     constexpr int W2OFF = BM * OPP, W2CH = BN / 16, W2PCS = W2CH * 4 * 64;
     static_assert(!FUSE || (WM == 4 && (size_t)W2OFF + W2PCS <= (size_t)D * SS && W2PCS % 256 == 0), "fused layer needs WM = 4 and room behind the tile");
-    const bool fuse = FUSE && p.W2p != nullptr;      // FUSE instantiations also run plain layers (fc_chain_kernel)
+    const bool fuse = FUSE && p.W2p != nullptr;      // FUSE instantiations also run plain layers
     // (Handing the tile to the loader waves one 32-column block at a time, so that the copy-out runs under the conversion,
     // was built and measured: epilogue 8.8k -> 7.9k cycles in tools/ring_prof.hip, but FC-8 and conv-16 passes 1 % SLOWER
     // -- five more workgroup-wide barriers and a third copy of the unrolled group loop in the instruction cache.)
@@ -473,6 +473,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     // branches inside.  The loop runs ONCE per launch from a cold instruction cache, so its time is set by its code
     // footprint: with all three output kinds behind per-group branches it was ~20 KB and 7.9k cycles for 20 groups.
     const bool act = p.act != 0;
+    float amax = 0.f;                                // range guard of the split outputs (pnn_device_common.h)
     auto groups = [&](auto direct_tag) {
         constexpr bool kDirect = decltype(direct_tag)::value;        // f32 / HM outputs straight from the accumulator layout
 #pragma unroll
@@ -507,6 +508,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                     if (!kDirect || p.Yhi || fuse) {  // same values and rounding as store_split4
                         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                         h4 hi, lo;
+                        amax = amax4(amax, v);
 #pragma unroll
                         for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
                         _Float16* dst = reinterpret_cast<_Float16*>(ring + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
@@ -525,6 +527,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
         }
     };
     if (p.Y || p.Yi) groups(std::true_type{}); else groups(std::false_type{});
+    report_range(p.range_flag, amax);
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -617,57 +620,9 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     ring_layer<RT, NT, KC, WM, D, FUSE>(*(CParams*)__builtin_amdgcn_kernarg_segment_ptr(), threadIdx.x);
 }
 
-// ---- a whole fully-connected PNN in ONE launch ---------------------------------------------------------------------------
-// The hidden layers of an FC net share M and N, so they share the tile grid: workgroup (x, y) computes tile (x, y) of
-// layer 0, then of layer 1, ... (the last one with the fused output layer).  Tile (x, y) of layer l+1 reads the 128 rows x
-// ALL columns that the gridDim.y workgroups (x, *) of layer l wrote, so those workgroups meet at a counter between two
-// layers -- a launch boundary (dispatch, drain, argument fetch, cold instruction cache: ~6 us) becomes a ~1 us handshake.
-// Requirements, checked by the host (pnn_abi.cpp): every workgroup resident at once (grid <= CUs, one per CU by LDS
-// size); the workgroups (x, *) on ONE XCD, so that their stores and loads meet in that XCD's L2 (workgroups go to XCDs
-// round-robin in dispatch order: linear id x + gridDim.x * y, gridDim.x % 8 == 0; verified once per context with
-// xcc_probe_kernel); each activation buffer is written once and read afterwards within the launch, so no stale line can
-// sit in a CU's L1.  The wait is bounded: on timeout the error flag is raised and the host falls back for good.
-
-template <int RT, int NT, int KC, int WM, int D>
-__global__ __launch_bounds__(512) void fc_chain_kernel(const ChainParams* __restrict__ cpp, const unsigned target)
-{
-    // the parameter block lives in DEVICE memory (uploaded when it changes) and is read through the constant address space:
-    // indexing a by-value argument block with the layer number makes the compiler copy it to scratch
-    typedef const __attribute__((address_space(4))) ChainParams CChain;
-    CChain& cp = *(CChain*)(uintptr_t)cpp;
-#pragma nounroll
-    for (int l = 0; l < cp.nlayers; l++) {
-        // the thread index is made opaque per iteration: otherwise every lane-only address term of the layer body (fragment
-        // offsets, swizzles, copy-out indices of BOTH wave roles) is hoisted out of this loop and kept live across it
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        ring_layer<RT, NT, KC, WM, D, true>(cp.layer[l], tid);
-        if (l + 1 < cp.nlayers) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's output stores are in L2
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned* cnt = cp.counters + l * gridDim.x + blockIdx.x;
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned budget = 1u << 21;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget) __builtin_amdgcn_s_sleep(4);
-                if (!budget) __hip_atomic_store(cp.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// XCD of every workgroup of a (gx, gy) grid of ring-sized workgroups (HW_REG_XCC_ID), for the host's placement check.
-__global__ __launch_bounds__(512) void xcc_probe_kernel(int* out)
-{
-    extern __shared__ __attribute__((aligned(16))) f32x4 ring_probe[];
-    if (threadIdx.x == 0) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        out[blockIdx.y * gridDim.x + blockIdx.x] = (int)(x & 15u);
-        ring_probe[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-}
+// (A variant that ran the hidden layers + output layer of an FC net as ONE launch, workgroups handing over between layers
+// through counters, was built in round 1, measured 2 % slower than the per-layer launches -- what a launch boundary costs
+// is start skew and stragglers, which the handshake waits for too -- and removed in round 2; see DESIGN.md.)
 
 // X(rt, nt, kc, wm, d): tile 32*rt*wm x 32*nt*(4/wm), d-deep ring
 #define PNN_RING_CFGS(X) \
@@ -761,62 +716,6 @@ hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s)
     PNN_RING_CFGS(X)
 #undef X
     return hipErrorInvalidValue;
-}
-
-// Tiles that exist as fc_chain_kernel (must be fuse-capable ring tiles).
-#define PNN_CHAIN_CFGS(X) X(1, 5, 2, 4, 4) X(1, 4, 2, 4, 4)
-
-bool fc_chain_has_cfg(int idx)
-{
-    const TileCfg t = tapgemm_ring_cfg(idx);
-#define X(r_, n_, k_, w_, d_) if (t.rt == r_ && t.nt == n_ && t.kc == k_ && t.wm == w_ && t.d == d_) return true;
-    PNN_CHAIN_CFGS(X)
-#undef X
-    return false;
-}
-
-template <int RT, int NT, int KC, int WM, int D>
-static hipError_t launch_chain(const ChainParams& cp, const ChainParams* d_cp, unsigned target, hipStream_t s)
-{
-    constexpr int BM = 32 * RT * WM, BN = 32 * NT * (4 / WM);
-    const size_t lds = tapgemm_ring_lds_bytes(TileCfg{RT, NT, KC, 316, WM, D});
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_kernel<RT, NT, KC, WM, D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const TapGemmParams& p = cp.layer[0];
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
-    pnn_launch(fc_chain_kernel<RT, NT, KC, WM, D>, grid, dim3(512), lds, s, d_cp, target);
-    return hipGetLastError();
-}
-
-hipError_t launch_fc_chain(const ChainParams& cp, const ChainParams* d_cp, unsigned target, int idx, hipStream_t s)
-{
-    if (cp.nlayers < 1 || cp.nlayers > 3 || !cp.counters || !cp.error || !d_cp) return hipErrorInvalidValue;
-    for (int l = 0; l < cp.nlayers; l++) {
-        const TapGemmParams& p = cp.layer[l];
-        if (!p.zero || p.ncls != 1 || p.SH * p.SW != 1 || p.M != cp.layer[0].M || p.Cout != cp.layer[0].Cout) return hipErrorInvalidValue;
-    }
-    const TileCfg t = tapgemm_ring_cfg(idx);
-#define X(r_, n_, k_, w_, d_) if (t.rt == r_ && t.nt == n_ && t.kc == k_ && t.wm == w_ && t.d == d_) return launch_chain<r_, n_, k_, w_, d_>(cp, d_cp, target, s);
-    PNN_CHAIN_CFGS(X)
-#undef X
-    return hipErrorInvalidValue;
-}
-
-hipError_t launch_xcc_probe(int gx, int gy, size_t lds_bytes, int* d_out, hipStream_t s)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(gx, gy), dim3(512), lds_bytes, s, d_out);
-    return hipGetLastError();
 }
 
 }  // namespace pnn

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     // Three copies of the unrolled group loop, chosen once (split-f16 only / f32 only / any mix) -- the loop runs once per launch from a cold instruction cache, its time follows its code footprint
     // (measured in the ring kernel: 7.9k -> 4.1k cycles for 20 groups).
     const bool act = p.act != 0;
+    float amax = 0.f;                                // range guard of the split outputs (pnn_device_common.h)
     auto groups = [&](auto kind_tag) {
         constexpr int kKind = decltype(kind_tag)::value;             // 0: split only, 1: f32 only, 2: general
 #pragma unroll
@@ -285,12 +286,12 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
                             v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
                         }
                         if (kKind == 0) {
-                            store_split4(p.Yhi, obase, n, v);   // split output for the next split-precision layer
+                            store_split4(p.Yhi, obase, n, v, amax);   // split output for the next split-precision layer
                         } else if (kKind == 1) {
                             *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
                         } else {
                             if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
-                            if (p.Yhi) store_split4(p.Yhi, obase, n, v);
+                            if (p.Yhi) store_split4(p.Yhi, obase, n, v, amax);
                             if (p.Yi) {
                                 int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean),
                                                     hm_round(v[3], p.mean));
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void tapgemm_sp_kernel(const TapGemmParams p)
     if (p.Yhi && !p.Y && !p.Yi) groups(std::integral_constant<int, 0>{});
     else if (p.Y && !p.Yhi && !p.Yi) groups(std::integral_constant<int, 1>{});
     else groups(std::integral_constant<int, 2>{});
+    report_range(p.range_flag, amax);
 }
 
 // X(rt, nt, kc, wm)
@@ -340,24 +342,27 @@ hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s)
 }
 
 // f32 [rows][C] -> split activations [rows][C/16][hi 16 x f16 | lo 16 x f16] for network inputs (C % 16 == 0).
-__global__ __launch_bounds__(256) void split_kernel(const float* x, long n, _Float16* out)
+__global__ __launch_bounds__(256) void split_kernel(const float* x, long n, _Float16* out, int* range_flag)
 {
+    float amax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = x[i];
+        amax = fmaxf(amax, fabsf(v));
         const _Float16 hv = (_Float16)v;
         _Float16* d = out + 2 * (i & ~15L) + (i & 15);
         d[0] = hv;
         d[16] = (_Float16)(v - (float)hv);
     }
+    report_range(range_flag, amax);
 }
 
-hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s)
+hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_flag, hipStream_t s)
 {
     (void)lo;
     if (n <= 0) return hipSuccess;
     long blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, (_Float16*)hi);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, (_Float16*)hi, range_flag);
     return hipGetLastError();
 }
 

@@ -47,6 +47,7 @@ struct TapGemmParams {
     int32_t* Yi;       // optional fused HM epilogue: (int) round(clamp(v + mean, 0, 255))
     void* Yhi;         // optional split-f16 output planes (split-precision kernel only)
     void* Ylo;
+    int* range_flag;   // raised (host-visible int) when a split-f16 output leaves the f16 range, see pnn_device_common.h
     float out_scale;   // split-precision kernel: exact power of two undoing the weight pre-scale
     unsigned x_bytes;  // size of X in bytes (< 2^31): bound of the activation buffer descriptor
     int M, SH, SW;
@@ -76,17 +77,6 @@ int tapgemm_ring_num_cfgs();
 TileCfg tapgemm_ring_cfg(int idx);
 size_t tapgemm_ring_lds_bytes(const TileCfg& t);
 bool tapgemm_ring_can_fuse(int idx);
-// A whole fully-connected net (its hidden layers + the fused output layer) in one launch: see fc_chain_kernel.
-struct ChainParams {
-    TapGemmParams layer[3];
-    int nlayers;
-    unsigned* counters;       // [3][gridDim.x], monotonic over launches
-    int* error;               // raised when a workgroup gives up waiting (host-visible memory)
-};
-bool fc_chain_has_cfg(int idx);
-// cp: host copy (validated), d_cp: the same block in device memory; target = gridDim.y * (chained launches so far incl. this one)
-hipError_t launch_fc_chain(const ChainParams& cp, const ChainParams* d_cp, unsigned target, int idx, hipStream_t s);
-hipError_t launch_xcc_probe(int gx, int gy, size_t lds_bytes, int* d_out, hipStream_t s);
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
                               hipStream_t s);
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)
@@ -95,7 +85,7 @@ TileCfg convimg_sp_cfg(int idx);
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
 bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0);   // the raw context tiles fit the weight staging area
 hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s);   // G images per workgroup, resident in LDS
-hipError_t launch_split(const float* x, long n, void* hi, void* lo, hipStream_t s);
+hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_flag, hipStream_t s);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
@@ -106,6 +96,7 @@ struct Conv1Params {
     int B, IH, IW, s, k, pad, OH, OW, Cout;
     int split;   // 1: write Y as split activations [pixel][Cout/16][hi 16 x f16 | lo 16 x f16] for the split-precision GEMM
     int band_rows;   // output rows per workgroup (set by the launcher)
+    int* range_flag; // split output only: raised when a value leaves the f16 range
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 
@@ -123,6 +114,7 @@ struct MergerParams {
     int B, C, na, nl, nout;
     int split;   // 1: write Y in the split f16 activation layout
     int one_order;   // 1: always the batch kernel (canonical_order: one summation order for every batch size)
+    int* range_flag; // split output only: raised when a value leaves the f16 range
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);
 

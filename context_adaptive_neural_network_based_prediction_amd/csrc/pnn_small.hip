@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
     __syncthreads();
     const int npix = p.OH * p.OW;
+    float amax = 0.f;                                // range guard of the split output (pnn_device_common.h)
     float* yb = p.Y + b * npix * p.Cout;
     for (int pix = oy0 * p.OW + psub; pix < oy1 * p.OW; pix += ppi) {
         const int oy = pix / p.OW, ox = pix - oy * p.OW;
@@ -53,9 +54,10 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
 #pragma unroll
             for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
         acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-        if (p.split) store_split4(p.Y, ((size_t)b * npix + pix) * p.Cout, 4 * cg, acc);
+        if (p.split) store_split4(p.Y, ((size_t)b * npix + pix) * p.Cout, 4 * cg, acc, amax);
         else *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
     }
+    if (p.split) report_range(p.range_flag, amax);
 }
 
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
     };
     part(p.A, p.na, 0);
     part(p.L, p.nl, p.na);
+    float amax = 0.f;                                // range guard of the split output (pnn_device_common.h)
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const float bv = p.bias[(size_t)(J * jq + j) * p.C + c];
@@ -330,10 +333,11 @@ __global__ __launch_bounds__(256) void merger_kernel(const MergerParams p)
         for (int m = 0; m < MB; m++)
             if (b0 + m < p.B) {
                 const float v = leaky(acc[m][j] + bv);
-                if (p.split) store_split1(p.Y, ((size_t)(b0 + m) * 16 + J * jq + j) * p.C, c, v);
+                if (p.split) store_split1(p.Y, ((size_t)(b0 + m) * 16 + J * jq + j) * p.C, c, v, amax);
                 else p.Y[((b0 + m) * 16 + J * jq + j) * p.C + c] = v;
             }
     }
+    if (p.split) report_range(p.range_flag, amax);
 }
 
 // The batch kernel on the fp32 matrix cores.  Per channel the merger is a [B x 80] x [80 x 16] product; with the channel
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
     f32x4 bv[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + (size_t)li * p.C + c0 + 4 * q);
+    float amax = 0.f;                                // range guard of the split output (pnn_device_common.h)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const long b = bg * 16 + 4 * lk + r;
@@ -408,11 +413,12 @@ __global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
                 f32x4 v;
 #pragma unroll
                 for (int i = 0; i < 4; i++) v[i] = leaky(acc[4 * q + i][r] + bv[q][i]);
-                if (SPLIT) store_split4(p.Y, pix * p.C, c0 + 4 * q, v);
+                if (SPLIT) store_split4(p.Y, pix * p.C, c0 + 4 * q, v, amax);
                 else *reinterpret_cast<f32x4*>(p.Y + pix * p.C + c0 + 4 * q) = v;
             }
         }
     }
+    if (SPLIT) report_range(p.range_flag, amax);
 }
 
 // Small batches (the in-loop single-block calls): the 80-position sum of one output is split over 4 threads (positions
@@ -444,12 +450,14 @@ __global__ __launch_bounds__(256) void merger_small_kernel(const MergerParams p)
     for (int j = 0; j < 4; j++) red[pg][j][cl] = acc[j];
     __syncthreads();
     if (pg == 0 && c < p.C) {
+        float amax = 0.f;                            // range guard of the split output (pnn_device_common.h)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float v = leaky(((red[0][j][cl] + red[1][j][cl]) + (red[2][j][cl] + red[3][j][cl])) + p.bias[(size_t)(4 * jq + j) * p.C + c]);
-            if (p.split) store_split1(p.Y, ((size_t)b * 16 + 4 * jq + j) * p.C, c, v);
+            if (p.split) store_split1(p.Y, ((size_t)b * 16 + 4 * jq + j) * p.C, c, v, amax);
             else p.Y[(b * 16 + 4 * jq + j) * p.C + c] = v;
         }
+        if (p.split) report_range(p.range_flag, amax);
     }
 }
 
@@ -487,6 +495,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
     const int na = 3 * w * w, per = 5 * w * w;
     const long total = (long)p.N * per;
     const Pel* plane = reinterpret_cast<const Pel*>(p.plane);
+    float unused = 0.f;                              // 8-bit samples minus the mean never leave the f16 range
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long tb = e / per;
         const int r = (int)(e - tb * per);
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
             if (col >= w) ok = (d.above_mask >> ((col - w) / p.unit)) & 1u;
             float v = 0.f;
             if (ok) v = (float)plane[d.origin + (long)(row - w) * d.stride + (col - w)] - p.mean;
-            if (p.split) store_split1(p.above, (size_t)tb * per, r, v);
+            if (p.split) store_split1(p.above, (size_t)tb * per, r, v, unused);
             else p.above[tb * p.pitch_above + r] = v;
         } else {
             const int rl = r - na;
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p)
             const bool ok = row < d.left_units * p.unit;
             float v = 0.f;
             if (ok) v = (float)plane[d.origin + (long)row * d.stride + (col - w)] - p.mean;
-            if (p.split) store_split1(p.above, (size_t)tb * per, r, v);          // FC row: left part follows the above part
+            if (p.split) store_split1(p.above, (size_t)tb * per, r, v, unused);  // FC row: left part follows the above part
             else p.left[tb * p.pitch_left + rl] = v;
         }
     }
@@ -540,7 +549,8 @@ __global__ __launch_bounds__(256) void gather_split4_kernel(const GatherParams p
             v = (f32x4){(float)src[0] - p.mean, (float)src[1] - p.mean, (float)src[2] - p.mean, (float)src[3] - p.mean};
         }
     }
-    store_split4(p.above, (size_t)tb * PER, r, v);
+    float unused = 0.f;                              // 8-bit samples minus the mean never leave the f16 range
+    store_split4(p.above, (size_t)tb * PER, r, v, unused);
 }
 
 // The same for f32 outputs (above / left portions of the convolutional nets, or f32 FC rows): one 16-byte store per thread.

@@ -36,6 +36,7 @@ extern "C" {
 #define PNN_E_MODEL (-3)    /* no model loaded for that width, or wrong kind */
 #define PNN_E_HIP (-4)      /* HIP runtime error */
 #define PNN_E_NOMEM (-5)
+#define PNN_E_RANGE (-6)    /* an asynchronous split-precision pass left the f16 range: its results are invalid */
 
 typedef struct pnn_ctx pnn_ctx;
 
@@ -68,9 +69,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
  * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
  * >= 1024 blocks through a fully-connected PNN with <= 64 outputs run the output layer inside the last hidden layer's
- * kernel; 0: separate launches), "chain" (0, default; 1: such a pass runs its three hidden layers and the output
- * layer as ONE launch whose workgroups hand over between layers through counters -- correct, tested, but measured no
- * faster than the per-layer launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
+ * kernel; 0: separate launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
  * _conv with n == 1, what HM issues -- are answered from a direct-mapped cache of that many MiB when the same input
  * bytes were predicted before: HM's rate-distortion search asks for the same block repeatedly; exact
  * match on the inputs, dropped whenever a model or an option changes),
@@ -93,10 +92,19 @@ float pnn_mean(const pnn_ctx* ctx);
  * the last bits, i.e. by one LSB on an exact .5 tie). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_CHAIN, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */
+/* Input-range contract of the default arithmetic ("precision" = 1): operands travel as pairs of f16 values, so every
+ * intermediate activation must satisfy |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude
+ * below that; arbitrary float inputs or models may not.  The kernels detect a violation (they never emit
+ * a silent NaN): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then repeat the pass on the exact-f32 kernels
+ * by themselves; device entry points are asynchronous, so the NEXT call on the context fails with PNN_E_RANGE, and
+ * pnn_check_range -- which waits for `stream` -- tells right away (returns PNN_OK or PNN_E_RANGE; *host_fallbacks, optional,
+ * = how many host calls took the exact-f32 repeat so far). */
+int pnn_check_range(pnn_ctx* ctx, void* stream, long* host_fallbacks);
+
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
 int pnn_num_split_configs(void);
 /* Hits / misses of the "cache_mb" prediction cache since the option was last set. */

@@ -43,6 +43,9 @@ int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const f
 /* == Session::Run on the server: the float prediction [w][w] (what the TensorFlow look-alike of pnn_tf_compat.h binds when
  * PNN_SERVICE_SOCKET is set, so that an UNMODIFIED HM process is served by the batching service). */
 int pnn_client_predict_f32(pnn_client* c, int width, const float* above, const float* left, float* out);
+/* Repeated requests (same width, same input bytes -- HM's RD search re-asks) are answered from a
+ * client-side cache of $PNN_CACHE_MB MiB (default 64, 0 = off) without a round trip; hits / misses so far. */
+int pnn_client_cache_stats(const pnn_client* c, long* hits, long* misses);
 void pnn_client_close(pnn_client* c);
 
 #ifdef __cplusplus

@@ -152,6 +152,7 @@ public:
         if (std::getenv("PNN_STATS") && width_) {
             long hits = 0, misses = 0;
             if (ctx_) pnn_cache_stats(ctx_, &hits, &misses);
+            if (client_) pnn_client_cache_stats(client_, &hits, &misses);
             std::fprintf(stderr, "[pnn] session width %d (%s%s): %ld Run calls, %ld answered from the cache\n", width_,
                          is_fc_ ? "fully-connected" : "convolutional", client_ ? ", via service" : "", runs_, hits);
         }

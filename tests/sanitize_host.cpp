@@ -1,0 +1,198 @@
+// AddressSanitizer / UBSan driver for the host-side code that ships in libpnn_hip.so without touching the GPU
+// (csrc/pnn_host.cpp: context gather, descriptor builder, model-table parser; csrc/pnn_service.cpp: batching server and
+// client) and for the CPU oracle (oracle/pnn_oracle.c).  Built and run by `make -C .../csrc sanitize`
+// (tests/test_host.py::test_host_code_under_sanitizers); any report makes the process exit non-zero.
+// SURVEY.md section 5 asked for exactly this; GPU ASan is not available on the pool.
+#include "pnn_hip.h"
+#include "pnn_service.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <unistd.h>
+
+extern "C" {
+// oracle/pnn_oracle.c
+int oracle_extract_context(const int32_t* roi_origin, float* above, float* left, const uint8_t* flags, int n_avail, int unit_w,
+                           int unit_h, int above_units, int left_units, int tu_w, int tu_h, int pic_stride, float mean);
+long oracle_param_count(int w, int is_fc);
+int oracle_fc_forward(const float* params, int w, const float* ctx, int B, float* out);
+int oracle_conv_forward(const float* params, int w, const float* above, const float* left, int B, float* out);
+void oracle_epilogue(const float* pred, long n, float mean, int32_t* dst);
+uint32_t oracle_block_cost(const int32_t* org, int org_stride, const int32_t* cur, int cur_stride, int w, int hadamard);
+// the one GPU entry point pnn_service.cpp references; never called here (pnn_service_run_backend gets a stand-in)
+int pnn_predict_f32_pel(pnn_ctx*, int, const float*, const float*, int, float*, int32_t*) { return PNN_E_HIP; }
+}
+namespace pnn { void set_create_error(const std::string&) {} }
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed at line %d: %s\n", __LINE__, #cond); exit(1); } } while (0)
+
+static unsigned rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+static void gather_cases()
+{
+    unsigned seed = 1;
+    for (int it = 0; it < 400; it++) {
+        const int w = 4 << (rnd(seed) % 5), unit = (it % 3 == 0 && w <= 32) ? 2 : 4, units = 2 * w / unit;
+        const int H = 3 * w, S = 3 * w + (int)(rnd(seed) % 7);        // the context exactly fills the plane: any overrun is caught
+        std::vector<int32_t> plane((size_t)H * S);
+        for (auto& v : plane) v = (int32_t)(rnd(seed) % 256);
+        std::vector<uint8_t> flags(2 * units + 1, 1);
+        if (it % 2) { for (auto& f : flags) f = rnd(seed) & 1; flags[units] = 1; }
+        int n_avail = 0;
+        for (uint8_t f : flags) n_avail += f;
+        std::vector<float> a((size_t)w * 3 * w), l((size_t)2 * w * w), a2(a.size()), l2(l.size());
+        const int32_t* origin = plane.data() + (size_t)w * S + w;
+        CHECK(pnn_extract_context(origin, a.data(), l.data(), flags.data(), n_avail, unit, unit, units, units, w, w, S, 117.9f) == 0);
+        CHECK(oracle_extract_context(origin, a2.data(), l2.data(), flags.data(), n_avail, unit, unit, units, units, w, w, S, 117.9f) == 0);
+        CHECK(!memcmp(a.data(), a2.data(), a.size() * 4) && !memcmp(l.data(), l2.data(), l.size() * 4));
+        pnn_tb_dev d;
+        CHECK(pnn_make_tb_desc(&d, (int64_t)w * S + w, S, flags.data(), n_avail, units, units) == 0);
+    }
+    uint8_t f[5] = {1, 1, 0, 1, 1};
+    int32_t px[64] = {0};
+    float o[64];
+    CHECK(pnn_extract_context(px + 32, o, o, f, 4, 4, 4, 2, 2, 4, 4, 8, 0.f) == -1);      // corner unavailable
+    CHECK(pnn_extract_context(nullptr, o, o, f, 4, 4, 4, 2, 2, 4, 4, 8, 0.f) == -1);
+    pnn_tb_dev d;
+    CHECK(pnn_make_tb_desc(&d, 0, 8, f, 4, 2, 2) == -1);
+}
+
+static void table_cases(const char* dir)
+{
+    const std::string path = std::string(dir) + "/table.txt";
+    const char* texts[] = {
+        "4,0,0,a.pnnw\n\n  \n8;0;0; b.pnnw \n16 , 1 ,, 0 ;;c.pnnw",     // blank lines, mixed delimiters, no final newline
+        "", "\n\n", "4,0,0", "x,0,0,p\n", "4,0,0," , ",,,,\n", "4,0,0,a\r\n8,0,0,b\r\n",
+    };
+    const int expect[] = {3, 0, 0, PNN_E_IO, PNN_E_IO, PNN_E_IO, PNN_E_IO, 2};
+    for (size_t i = 0; i < sizeof texts / sizeof texts[0]; i++) {
+        FILE* fp = fopen(path.c_str(), "wb");
+        CHECK(fp);
+        fwrite(texts[i], 1, strlen(texts[i]), fp);
+        fclose(fp);
+        int w[8], pr[8], ch[8];
+        const char* p[8];
+        const int n = pnn_parse_model_table(path.c_str(), w, pr, ch, p, 8);
+        if (n != expect[i]) { fprintf(stderr, "table case %zu: got %d, expected %d\n", i, n, expect[i]); exit(1); }
+        if (i == 0) CHECK(w[2] == 16 && pr[2] == 1 && ch[2] == 0 && !strcmp(p[1], "b.pnnw") && !strcmp(p[2], "c.pnnw"));
+        CHECK(pnn_parse_model_table(path.c_str(), w, pr, ch, p, 1) <= 1);              // max_entries respected
+    }
+    CHECK(pnn_parse_model_table((std::string(dir) + "/absent.txt").c_str(), nullptr, nullptr, nullptr, nullptr, 0) == PNN_E_IO);
+    unlink(path.c_str());
+}
+
+static int sum_backend(void*, int width, const float* above, const float* left, int n, int32_t* dst, float* out)
+{
+    const int w2 = width * width, na = (left ? 3 : 5) * w2;
+    for (int i = 0; i < n; i++) {
+        float s = 0.f;
+        for (int k = 0; k < na; k++) s += above[(size_t)i * na + k];
+        if (left) for (int k = 0; k < 2 * w2; k++) s += left[(size_t)i * 2 * w2 + k];
+        for (int k = 0; k < w2; k++) {
+            if (dst) dst[(size_t)i * w2 + k] = (int32_t)s + k;
+            if (out) out[(size_t)i * w2 + k] = s + 0.5f * k;
+        }
+    }
+    return 0;
+}
+
+static void service_cases(const char* dir)
+{
+    const std::string sock = std::string(dir) + "/pnn_san.sock";
+    volatile int stop = 0;
+    long stats[4] = {0, 0, 0, 0};
+    int rc_server = -99;
+    std::thread server([&] { rc_server = pnn_service_run_backend(sock.c_str(), sum_backend, nullptr, 8, 300, &stop, stats); });
+    std::atomic<int> bad{0};
+    auto client = [&](int k) {
+        pnn_client* c = nullptr;
+        for (int t = 0; t < 500 && pnn_client_connect(&c, sock.c_str()) != 0; t++) usleep(2000);
+        if (!c) { bad++; return; }
+        unsigned seed = 100 + k;
+        for (int it = 0; it < 60; it++) {
+            const int w = 4 << ((k + it) % 4), w2 = w * w;
+            const bool conv = w >= 16;
+            std::vector<float> a((conv ? 3 : 5) * w2), l(conv ? 2 * w2 : 0);
+            float s = 0.f;
+            for (auto& v : a) { v = (float)(rnd(seed) % 7); s += v; }
+            for (auto& v : l) { v = (float)(rnd(seed) % 5); s += v; }
+            std::vector<int32_t> pel((size_t)w * (w + 3), -1);
+            std::vector<float> f32(w2);
+            if (pnn_client_predict_pel(c, w, a.data(), conv ? l.data() : nullptr, pel.data(), w + 3) != 0) bad++;
+            if (pnn_client_predict_f32(c, w, a.data(), conv ? l.data() : nullptr, f32.data()) != 0) bad++;
+            for (int y = 0; y < w; y++)
+                for (int x = 0; x < w + 3; x++)
+                    if (pel[(size_t)y * (w + 3) + x] != (x < w ? (int32_t)s + y * w + x : -1)) bad++;
+            for (int i = 0; i < w2; i++) if (f32[i] != s + 0.5f * i) bad++;
+            if (it % 10 == 9 && pnn_client_predict_f32(c, w, a.data(), conv ? l.data() : nullptr, f32.data()) != 0) bad++;   // cache hit
+        }
+        long hits = 0, misses = 0;
+        pnn_client_cache_stats(c, &hits, &misses);
+        if (hits < 6) bad++;
+        pnn_client_close(c);
+    };
+    std::vector<std::thread> ts;
+    for (int k = 0; k < 5; k++) ts.emplace_back(client, k);
+    // a client that dies in the middle of a request, and one that talks nonsense
+    {
+        sockaddr_un addr;
+        memset(&addr, 0, sizeof addr);
+        addr.sun_family = AF_UNIX;
+        strcpy(addr.sun_path, sock.c_str());
+        for (int kind = 0; kind < 2; kind++) {
+            const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+            for (int t = 0; t < 500 && connect(fd, (sockaddr*)&addr, sizeof addr) != 0; t++) usleep(2000);
+            const unsigned hdr[5] = {kind ? 0x324e4e50u : 0x12345678u, 4u, 80u, 0u, 0u};
+            (void)!write(fd, hdr, kind ? 20 : 20);
+            if (kind) { float half[40] = {0}; (void)!write(fd, half, sizeof half); }    // half a payload, then gone
+            usleep(20000);
+            close(fd);
+        }
+    }
+    for (auto& t : ts) t.join();
+    stop = 1;
+    server.join();
+    CHECK(rc_server == 0);
+    CHECK(bad == 0);
+    CHECK(stats[0] == 5 * 60 * 2 && stats[3] == 7);
+}
+
+static void oracle_cases()
+{
+    unsigned seed = 7;
+    for (int cfg = 0; cfg < 4; cfg++) {
+        const int w = cfg < 2 ? 4 << cfg : 4 << (cfg - 2), is_fc = cfg < 2, B = 3;
+        const long np = oracle_param_count(w, is_fc);
+        std::vector<float> params(np), a((size_t)B * 3 * w * w), l((size_t)B * 2 * w * w), ctx((size_t)B * 5 * w * w), out((size_t)B * w * w);
+        for (auto& v : params) v = ((int)(rnd(seed) % 2001) - 1000) * 2e-5f;
+        for (auto& v : a) v = (float)(rnd(seed) % 256) - 117.9f;
+        for (auto& v : l) v = (float)(rnd(seed) % 256) - 117.9f;
+        for (auto& v : ctx) v = (float)(rnd(seed) % 256) - 117.9f;
+        CHECK((is_fc ? oracle_fc_forward(params.data(), w, ctx.data(), B, out.data()) : oracle_conv_forward(params.data(), w, a.data(), l.data(), B, out.data())) == 0);
+        std::vector<int32_t> pel(out.size());
+        oracle_epilogue(out.data(), (long)out.size(), 117.9f, pel.data());
+        for (int32_t v : pel) CHECK(v >= 0 && v <= 255);
+        for (float v : out) CHECK(std::isfinite(v));
+        CHECK(oracle_block_cost(pel.data(), w, pel.data(), w, w, 1) == 0);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const char* dir = argc > 1 ? argv[1] : "/tmp";
+    gather_cases();
+    table_cases(dir);
+    service_cases(dir);
+    oracle_cases();
+    puts("sanitize_host: ok");
+    return 0;
+}

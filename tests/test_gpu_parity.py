@@ -404,27 +404,179 @@ def test_batching_service_on_gpu(pnn, tmp_path):
     assert stats["requests"] == n and stats["largest_batch"] >= 2
 
 
-def test_chained_fc_kernel(pnn, oracle, precision):
-    """Option "chain": the hidden layers + output layer of a big FC pass in one launch with inter-layer handshakes between
-    the workgroups of a row tile.  Repeatable bit for bit (a missed handshake would show as run-to-run differences), and
-    equal to the oracle and to the per-layer launches within the float tolerance."""
+def _natural_contexts(w, n, seed):
+    """Contexts cut from a smooth synthetic picture with HM-style availability (what the trained nets were made for)."""
+    from oracle import pnn_oracle as O
+    plane = util.make_plane(192, 256, seed=seed)
+    xs, ys, flags = util.make_tbs(192, 256, w, n, seed=seed + 1, partial_fraction=0.4)
+    ab = np.zeros((n, w, 3 * w), np.float32)
+    lf = np.zeros((n, 2 * w, w), np.float32)
+    for i in range(n):
+        _, ab[i], lf[i] = O.extract_context(plane, int(xs[i]), int(ys[i]), w, flags[i], util.MEAN)
+    return ab, lf
+
+
+@pytest.mark.parametrize("w", [4, 8])
+def test_trained_checkpoints_through_the_split_kernels(pnn, oracle, precision, w):
+    """The reference's two trained models on the 3 x f16 split-product kernels (ring / register-staged / LDS-resident-image),
+    the default arithmetic of every batched call: 1024 natural-like contexts in one pass (the batch rule sends that to the
+    split kernels), and the committed 8 contexts with `split_min_px` = 0 and under `canonical_order` (which pin the split
+    kernels at any batch size).  Float predictions within FLOAT_ATOL of the oracle, Pel within one LSB."""
     if precision != "split_f16":
-        pytest.skip("split-precision path only")
-    w, n = 8, 4096
-    params = util.make_params(w, True, 71, out_gain=util.out_gain(w, True))
-    above, left = util.make_contexts(w, n, 72)
-    ctx = util.flatten_fc(above, left)
-    net = pnn.PredictionNeuralNetwork(n, w, True, params=params)
-    ref = net.predict(ctx).copy()
-    net.set_option("chain", 1)
-    first = net.predict(ctx).copy()
-    assert net.last_call_stats()["launches"] == 3                    # split + chained kernel + reduce (the context arrives as f32 here)
-    for _ in range(10):
-        assert np.array_equal(net.predict(ctx), first)
-    np.testing.assert_allclose(first, ref, rtol=0, atol=FLOAT_ATOL)
-    idx = np.random.RandomState(2).choice(n, 64, replace=False)
-    np.testing.assert_allclose(first[idx, ..., 0], oracle.fc_forward(params, w, ctx[idx]), rtol=0, atol=FLOAT_ATOL)
-    _check_pel(net.predict_pel(ctx)[idx], oracle.epilogue(oracle.fc_forward(params, w, ctx[idx]), util.MEAN))
+        pytest.skip("split-precision kernels only")
+    path = os.path.join(GOLD, "conv%d_single.pnnw" % w)
+    flat = wts.load_pnnw(path)[0]
+    n = 1024
+    ab, lf = _natural_contexts(w, n, 300 + w)
+    net = pnn.PredictionNeuralNetwork(n, w, False, path_to_model=path)
+    want = oracle.conv_forward(flat, w, ab, lf)
+    got = net.predict(ab, lf)
+    assert net.last_call_stats()["gemm_launches"] >= 3
+    np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=FLOAT_ATOL)
+    _check_pel(net.predict_pel(ab, lf), oracle.epilogue(want, util.MEAN))
+    assert want.max() - want.min() > 60                              # real pictures, not a flat answer
+    g = np.load(os.path.join(GOLD, "nets.npz"))
+    for opt in ("split_min_px", "canonical_order"):
+        net2 = pnn.PredictionNeuralNetwork(8, w, False, path_to_model=path)
+        net2.set_option(opt, 0 if opt == "split_min_px" else 1)
+        got8 = net2.predict(g["real%d_above" % w], g["real%d_left" % w])
+        np.testing.assert_allclose(got8[..., 0], g["real%d_out" % w], rtol=0, atol=FLOAT_ATOL)
+        _check_pel(net2.predict_pel(g["real%d_above" % w], g["real%d_left" % w]), oracle.epilogue(g["real%d_out" % w], util.MEAN))
+        net2.close()
+
+
+@pytest.mark.parametrize("w,is_fc,n", [(8, True, 600), (8, True, 1), (16, False, 90)])
+def test_f16_range_guard(pnn, oracle, precision, w, is_fc, n):
+    """Split precision carries activations as f16 pairs: |v| >= 65504 must never turn into a silent NaN -> 255.  First-layer
+    weights are scaled until hidden activations pass 1e5 (the last layer is scaled back, so the prediction stays in range):
+    host calls must still match the oracle (they repeat the pass on the exact-f32 kernels and count it), device calls
+    must report PNN_E_RANGE."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, is_fc, 81, out_gain=util.out_gain(w, is_fc)).copy()
+    specs = wts.tensor_specs(w, is_fc)
+    sizes = [int(np.prod(sh)) for _, sh, _ in specs]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    gain = 3000.0 if is_fc else 30000.0
+    params[offs[0]:offs[2]] *= gain                                  # first layer: weights and biases (LeakyReLU is positively homogeneous)
+    params[offs[-3]:offs[-2]] /= gain                                # last layer's weights undo it
+    above, left = util.make_contexts(w, n, 82)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    net.set_option("canonical_order", 1)                             # split kernels at every batch size
+    if is_fc:
+        x = (util.flatten_fc(above, left),)
+        want = oracle.fc_forward(params, w, x[0])
+    else:
+        x = (above, left)
+        want = oracle.conv_forward(params, w, above, left)
+    got = net.predict(*x)
+    fallbacks = ctypes.c_long()
+    assert L.pnn_check_range(net.ctx, None, ctypes.byref(fallbacks)) == 0
+    if precision == "split_f16":
+        assert fallbacks.value == 1, "hidden activations were meant to leave the f16 range"
+    else:
+        assert fallbacks.value == 0
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=FLOAT_ATOL * 4)   # 1e5-sized intermediates: a little more float noise
+    _check_pel(net.predict_pel(*x), oracle.epilogue(want, util.MEAN))
+    # device entry point: asynchronous, so the violation is reported, not repaired
+    ts = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in x]
+    out = net.predict(*[t if is_fc else t[..., None] for t in ts])
+    rc = L.pnn_check_range(net.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None)
+    if precision == "split_f16":
+        assert rc == -6 and b"f16 range" in L.pnn_last_error(net.ctx)
+        assert L.pnn_check_range(net.ctx, None, None) == 0           # reported once
+        out = net.predict(*[t if is_fc else t[..., None] for t in ts])
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.PnnError):                           # ... or by the next call on the context
+            net.predict(*[t if is_fc else t[..., None] for t in ts])
+        net.set_option("precision", 0)
+        out = net.predict(*[t if is_fc else t[..., None] for t in ts])
+        assert L.pnn_check_range(net.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None) == 0
+    else:
+        assert rc == 0
+    np.testing.assert_allclose(out.cpu().numpy()[..., 0], want, rtol=0, atol=FLOAT_ATOL * 4)
+
+
+def test_reference_gather_fixtures_through_the_hip_gather(pnn):
+    """tests/golden/gather_ref.npz -- outputs of the REFERENCE's own extract_context_portions (the tests.cpp ramp scenarios
+    and 40 seeded cases incl. flag patterns with holes) -- straight through pnn_make_tb_desc + pnn_gather_device, from
+    int32 and from uint8 planes: bit-exact."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    g = np.load(os.path.join(GOLD, "gather_ref.npz"))
+    nets = {}
+    for k in range(int(g["n_cases"])):
+        w, mean = int(g["c%d_w" % k]), float(g["c%d_mean" % k])
+        plane, (x, y), flags = g["c%d_plane" % k], g["c%d_xy" % k], g["c%d_flags" % k]
+        key = (w <= 8, mean)
+        if key not in nets:
+            nets[key] = pnn.PredictionNeuralNetwork(1, 4, True, params=util.make_params(4, True, 1), mean_training=mean)
+        net = nets[key]
+        units = 2 * w // 4
+        tb = (_lib.TbDev * 1)()
+        assert L.pnn_make_tb_desc(ctypes.byref(tb[0]), int(y) * plane.shape[1] + int(x), plane.shape[1],
+                                  flags.ctypes.data_as(_lib.u8p), int(flags.sum()), units, units) == 0
+        d_tbs = torch.from_numpy(np.frombuffer(tb, dtype=np.uint8).copy()).cuda()
+        variants = [(plane.astype(np.int32), 4)]
+        if plane.max() < 256:
+            variants.append((plane.astype(np.uint8), 1))
+        for pl, pel_bytes in variants:
+            d_plane = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+            d_above = torch.full((w, 3 * w), float("nan"), device="cuda")
+            d_left = torch.full((2 * w, w), float("nan"), device="cuda")
+            assert L.pnn_gather_device(net.ctx, w, 4, d_plane.data_ptr(), pel_bytes, d_tbs.data_ptr(), 1, d_above.data_ptr(), 3 * w * w,
+                                       d_left.data_ptr(), 2 * w * w, None) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(d_above.cpu().numpy(), g["c%d_above" % k]), "case %d (w %d, pel_bytes %d): above differs" % (k, w, pel_bytes)
+            assert np.array_equal(d_left.cpu().numpy(), g["c%d_left" % k]), "case %d (w %d, pel_bytes %d): left differs" % (k, w, pel_bytes)
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+@pytest.mark.parametrize("holes", [False, True])
+def test_gather_chroma_units(pnn, oracle, w, holes):
+    """Chroma planes of 4:2:0 video reach the PNN with unitWidth = unitHeight = 2 (TEncSearch.cpp:1197-1200):
+    availability flags then cover 2-pixel units, 2w/2 of them per side.  HIP gather == oracle (== reference, test_oracle)."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    n, unit = 150, 2
+    units = 2 * w // unit
+    plane = util.make_plane(200, 280, seed=40 + w, pad=4)
+    rng = np.random.RandomState(50 + w)
+    xs = 4 * rng.randint((w + 3) // 4, (280 - 2 * w) // 4 + 1, n)
+    ys = 4 * rng.randint((w + 3) // 4, (200 - 2 * w) // 4 + 1, n)
+    flags = np.ones((n, 2 * units + 1), np.uint8)
+    for i in range(n):
+        if rng.rand() < 0.7:
+            if holes:
+                flags[i] = rng.randint(0, 2, 2 * units + 1)
+                flags[i, units] = 1
+            else:
+                kl, ka = rng.randint(0, units // 2 + 1, 2)
+                if kl:
+                    flags[i, :kl] = 0
+                if ka:
+                    flags[i, 2 * units + 1 - ka:] = 0
+    net = pnn.PredictionNeuralNetwork(n, 4, True, params=util.make_params(4, True, 1))
+    arr = (_lib.TbDev * n)()
+    for i in range(n):
+        assert L.pnn_make_tb_desc(ctypes.byref(arr[i]), int(ys[i]) * plane.shape[1] + int(xs[i]), plane.shape[1],
+                                  flags[i].ctypes.data_as(_lib.u8p), int(flags[i].sum()), units, units) == 0
+    d_plane = torch.from_numpy(plane).cuda()
+    d_tbs = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).cuda()
+    d_above = torch.full((n, w, 3 * w), float("nan"), device="cuda")
+    d_left = torch.full((n, 2 * w, w), float("nan"), device="cuda")
+    assert L.pnn_gather_device(net.ctx, w, unit, d_plane.data_ptr(), 4, d_tbs.data_ptr(), n, d_above.data_ptr(), 3 * w * w,
+                               d_left.data_ptr(), 2 * w * w, None) == 0
+    torch.cuda.synchronize()
+    ga, gl = d_above.cpu().numpy(), d_left.cpu().numpy()
+    for i in range(n):
+        rc, a, l = oracle.extract_context(plane, int(xs[i]), int(ys[i]), w, flags[i], util.MEAN, unit=unit)
+        assert rc == 0
+        assert np.array_equal(ga[i], a) and np.array_equal(gl[i], l), "TB %d differs" % i
 
 
 def _random_size_cases():

@@ -402,3 +402,58 @@ def test_frozen_graphdef_reader(tmp_path):
     assert np.array_equal(wts.load_pnnw(out)[0], flat)
     with pytest.raises((KeyError, ValueError)):
         wts.params_from_frozen_graph(path, 8, False)       # a width-8 net does not match this file's tensors
+
+
+def test_batching_service_survives_bad_clients(tmp_path):
+    """One client that stops in the middle of a header, one that sends a malformed header and one that never reads its
+    reply must not delay or break the others (the server is non-blocking with per-client buffers); a repeated request is
+    answered from the client-side cache without reaching the server."""
+    import socket
+    import struct
+    import time
+    from context_adaptive_neural_network_based_prediction_amd import service
+
+    def backend(width, above, left):
+        return np.tile(np.round(above.sum(axis=1)).astype(np.int32)[:, None, None], (1, width, width))
+
+    sock = str(tmp_path / "pnn.sock")
+    srv = service.serve_in_thread(sock, backend=backend, max_batch=8, window_us=500)
+    good = service.Client(sock)
+    stalled = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    stalled.connect(sock)
+    stalled.sendall(b"PNN2\x04\x00")                      # 6 of 20 header bytes, then silence
+    junk = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    junk.connect(sock)
+    junk.sendall(struct.pack("<IiIII", 0xdeadbeef, 4, 80, 0, 0))
+    deaf = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    deaf.connect(sock)
+    deaf.sendall(struct.pack("<IiIII", 0x324e4e50, 4, 80, 0, 0) + np.ones(80, np.float32).tobytes())   # valid; reply never read
+    t0 = time.time()
+    for i in range(50):
+        a = np.full(80, float(i), np.float32)
+        assert np.array_equal(good.predict_pel(4, a), np.full((4, 4), 80 * i, np.int32))
+    assert time.time() - t0 < 5.0, "the good client was held up by the bad ones"
+    assert junk.recv(16) == b""                            # malformed header: connection closed by the server
+    hits, misses = ctypes.c_long(), ctypes.c_long()
+    L = _lib.lib()
+    again = good.predict_pel(4, np.full(80, 7.0, np.float32))
+    assert np.array_equal(again, np.full((4, 4), 560, np.int32))
+    L.pnn_client_cache_stats(good._c, ctypes.byref(hits), ctypes.byref(misses))
+    assert hits.value == 1 and misses.value == 50
+    good.close()
+    stats = srv.stop()
+    assert srv.rc == 0 and stats["requests"] == 51 and stats["clients"] == 4   # 50 + the deaf client's one
+    for s in (stalled, junk, deaf):
+        s.close()
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """the host-only part of the library (context gather, descriptor builder, model-table parser,
+    batching server + client incl. misbehaving clients) and the CPU oracle under AddressSanitizer + UBSan
+    (`make -C csrc sanitize`, driver tests/sanitize_host.cpp).  Any report aborts the driver."""
+    csrc = os.path.join(ROOT, "context_adaptive_neural_network_based_prediction_amd", "csrc")
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(["make", "-C", csrc, "sanitize"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "sanitize_host: ok" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

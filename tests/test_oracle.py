@@ -55,6 +55,45 @@ def test_gather_live_against_reference_build(oracle):
         assert r0[0] == r1[0] == 0 and np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])
 
 
+def _chroma_flags(rng, units, holes):
+    flags = np.ones(2 * units + 1, np.uint8)
+    if holes:
+        flags = rng.randint(0, 2, 2 * units + 1).astype(np.uint8)
+        flags[units] = 1
+    else:
+        kl, ka = rng.randint(0, units // 2 + 1, 2)
+        if kl:
+            flags[:kl] = 0
+        if ka:
+            flags[2 * units + 1 - ka:] = 0
+    return flags
+
+
+def test_gather_chroma_units_against_reference_build(oracle):
+    """unitWidth = unitHeight = 2 (chroma planes of 4:2:0 video, TEncSearch.cpp:1197-1200 / SURVEY E6): the oracle and the
+    shipped host function pnn_extract_context against the reference's own function, 2w/2 units per side."""
+    import ctypes
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    L = _lib.lib()
+    rng = np.random.RandomState(5)
+    for j in range(120):
+        w = int(rng.choice([4, 8, 16, 32]))
+        units = 2 * w // 2
+        plane = util.make_plane(3 * w + 8, 3 * w + 16, seed=1000 + j)
+        x, y = w + 4 * int(rng.randint(0, 3)), w + 4 * int(rng.randint(0, 2))
+        flags = _chroma_flags(rng, units, holes=j % 2 == 0)
+        r0 = oracle.extract_context(plane, x, y, w, flags, util.MEAN, unit=2, use_ref=True)
+        r1 = oracle.extract_context(plane, x, y, w, flags, util.MEAN, unit=2)
+        assert r0[0] == r1[0] == 0 and np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2]), j
+        above, left = np.full((w, 3 * w), np.nan, np.float32), np.full((2 * w, w), np.nan, np.float32)
+        origin = ctypes.cast(plane.ctypes.data + 4 * (y * plane.shape[1] + x), _lib.i32p)
+        assert L.pnn_extract_context(origin, above.ctypes.data_as(_lib.f32p), left.ctypes.data_as(_lib.f32p), flags.ctypes.data_as(_lib.u8p),
+                                     int(flags.sum()), 2, 2, units, units, w, w, plane.shape[1], ctypes.c_float(util.MEAN)) == 0
+        assert np.array_equal(above, r0[1]) and np.array_equal(left, r0[2]), j
+
+
 def test_gather_known_answers_of_reference_tests(oracle):
     """Expected-buffer strings printed by hevc/hm_common/c++/source_test/tests.cpp:340-347,387-394,434-441 (w = 4, 8)
     and :518,532,573,587,629,642 (w = 16); '...' in those strings stands for the obvious continuation."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the working tree against a git revision ON ONE BOX (box-to-box variance is +-4 %, more than most single changes):
-#   here:        ./tools_ab.sh build [rev]      builds <rev> (default HEAD) into build_tmp/libpnn_hip_prev.so
-#   on the box:  gpurun -- './tools_ab.sh run [workload ...]'   alternates the two libraries, 3 rounds
+#   here:        ./tools/ab.sh build [rev]      builds <rev> (default HEAD) into build_tmp/libpnn_hip_prev.so
+#   on the box:  gpurun -- './tools/ab.sh run [workload ...]'   alternates the two libraries, 3 rounds
 set -e
 if [ "$1" = "build" ]; then
   rev=${2:-HEAD}

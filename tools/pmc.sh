@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <bench args...>   -- separate rocprofv3 --pmc passes (never mixed with tracing)
+# usage: tools/pmc.sh <tag> <bench args...>   -- separate rocprofv3 --pmc passes (never mixed with tracing)
 export TMPDIR=/tmp
 tag=$1; shift
 i=0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSVs written by tools_pmc.sh: per kernel (name, grid), mean counter values per dispatch."""
+"""Summarise rocprofv3 --pmc CSVs written by tools/pmc.sh: per kernel (name, grid), mean counter values per dispatch."""
 import collections, csv, glob, sys
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

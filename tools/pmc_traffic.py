@@ -2,7 +2,7 @@
 """HBM traffic per launch of the split-precision GEMM kernels from the separate FETCH_SIZE / WRITE_SIZE --pmc passes
 (gpurun_out/pmc_<workload>/p3, p4), corrected as the MI355X guide prescribes (gfx950: FETCH_SIZE counts 64-byte
 units of a 128-byte-wide read path: x2; both counters are in KiB).  Writes profiles/pmc_traffic.json, which bench.py
-reports as roofline.traffic.   usage: tools_pmc_traffic.py <out.json> <workload> [<workload> ...]"""
+reports as roofline.traffic.   usage: tools/pmc_traffic.py <out.json> <workload> [<workload> ...]"""
 import collections, csv, glob, json, sys
 GEMM = ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")
 out = {}

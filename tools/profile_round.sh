@@ -8,7 +8,7 @@ out=gpurun_out/profiles_$r
 mkdir -p $out
 for wl in fc8 conv16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > $out/${wl}_trace.log 2>&1
-  python3 tools_trace_summary.py $out/${wl}_trace > $out/${wl}_kernel_summary.txt
+  python3 tools/trace_summary.py $out/${wl}_trace > $out/${wl}_kernel_summary.txt
   cp $out/${wl}_trace/*/*_kernel_stats.csv $out/${wl}_kernel_stats.csv
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" \
@@ -17,13 +17,13 @@ for wl in fc8 conv16; do
     i=$((i+1))
     PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > $out/${wl}_pmc_p$i.log 2>&1
   done
-  python3 tools_pmc_summary.py $wl > $out/${wl}_pmc_summary.txt
+  python3 tools/pmc_summary.py $wl > $out/${wl}_pmc_summary.txt
   rm -rf $out/${wl}_trace
 done
-python3 tools_pmc_traffic.py $out/pmc_traffic.json fc8 conv16 > /dev/null
+python3 tools/pmc_traffic.py $out/pmc_traffic.json fc8 conv16 > /dev/null
 for wl in fc8 conv16; do   # timeline of one steady-state step (rule-based tiles: no tuning launches in the trace)
   PNN_AUTOTUNE=0 rocprofv3 --kernel-trace --output-format csv -d $out/${wl}_tl -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-  python3 tools_trace_gaps.py $out/${wl}_tl > $out/${wl}_step_timeline.txt
+  python3 tools/trace_gaps.py $out/${wl}_tl > $out/${wl}_step_timeline.txt
   rm -rf $out/${wl}_tl
 done
 python3 bench.py --steps 100 --warmup 10 > $out/bench_fc8.json 2> $out/bench_fc8.err
