@@ -4,6 +4,47 @@ exchanges are the bench barrier / max-over-ranks clock and the optional result g
 (the reference itself has no multi-device code.)"""
 
 
+import os
+import time
+
+
+def rank_env(environ=None):
+    """(rank, local_rank, world_size) as torch.distributed.run exports them; (0, 0, 1) for a plain process."""
+    e = os.environ if environ is None else environ
+    return int(e.get("RANK", "0")), int(e.get("LOCAL_RANK", "0")), int(e.get("WORLD_SIZE", "1"))
+
+
+def init_ranks(backend, device=None):
+    """Joins the job's process group when WORLD_SIZE > 1 (backend "nccl" = RCCL on the GPUs, "gloo" on the CPU) and
+    returns the torch.distributed module, or None for a single process.  Rendezvous defaults to 127.0.0.1."""
+    rank, _, world = rank_env()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kw = {"device_id": device} if device is not None else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def timed_steps(step, n_steps, sync, dist=None, device=None):
+    """The bench contract's timed region: barrier + device synchronisation, EXACTLY n_steps calls of `step`, device
+    synchronisation + barrier, and the job's time = the MAX over ranks (seconds, the same value on every rank).
+    `sync` waits for this rank's device work (torch.cuda.synchronize on a GPU rank, a no-op on the CPU)."""
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    return max_over_ranks(time.perf_counter() - t0, dist, device)
+
+
 def shard_bounds(n_items, rank, world_size):
     """[begin, end) of `rank`'s contiguous shard; the first n % world ranks take one extra item."""
     if world_size <= 0 or not 0 <= rank < world_size:

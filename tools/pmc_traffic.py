@@ -4,9 +4,11 @@
 units of a 128-byte-wide read path: x2; both counters are in KiB).  Writes profiles/pmc_traffic.json, which bench.py
 reports as roofline.traffic.   usage: tools/pmc_traffic.py <out.json> <workload> [<workload> ...]"""
 import collections, csv, glob, json, sys
-GEMM = ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")
+GEMM_SPLIT = ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")
+GEMM_F32 = ("tapgemm_kernel", "tapgemm32_kernel", "tapgemm_splitk_kernel")
 out = {}
-for wl in sys.argv[2:]:
+for wl in sys.argv[2:]:                      # "<workload>" = default (split) arithmetic, "<workload>_f32" = PNN_PRECISION=0 passes
+    GEMM = GEMM_F32 if wl.endswith("_f32") else GEMM_SPLIT
     per = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
     names = collections.Counter()
     for f in glob.glob("gpurun_out/pmc_%s/p[34]/*/*_counter_collection.csv" % wl):
@@ -23,8 +25,9 @@ for wl in sys.argv[2:]:
     write = sum(per["WRITE_SIZE"].values()) / nw
     out[wl] = {"bytes_per_launch": (2.0 * fetch + write) * 1024.0, "fetch_kb_raw_mean": fetch, "write_kb_mean": write,
                "launches": nf, "kernels": dict(names),
+               "precision": 0 if wl.endswith("_f32") else 1,
                "source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload %s` with the rule-based tile choice "
-                         "(PNN_AUTOTUNE=0, so that tuning launches do not enter the mean); mean over the split-GEMM dispatches of "
+                         "(PNN_AUTOTUNE=0, so that tuning launches do not enter the mean); mean over the GEMM dispatches of that arithmetic of "
                          "2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes" % wl}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))
