@@ -231,55 +231,64 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True):
     return res
 
 
-def cpu_legs(wl, budget_s=4.0):
-    """BASELINE.md section 3: the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
-    an independent PyTorch-CPU formulation (oneDNN / MKL), each batched and at batch 1 sequential (what HM does per TB).
-    Bounded samples: every leg runs for about `budget_s`."""
-    import torch
-    from oracle import pnn_oracle as O
-    from tests import torch_formulation as TF
+def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
+    """One CPU leg in its own process (`bench.py --cpu-leg ...`): a clean thread environment -- two OpenMP runtimes with
+    256 spinning threads each in one process (oracle + PyTorch, beside the HIP runtime's own threads) measured each other
+    rather than the nets.  Prints one JSON object."""
     from tests import util
-    w, fc = wl.width, wl.is_fc
-    ncores = os.cpu_count()
-    nb = min(wl.batch, 4096 if fc else (512 if w <= 16 else 64))
+    w, fc, default_batch, _ = WORKLOADS[workload]
+    params = util.make_params(w, fc, seed=1, out_gain=30.0)
+    nb = min(default_batch, 4096 if fc else (512 if w <= 16 else 64))
     above, left = util.make_contexts(w, nb, seed=7)
     ctx = util.flatten_fc(above, left) if fc else None
+    if kind == "oracle":
+        from oracle import pnn_oracle as M
+    else:
+        import torch
+        from tests import torch_formulation as M
+        torch.set_num_threads(threads)
+    if batch1:
+        k1 = 16
+        one = (lambda i: M.fc_forward(params, w, ctx[i:i + 1])) if fc else (lambda i: M.conv_forward(params, w, above[i:i + 1], left[i:i + 1]))
+        fn, per_call = (lambda: [one(i) for i in range(k1)]), k1
+    else:
+        fn, per_call = ((lambda: M.fc_forward(params, w, ctx)) if fc else (lambda: M.conv_forward(params, w, above, left))), nb
+    fn()                                                # warm-up (thread pools, page faults)
+    ts, t0 = [], time.perf_counter()
+    while (len(ts) < 5 and time.perf_counter() - t0 < 3 * budget_s) or (time.perf_counter() - t0 < budget_s and len(ts) < 500):
+        a = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - a)
+    print(json.dumps({"blocks_per_s": per_call / float(np.median(ts)), "runs": len(ts), "blocks_per_run": per_call, "threads": threads}))
 
-    def timed(fn, per_call):
-        fn()                                            # warm-up (thread pools, page faults)
-        ts, t0 = [], time.perf_counter()
-        while len(ts) < 5 or (time.perf_counter() - t0 < budget_s and len(ts) < 200):
-            a = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - a)
-            if time.perf_counter() - t0 > 3 * budget_s:
-                break
-        return {"blocks_per_s": per_call / float(np.median(ts)), "runs": len(ts), "blocks_per_run": per_call}
+
+def cpu_legs(wl, budget_s=3.0):
+    """BASELINE.md section 3: the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
+    an independent PyTorch-CPU formulation (oneDNN / MKL), each batched and at batch 1 sequential (what HM does per TB).
+    Bounded samples: every leg runs for about `budget_s` in its own process; thread count = all cores for the batched legs,
+    the best of {all, 8, 1} for the batch-1 legs (a single block rarely profits from every core)."""
+    import subprocess
+    ncores = os.cpu_count()
+
+    def run(kind, batch1, threads):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", kind, "--workload", wl.name, "--leg-batch1", str(int(batch1)),
+                            "--leg-threads", str(threads), "--leg-budget", str(budget_s)], env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
 
     legs = {}
-    legs["oracle_batched"] = timed((lambda: O.fc_forward(wl.params, w, ctx)) if fc else (lambda: O.conv_forward(wl.params, w, above, left)), nb)
-    legs["oracle_batched"]["threads"] = ncores
-    one = (lambda i: O.fc_forward(wl.params, w, ctx[i:i + 1])) if fc else (lambda i: O.conv_forward(wl.params, w, above[i:i + 1], left[i:i + 1]))
-    k1 = 16
-    legs["oracle_batch1"] = timed(lambda: [one(i) for i in range(k1)], k1)
-    legs["oracle_batch1"]["threads"] = ncores
-    torch.set_num_threads(ncores)
-    legs["torch_cpu_batched"] = timed((lambda: TF.fc_forward(wl.params, w, ctx)) if fc else (lambda: TF.conv_forward(wl.params, w, above, left)), nb)
-    legs["torch_cpu_batched"]["threads"] = ncores
-    onet = (lambda i: TF.fc_forward(wl.params, w, ctx[i:i + 1])) if fc else (lambda i: TF.conv_forward(wl.params, w, above[i:i + 1], left[i:i + 1]))
-    best = None
-    for nt in (ncores, min(ncores, 8), 1):             # batch 1 rarely profits from every core: keep the best thread count
-        torch.set_num_threads(nt)
-        r = timed(lambda: [onet(i) for i in range(k1)], k1)
-        r["threads"] = nt
-        if best is None or r["blocks_per_s"] > best["blocks_per_s"]:
-            best = r
-    legs["torch_cpu_batch1"] = best
-    torch.set_num_threads(ncores)
-    return {"value": legs["oracle_batched"]["blocks_per_s"], "unit": "blocks/s", "cores": ncores, "kind": "port",
-            "sample": "%d-block batches (batched legs) / 16 single-block calls in sequence (batch-1 legs) of the same net, median of >= 5 runs per "
-                      "leg, ~%.0f s per leg; `value` = oracle/pnn_oracle.c batched (OpenMP, -O3 -mavx2 -mfma). Stand-ins for the reference's "
-                      "TF-1.9 CPU path, which cannot be installed here" % (nb, budget_s),
+    for kind, tag in (("oracle", "oracle"), ("torch", "torch_cpu")):
+        legs[tag + "_batched"] = run(kind, False, ncores)
+        cands = [run(kind, True, t) for t in sorted({ncores, min(ncores, 8), 1}, reverse=True)]
+        legs[tag + "_batch1"] = max(cands, key=lambda r: r.get("blocks_per_s", 0.0))
+    best = max(("oracle_batched", "torch_cpu_batched"), key=lambda k: legs[k].get("blocks_per_s", 0.0))
+    return {"value": legs[best].get("blocks_per_s"), "unit": "blocks/s", "cores": ncores, "kind": "port", "value_leg": best,
+            "sample": "batched legs: batches of %s blocks; batch-1 legs: 16 single-block calls in sequence (what HM issues per TB); median of the "
+                      "runs that fit ~%.0f s per leg, each leg in its own process; `value` = the FASTER of the two batched legs (oracle/pnn_oracle.c "
+                      "with OpenMP -O3 -mavx2 -mfma; PyTorch-CPU functional formulation on oneDNN / MKL).  Stand-ins for the reference's TF-1.9 "
+                      "CPU path, which cannot be installed here" % (legs["oracle_batched"].get("blocks_per_run"), budget_s),
             "legs": legs}
 
 
@@ -292,7 +301,13 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32_exact / conv16 sub-measurements")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)       # internal: one CPU-baseline leg, see cpu_leg_worker
+    ap.add_argument("--leg-batch1", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--leg-threads", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--leg-budget", type=float, default=3.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_leg:
+        return cpu_leg_worker(args.cpu_leg, args.workload, bool(args.leg_batch1), args.leg_threads, args.leg_budget)
 
     import torch
     from context_adaptive_neural_network_based_prediction_amd import sharding
@@ -340,7 +355,7 @@ def main():
             extras["conv16"] = {"config": {"workload": wc.cfg_name, "batch_per_gpu": wc.batch, "steps": k16},
                                 "split_f16": measure(wc, 1, k16, args.warmup, None), "f32_exact": measure(wc, 0, k16, args.warmup, None)}
             if not args.no_cpu_baseline:
-                extras["conv16"]["cpu_baseline"] = cpu_legs(wc, budget_s=2.5)
+                extras["conv16"]["cpu_baseline"] = cpu_legs(wc, budget_s=2.0)
         out.update(extras)
     if rank == 0 and single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_legs(wl)
