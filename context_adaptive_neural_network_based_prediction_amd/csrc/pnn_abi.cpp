@@ -28,6 +28,10 @@ namespace pnn { void set_create_error(const std::string& msg) { g_create_error =
 namespace {
 
 constexpr int kHidden = 1200;                         // pnn/components.py:130-160
+// The output layer of an FC net with <= 64 outputs is summed in K segments of 10 chunks (160 hidden units) whose partial
+// sums are then added in ascending order (fuse_reduce_kernel): the order the ring kernel's fused output layer produces
+// with its 128 x 160 tile, and the order tapgemm_small_kernel's K-segment mode reproduces at any batch size.
+constexpr int kFuseSegChunks = 10;
 int strides_for(int w, int* st)                       // pnn/PredictionNeuralNetwork.py:126-132
 {
     switch (w) {
@@ -110,6 +114,8 @@ struct pnn_ctx {
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
+    long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
+    long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
     std::map<std::pair<const void*, long>, int> tuned;
@@ -641,8 +647,11 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
 // finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
 int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
                 long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
-                const Conv1Params* first = nullptr)
+                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0)
 {
+    // x_is_f32: Xhi holds plain f32 rows (an FC net's input as the caller handed it over); only the small-M kernel takes
+    // that (it splits in registers), any other choice gets split_kernel launched in front (into ws[2]).
+    // seg_chunks > 0: K-segment mode of an FC output layer (small-M kernel only): raw partials to `part`, see fc_pass.
     // `first` (optional): the Cin = 1 convolution that produces this layer's input Xhi.  It has NOT been launched: a
     // convimg configuration computes it inside the kernel (no 50 MB round trip of the maps), any other configuration gets
     // it launched here in front of the GEMM.
@@ -665,6 +674,42 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     p.x_bytes = (unsigned)xb;
     const int cpt = p.Cin / 16;
     const bool one_tap = (L.k_total == (double)p.Cin);
+    static const bool diag0 = getenv("PNN_SP_DIAG") != nullptr;
+    // Few output tiles (the in-loop single-block calls, the batching service's handfuls): one wave per 32 x 32 tile over all
+    // CUs instead of one or two big workgroups walking K alone.  Same per-output summation order: bit-identical.
+    const bool small = seg_chunks > 0 || (!next && !diag0 && c->opt_small && c->opt_sp_cfg < 0 && tapgemm_small_tiles(p) <= c->opt_small_tiles);
+    if (small) {
+        if (seg_chunks > 0) p.part = part;
+        if (first) { HIPCHK(c, launch_conv_cin1(*first, s)); c->stat_launches++; }
+        static const bool dbg = getenv("PNN_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> small kernel (%ld tiles%s%s)\n", M, L.k_total, p.Cout, p.ncls,
+                         tapgemm_small_tiles(p), x_is_f32 ? ", f32 input" : "", seg_chunks ? ", K segments" : "");
+        const double flops = 2.0 * (double)M * L.k_total * p.Cout;
+        if (c->opt_time_launches) {
+            pnn_ctx::LaunchRec r;
+            HIPCHK(c, hipEventCreate(&r.e0));
+            HIPCHK(c, hipEventCreate(&r.e1));
+            r.kind = 5; r.flops = flops;
+            const LaunchEvents ev{r.e0, r.e1};
+            g_launch_events = &ev;
+            const hipError_t le = launch_tapgemm_small(p, x_is_f32, seg_chunks, s);
+            g_launch_events = nullptr;
+            HIPCHK(c, le);
+            c->launch_recs.push_back(r);
+        } else {
+            HIPCHK(c, launch_tapgemm_small(p, x_is_f32, seg_chunks, s));
+        }
+        c->stat_gemm_launches++; c->stat_launches++;
+        c->stat_gemm_flops += flops;
+        if (tiles_out) *tiles_out = seg_chunks > 0 ? (int)(((long)(L.k_total / 16.0) + seg_chunks - 1) / seg_chunks) : 0;
+        return PNN_OK;
+    }
+    if (x_is_f32) {                                   // the big-tile kernels read split activations
+        const long nin = nblocks * (long)p.IH * p.IW * p.Cin;
+        HIPCHK(c, launch_split((const float*)Xhi, nin, c->ws[2].p, nullptr, c->h_range, s));
+        c->stat_launches++;
+        p.X = (const float*)c->ws[2].p;
+    }
     const int nsp = tapgemm_sp_num_cfgs(), nci = convimg_sp_num_cfgs(), nrg = tapgemm_ring_num_cfgs();
     // configuration codes: [0, nsp) = tapgemm_sp_kernel tiles, then the convimg_sp_kernel tiles (images resident in
     // LDS), then the tapgemm_ring_kernel tiles (LDS-DMA ring)
@@ -672,7 +717,10 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     auto cfg_of = [&](int code) { return code < nsp ? tapgemm_sp_cfg(code) : code < nsp + nci ? convimg_sp_cfg(code - nsp) : tapgemm_ring_cfg(code - nsp - nci); };
     auto kind_of = [&](int code) { return code < nsp ? "" : code < nsp + nci ? "img" : "ring"; };
     auto legal = [&](int code) {
-        if (next) return code >= nsp + nci && !diag && c->opt_ring && tapgemm_ring_can_fuse(code - nsp - nci);
+        // fused output layer: only the 160-column tile -- its column tiles ARE the K segments of the output layer's canonical
+        // summation order (kFuseSegChunks chunks each), which the small-M kernel reproduces for every other batch size
+        if (next) return code >= nsp + nci && !diag && c->opt_ring && tapgemm_ring_can_fuse(code - nsp - nci) &&
+                         32 * tapgemm_ring_cfg(code - nsp - nci).nt * (4 / tapgemm_ring_cfg(code - nsp - nci).wm) == 16 * kFuseSegChunks;
         if (code < nsp) return one_tap || cpt % tapgemm_sp_cfg(code).kc == 0;
         if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
         return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
@@ -748,6 +796,11 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         }
         cfg = it->second;
     }
+    if (next && !legal(cfg)) {                        // checked BEFORE anything is launched: the caller falls back to separate launches
+        cfg = -1;
+        for (int i = nsp + nci; i < nsp + nci + nrg && cfg < 0; i++) if (legal(i)) cfg = i;
+        if (cfg < 0) return fail(c, PNN_E_ARG, "no ring configuration can fuse the next layer");
+    }
     static const bool debug = getenv("PNN_DEBUG") != nullptr;
     static const bool profile = getenv("PNN_PROFILE") != nullptr;
     const TileCfg t = cfg_of(cfg);
@@ -794,7 +847,6 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
     if (next) {
-        if (!legal(cfg)) return fail(c, PNN_E_ARG, "no ring configuration can fuse the next layer");
         c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
         if (tiles_out) *tiles_out = (int)((p.Cout + 32L * t.nt * (4 / t.wm) - 1) / (32L * t.nt * (4 / t.wm)));
     }
@@ -880,26 +932,28 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
     float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
     int rc;
     if (pass_uses_split(c, m, nb)) {
-        // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32)
-        const long nin = nb * 5L * m->width * m->width;
-        const void* S = d_ctx;                        // already in the split layout when the gather wrote it
-        if (!ctx_is_split) {
-            HIPCHK(c, launch_split(d_ctx, nin, c->ws[2].p, nullptr, c->h_range, s));
-            c->stat_launches++;
-            S = c->ws[2].p;
-        }
+        // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32); the input is
+        // already split when the gather wrote it, else the first layer's kernel splits it (small-M kernel: in registers)
         const int n_out = m->fc[3].proto.Cout;
-        const bool fuse_ok = c->opt_fuse_last && c->opt_ring && !c->opt_canonical && c->opt_sp_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && nb >= 1024;
-        if ((rc = run_gemm_sp(c, m->fc[0], S, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
+        // Output layer of the 4x4 / 8x8 nets (<= 64 outputs): summed in K segments of kFuseSegChunks chunks + fuse_reduce, at
+        // EVERY batch size -- by the ring kernel's fused output layer (big batches: the 1200-wide activations of the third
+        // hidden layer never leave the workgroups that produce them) or by the small-M kernel's K-segment mode.
+        const bool seg_model = n_out <= 64 && n_out % 4 == 0;
+        const bool ring_fuse = seg_model && c->opt_fuse_last && c->opt_ring && c->opt_sp_cfg < 0 && nb >= 1024;
+        if ((rc = run_gemm_sp(c, m->fc[0], d_ctx, nullptr, nullptr, P0, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, !ctx_is_split))) return rc;
         if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
-        if (fuse_ok) {
-            // last hidden layer + output layer in one launch: the 1200-wide activations of the third hidden layer never
-            // leave the workgroups that produce them (pnn_gemm_ring.hip, FUSE); a small kernel sums the column tiles' partials
+        if (seg_model) {
             if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
+            float* part = (float*)c->ws[3].p;
             int tiles = 0;
-            if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], (float*)c->ws[3].p, &tiles))) return rc;
-            if (tiles > 20) return fail(c, PNN_E_ARG, "fused layer: %d column tiles exceed the partial buffer", tiles);
-            HIPCHK(c, launch_fuse_reduce((const float*)c->ws[3].p, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
+            if (ring_fuse) {
+                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
+            } else {
+                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
+                if ((rc = run_gemm_sp(c, m->fc[3], P0, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, nullptr, part, &tiles, nullptr, false, kFuseSegChunks))) return rc;
+            }
+            if (tiles <= 0 || tiles > 20) return fail(c, PNN_E_ARG, "output layer: %d K segments do not fit the partial buffer", tiles);
+            HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
             c->stat_launches++;
             return PNN_OK;
         }
@@ -1041,6 +1095,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
+    if (const char* e = getenv("PNN_SMALL")) c->opt_small = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
@@ -1176,6 +1231,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "autotune")) c->opt_autotune = value;
     else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
+    else if (!strcmp(name, "small")) c->opt_small = value;
+    else if (!strcmp(name, "small_max_tiles")) c->opt_small_tiles = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;

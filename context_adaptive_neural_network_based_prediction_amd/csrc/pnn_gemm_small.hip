@@ -1,0 +1,257 @@
+// Split-precision tap GEMM for SMALL M: one 4-wave workgroup (1 MFMA wave + 3 LDS-DMA loader waves) per 32 x 32 output tile.
+//
+// Why: HM asks for one block at a time (TComPrediction.cpp:572-579,601-608) and the batching service for a handful, so
+// M -- blocks x pixels of the layer -- is 1 ... a few hundred rows.  The big-tile kernels (tapgemm_ring / tapgemm_sp /
+// convimg_sp) then run ONE or two workgroups, each walking the whole K of a 64-192-row tile alone: 14-60 us per layer
+// (profiles/r02_batch1_*), most rows padding.  The old answer, a split-K f32 kernel, is fast but adds K in another order,
+// so a block predicted alone could differ in the last bit from the same block predicted inside a batch -- encoder/decoder
+// drift unless "canonical_order" forced the slow path.
+//
+// This kernel keeps the big kernels' arithmetic EXACTLY -- same instruction (v_mfma_f32_32x32x16_f16), same operand roles
+// (A = weights, B = activations), per accumulator the 16-deep K chunks in ascending order and per chunk
+// w_hi*a_hi, w_hi*a_lo, w_lo*a_hi -- so its results are bit-identical to theirs (tests: every batch size, every kernel
+// family), and gets its speed from parallelism over tiles instead of over K:
+//   * grid = (M / 32) x (Cout / 32) x classes workgroups of 4 waves, one 32 x 32 tile each; a 1200 x 1200 FC layer at
+//     batch 1 is 38 workgroups on 38 CUs, each streaming only ITS 2 KiB of weights per chunk;
+//   * wave 0 only reads fragments from an LDS ring and issues MFMAs; waves 1-3 only issue LDS-DMA (buffer_load ... lds, no
+//     VGPRs): a stage is 3 chunks, loader j owns chunk j of every stage -- 4 instructions of 1 KiB (w_hi, w_lo and the two
+//     activation pieces), every lane fetching exactly the 16 bytes some lane of wave 0 will feed to the MFMA, so the ring
+//     is read back lane-linear, conflict-free -- and retires them with counted vmcnt; one s_barrier per stage joins the
+//     roles (the ring kernel's protocol at tile size 32 x 32).  4 stages = 48 KiB in flight per workgroup.
+//     (A first version had ONE wave do both jobs: 16 us per 1200-deep layer instead of the ~4 us its 225 MFMAs need -- a
+//     wave is blocked ~70 cycles while it issues a 1-KiB vector-memory instruction, 280 of its ~350 cycles per chunk.)
+//   * rows past M, taps outside the image and chunks past the end of K are buffer-descriptor range misses: zeros, no traffic.
+//
+// Extras: AF32 -- the activations are plain f32 rows (an FC net's input as HM hands it over) and are split into f16 pairs
+// in registers, the same conversion split_kernel applies (saves that launch); `seg` > 0 -- K-segment mode for the output
+// layer of an FC net: blockIdx.z selects `seg` chunks of K and the raw partial sums go to part[z][m][64], exactly the
+// per-column-tile partials the ring kernel's fused output layer produces (pnn_gemm_ring.hip, FUSE, BN = 16 * seg), so
+// fuse_reduce_kernel finishes both the same way.
+#include "pnn_kernels.h"
+#include <type_traits>
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSmallCS = 3;                         // chunks per stage = loader waves
+constexpr int kSmallLA = 4;                         // stages in flight ahead of the one being computed
+constexpr int kSmallD = kSmallLA + 1;               // ring slots (stages): 5 x 12 KiB
+
+template <int N>
+__device__ __forceinline__ void small_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool AF32>
+__global__ __launch_bounds__(256) void tapgemm_small_kernel(const TapGemmParams p, const int seg)
+{
+    touch_kernargs<sizeof(TapGemmParams)>();
+    constexpr int CS = kSmallCS, LA = kSmallLA, D = kSmallD;
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][4 pieces][64 lanes]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: everything derived from it (chunk, tap) stays in SGPRs
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cls = seg > 0 ? 0 : (int)blockIdx.z;
+    const int n0 = blockIdx.y * 32;
+    const int mblk = blockIdx.x * 32;
+    const int SP = p.SH * p.SW;
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    int c0 = 0, c1 = nchunks;                        // this workgroup's chunks [c0, c1) of the class
+    if (seg > 0) {
+        c0 = (int)blockIdx.z * seg;
+        c1 = c0 + seg < nchunks ? c0 + seg : nchunks;
+    }
+    const int nst = (c1 - c0 + CS - 1) / CS;
+
+    // activation row of this lane: m = mblk + l31 -> (block, i, j)
+    const int mg = mblk + l31;
+    const bool rowok = mg < p.M;
+    const int mc = rowok ? mg : 0;
+    const int rb = mc / SP;
+    const int rq = mc - rb * SP;
+    const int ri = rq / p.SW, rj = rq - ri * p.SW;
+
+    if (wave != 0) {
+        // ---- loader wave j: chunk j of every stage ---------------------------------------------------------------------------
+        const int j = wave - 1;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0x7fffffffu, 0x00020000);
+        const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
+        const unsigned wlane = (unsigned)((h * p.Npad + n0 + l31) << 4);    // plane (hi, h); the lo planes are 2 * Npad pieces further
+        const unsigned wlo_delta = (unsigned)(2 * p.Npad) << 4;
+        constexpr unsigned kOob = 0x80000000u;                               // past every descriptor: the load returns zeros
+        int ci = c0 + j;                             // next chunk to issue (class-relative), its tap and position inside the tap
+        int it = t0 + ci / cpt, icc = ci - (ci / cpt) * cpt;
+        unsigned apix = kOob;                        // byte offset of this lane's input pixel for tap `it`
+        auto tap_setup = [&](int t) {
+            const int tp = p.tap[t < t1 ? t : t1 - 1];
+            const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+            const int iy = ri * p.a + dy, ix = rj * p.a + dx;
+            const bool ok = rowok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            apix = ok ? (((unsigned)((rb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) : kOob;
+        };
+        tap_setup(it);
+        auto issue = [&](int slot) {                 // DMA of chunk `ci` into its place of ring slot `slot`, then advance by one stage
+            f32x4* dst = ring + (slot * CS + j) * 256;
+            const bool live = ci < c1;
+            const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
+            const unsigned ao = (live && apix != kOob) ? apix + (unsigned)(icc << 6) + (unsigned)(h << (AF32 ? 5 : 4)) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst), 16, wo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + 64), 16, live ? wo + wlo_delta : kOob, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(dst + 128), 16, ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(dst + 192), 16, ao == kOob ? kOob : ao + (AF32 ? 16u : 32u), 0, 0, 0);
+            ci += CS; icc += CS;
+            if (icc >= cpt) {
+                do { icc -= cpt; ++it; } while (icc >= cpt);
+                tap_setup(it);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < LA; s++) issue(s);       // stages past the end of K are range misses (zeros): the counts stay uniform
+        small_wait_vm<4 * (LA - 1)>();               // stage 0 has landed
+        __builtin_amdgcn_s_barrier();
+        int slot = LA;                               // slot of stage s + LA = (s + LA) % D, the one stage s - 1 has left
+        for (int s = 0; s + 1 < nst; s++) {
+            issue(slot);
+            if (++slot == D) slot = 0;
+            small_wait_vm<4 * (LA - 1)>();           // stage s + 1 has landed
+            __builtin_amdgcn_s_barrier();            // barrier s
+        }
+        small_wait_vm<0>();                          // trailing (range-miss) DMAs must not outlive the workgroup's LDS
+        return;
+    }
+
+    // ---- MFMA wave -------------------------------------------------------------------------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    float amax_in = 0.f;                             // AF32: range guard of the converted inputs
+    __builtin_amdgcn_s_barrier();                    // stage 0 is in the ring
+    // Fragment reads run one chunk ahead of the MFMAs (three register sets, one per chunk of a stage), and the stage barrier
+    // sits in front of the LAST chunk's MFMAs: by then the whole stage is in registers, so its slot may be refilled, and the
+    // first chunk of the next stage is requested right behind the barrier, under those MFMAs.  (With reads and MFMAs of a
+    // chunk back to back, a stage took ~460 cycles for 288 cycles of matrix work.)
+    f32x4 fr[CS][4];
+    auto read_chunk = [&](int slot, int k) {
+        const f32x4* src = ring + (slot * CS + k) * 256 + lane;
+        fr[k][0] = src[0]; fr[k][1] = src[64]; fr[k][2] = src[128]; fr[k][3] = src[192];
+    };
+    auto mfma_chunk = [&](int k) {
+        f16x8 ahi, alo;
+        if (AF32) {
+            // the same split as split_kernel / store_split4: hi = (f16) x, lo = (f16)(x - hi)
+            amax_in = amax4(amax4(amax_in, fr[k][2]), fr[k][3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ahi[i] = (_Float16)fr[k][2][i]; alo[i] = (_Float16)(fr[k][2][i] - (float)ahi[i]);
+                ahi[4 + i] = (_Float16)fr[k][3][i]; alo[4 + i] = (_Float16)(fr[k][3][i] - (float)ahi[4 + i]);
+            }
+        } else {
+            ahi = __builtin_bit_cast(f16x8, fr[k][2]);
+            alo = __builtin_bit_cast(f16x8, fr[k][3]);
+        }
+        const f16x8 whi = __builtin_bit_cast(f16x8, fr[k][0]), wlo = __builtin_bit_cast(f16x8, fr[k][1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc, 0, 0, 0);
+    };
+    int slot = 0;
+    read_chunk(0, 0);
+    for (int s = 0; s < nst; s++) {
+        const int cb = c0 + s * CS;                  // chunks past c1 (tail of the last stage) hold zeros: skipped, not multiplied
+#pragma unroll
+        for (int k = 0; k < CS; k++) {
+            if (k + 1 < CS) {
+                read_chunk(slot, k + 1);
+            } else {
+                const int nslot = slot + 1 == D ? 0 : slot + 1;
+                // the whole stage is in registers.  Through the builtin, not inline asm, and on both paths: the compiler's own
+                // wait insertion then knows that chunk CS - 1's registers are ready and does not wait for the NEXT stage's
+                // first reads in front of its MFMAs (it did: s_waitcnt lgkmcnt(1) there, the overlap gone)
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched (gfx9 encoding)
+                if (s + 1 < nst) {
+                    __builtin_amdgcn_s_barrier();    // barrier s: stage s + 1 is in the ring, slot of stage s may be refilled
+                    read_chunk(nslot, 0);
+                }
+                slot = nslot;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the requests in front of the MFMAs they hide under
+            if (cb + k < c1) mfma_chunk(k);
+        }
+    }
+    if (AF32) report_range(p.range_flag, amax_in);
+
+    if (seg > 0) {                                   // raw partial sums of this K segment (scale, bias, epilogue: fuse_reduce_kernel)
+        if (rowok) {
+            float* __restrict__ part = p.part + ((size_t)blockIdx.z * p.M + mg) * 64;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + 8 * g + 4 * h;
+                if (n < 64) *reinterpret_cast<f32x4*>(part + n) = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue: undo the weight scale, bias (+ LeakyReLU); f32 and/or split-f16 outputs, optional HM epilogue --------
+    if (!rowok) return;
+    const int py = p.py[cls], px = p.px[cls];
+    const int oy = ri * p.os + py, ox = rj * p.os + px;
+    const size_t obase = (((size_t)rb * p.OH + oy) * p.OW + ox) * p.Cout;
+    const bool act = p.act != 0;
+    float amax = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int n = n0 + 8 * g + 4 * h;
+        if (n < p.Cout) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            f32x4 v = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} * p.out_scale + bv;
+            if (act) {
+                v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+            }
+            if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+            if (p.Yhi) store_split4(p.Yhi, obase, n, v, amax);
+            if (p.Yi) {
+                int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+                *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+            }
+        }
+    }
+    if (p.Yhi) report_range(p.range_flag, amax);
+}
+
+size_t tapgemm_small_lds_bytes() { return (size_t)kSmallD * kSmallCS * 4 * 64 * 16; }
+
+// Number of workgroups (one 32 x 32 tile each) the layer needs (what the caller compares with the chip): row tiles x column tiles x classes.
+long tapgemm_small_tiles(const TapGemmParams& p) { return (long)((p.M + 31) / 32) * ((p.Cout + 31) / 32) * p.ncls; }
+
+hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    static bool attr_done = false;
+    if (!attr_done) {                                // 60 KiB of dynamic LDS: above the 48 KiB a kernel gets without asking
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_small_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    unsigned gz = (unsigned)p.ncls;
+    if (seg_chunks > 0) {
+        if (p.ncls != 1 || p.Cout > 64 || !p.part) return hipErrorInvalidValue;
+        const int nchunks = (p.tap_begin[1] - p.tap_begin[0]) * (p.Cin >> 4);
+        gz = (unsigned)((nchunks + seg_chunks - 1) / seg_chunks);
+    }
+    const dim3 grid((p.M + 31) / 32, (p.Cout + 31) / 32, gz);
+    if (a_is_f32) pnn_launch(tapgemm_small_kernel<true>, grid, dim3(256), tapgemm_small_lds_bytes(), s, p, seg_chunks);
+    else pnn_launch(tapgemm_small_kernel<false>, grid, dim3(256), tapgemm_small_lds_bytes(), s, p, seg_chunks);
+    return hipGetLastError();
+}
+
+}  // namespace pnn

@@ -86,6 +86,11 @@ size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
 bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0);   // the raw context tiles fit the weight staging area
 hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s);   // G images per workgroup, resident in LDS
 hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_flag, hipStream_t s);
+// Small-M split-precision tap GEMM (pnn_gemm_small.hip): one wave per 32 x 32 output tile, same per-output summation
+// order as the three big-tile kernels.  a_is_f32: p.X holds plain f32 rows (split in registers); seg_chunks > 0: K-segment
+// mode of an FC output layer (<= 64 outputs), raw partials to p.part[segment][M][64] for launch_fuse_reduce.
+long tapgemm_small_tiles(const TapGemmParams& p);
+hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);

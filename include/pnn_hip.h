@@ -85,6 +85,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
  * calls -- run the two independent branches on two HIP streams, forked and joined by events; 2: every small conv
  * pass; 0: one stream.  Results do not depend on it),
+ * "small" (1, default: split-precision GEMMs with at most "small_max_tiles" (512) output tiles of 32 x 32 -- single-block
+ * calls, small batches -- run on tapgemm_small_kernel, one wave per tile spread over the chip, in the SAME per-output
+ * summation order as the big-tile kernels; 0: big-tile kernels only),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
@@ -92,7 +95,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * the last bits, i.e. by one LSB on an exact .5 tie). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */
@@ -187,7 +190,7 @@ int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_f
 
 /* With pnn_set_option(ctx, "time_launches", 1) every tap-GEMM launch is bracketed by HIP events on its launch
  * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_kernel / tapgemm32_kernel,
- * 1 = tapgemm_splitk_kernel, 2 = tapgemm_sp_kernel, 3 = convimg_sp_kernel, 4 = tapgemm_ring_kernel), the number of
+ * 1 = tapgemm_splitk_kernel, 2 = tapgemm_sp_kernel, 3 = convimg_sp_kernel, 4 = tapgemm_ring_kernel, 5 = tapgemm_small_kernel), the number of
  * launches since the last call, their summed duration and their summed algorithmic FLOPs. */
 int pnn_launch_times(pnn_ctx* ctx, int kind, int* n_launches, double* total_us, double* total_flops);
 

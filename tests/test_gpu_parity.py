@@ -729,6 +729,33 @@ def test_full_size_properties(pnn, oracle, w, is_fc, n):
     _check_pel(got[sample], oracle.predict_tbs(params, w, is_fc, plane, xs[sample], ys[sample], flags[sample], util.MEAN))
 
 
+@pytest.mark.parametrize("w,is_fc,big", [(4, True, 1500), (8, True, 2048), (4, False, 700), (8, False, 600), (16, False, 200), (32, False, 40),
+                                         (64, False, 5)])
+def test_one_summation_order_at_every_batch_size(pnn, precision, w, is_fc, big):
+    """canonical_order: a block's float prediction is the same bit pattern whether it is predicted alone (tapgemm_small_kernel,
+    one wave per 32 x 32 tile, K-segment output layer), in a handful, in a mid-size pass or in a big batch (ring / sp /
+    convimg kernels, fused output layer) -- what an encoder behind the batching service and a stand-alone decoder need."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    params = util.make_params(w, is_fc, 111, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, big, 112)
+    net = pnn.PredictionNeuralNetwork(big, w, is_fc, params=params)
+    net.set_option("canonical_order", 1)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    full = run(above, left)
+    net.set_option("small", 0)                                       # the big-tile kernels alone
+    assert np.array_equal(run(above, left), full)
+    few = run(above[:3], left[:3])
+    net.set_option("small", 1)
+    assert np.array_equal(few, full[:3])
+    for n in (1, 2, 3, 17, 33, min(160, big)):
+        lo = big - n
+        got = run(above[lo:], left[lo:])
+        assert np.array_equal(got, full[lo:]), "a batch of %d differs from the same blocks inside a batch of %d" % (n, big)
+    assert np.array_equal(net.predict_pel(*((util.flatten_fc(above[2:3], left[2:3]),) if is_fc else (above[2:3], left[2:3])))[0],
+                          net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))[2])
+
+
 def test_tf_compat_session_run(pnn, oracle, tmp_path):
     """The TensorFlow-look-alike session API of include/pnn_tf_compat.h (what HM's C++ calls) against the oracle."""
     import subprocess
