@@ -43,7 +43,8 @@ KERNELS = ((0, "tapgemm_kernel (exact f32 MFMA 16x16x4, LDS-staged weights)"),
            (1, "tapgemm_splitk_kernel (f32 MFMA, small M)"),
            (2, "tapgemm_sp_kernel (f32-class split products on 3 x f16 MFMA 32x32x16, register-staged operands)"),
            (3, "convimg_sp_kernel (same split-product MFMAs, feature maps resident in LDS)"),
-           (4, "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)"))
+           (4, "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)"),
+           (5, "tapgemm_small_kernel (same split-product MFMAs; one 32 x 32 tile per workgroup, 1 MFMA + 3 loader waves: small M)"))
 
 
 def flops_per_block(width, is_fc):

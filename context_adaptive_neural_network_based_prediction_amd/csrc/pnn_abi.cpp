@@ -108,7 +108,10 @@ struct pnn_ctx {
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
-    long opt_canonical = 0;                           // 1: one summation order for every batch size (no split-K)
+    // 1 (default): one per-output summation order at every batch size -- a block's prediction does not depend on the batch
+    // it travels in (encoder behind the batching service, decoder alone: no drift).  0: small passes may take the exact-f32
+    // split-K kernels (a few us faster per single-block call; last float bits can differ from the batched result).
+    long opt_canonical = 1;
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves

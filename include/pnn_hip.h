@@ -89,10 +89,12 @@ float pnn_mean(const pnn_ctx* ctx);
  * calls, small batches -- run on tapgemm_small_kernel, one wave per tile spread over the chip, in the SAME per-output
  * summation order as the big-tile kernels; 0: big-tile kernels only),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
- * "canonical_order" (1 = every batch size uses the same per-output summation order, so a block's float
- * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder
- * pair needs; 0 (default) lets small batches use the faster split-K kernel, whose float result can differ in
- * the last bits, i.e. by one LSB on an exact .5 tie). */
+ * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
+ * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs
+ * (single-block calls then run on tapgemm_small_kernel, the output layer of the 4x4 / 8x8 nets is summed in the same K
+ * segments as the big batches' fused output layer); 0: small passes may use the exact-f32 split-K kernels, a few
+ * microseconds faster per single-block call, whose float result can differ in the last bits, i.e. by one LSB on an
+ * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
  * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:

@@ -703,13 +703,12 @@ def test_full_size_properties(pnn, oracle, w, is_fc, n):
     perm = np.random.RandomState(0).permutation(n)
     assert np.array_equal(run(above[perm], left[perm]), full[perm])
     net.set_option("max_chunk", 300)                                 # ragged chunks: 300, 300, ..., remainder
-    np.testing.assert_allclose(run(above, left), full, rtol=0, atol=FLOAT_ATOL)   # small passes may pick the split-K kernel
-    net.set_option("canonical_order", 1)                             # ... unless one summation order is requested:
-    canon = run(above, left)
+    assert np.array_equal(run(above, left), full)                    # one summation order (the default): chunking changes nothing, bit for bit
+    assert np.array_equal(run(above[5:6], left[5:6])[0], full[5])    # ... down to a batch of one
+    net.set_option("canonical_order", 0)                             # opt-out: small passes may take the f32 split-K kernels
+    np.testing.assert_allclose(run(above, left), full, rtol=0, atol=FLOAT_ATOL)
+    net.set_option("canonical_order", 1)
     net.set_option("max_chunk", 0)
-    assert np.array_equal(run(above, left), canon)                   # then chunking / batch size change nothing, bit for bit
-    assert np.array_equal(run(above[5:6], left[5:6])[0], canon[5])   # ... down to a batch of one
-    net.set_option("canonical_order", 0)
     assert np.array_equal(full[n // 2], full[3])
     idx = np.random.RandomState(1).choice(n, 64, replace=False)
     want = oracle.fc_forward(params, w, util.flatten_fc(above[idx], left[idx])) if is_fc else oracle.conv_forward(params, w, above[idx], left[idx])
