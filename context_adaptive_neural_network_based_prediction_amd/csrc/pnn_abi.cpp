@@ -1435,32 +1435,37 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (in_l && (rc = dev_reserve(c, c->stage_in[1], in_l))) return rc;
     if ((rc = dev_reserve(c, c->stage_out[0], (size_t)n * w2 * 4))) return rc;
     if (dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;
-    // Single-block calls (what HM issues): no copy engine at all -- the first kernel reads the inputs from pinned host
-    // memory and the last one writes the results there (two launches and ~12 us less per call than H2D + D2H copies).
-    constexpr size_t kPinIn = 16 << 10, kPinOut = 16 << 10;
-    if (n == 1 && in_a <= kPinIn && in_l <= kPinIn && w2 * 4 <= kPinOut) {
+    // Single-block calls (what HM issues) and the batching service's handfuls: no copy engine at all -- the first kernel reads
+    // the inputs from pinned host memory and the last one writes the results there (two launches and ~12 us less per call
+    // than H2D + D2H copies; at these sizes the PCIe reads hide under the weight stream).
+    constexpr size_t kPinIn = 64 << 10, kPinOut = 64 << 10;
+    if (in_a <= kPinIn && in_l <= kPinIn && (size_t)n * w2 * 4 <= kPinOut) {
         if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 2 * kPinIn + 2 * kPinOut, hipHostMallocDefault));
         char* hp = c->h_pin;
         memcpy(hp, above, in_a);
         if (in_l) memcpy(hp + kPinIn, left, in_l);
         float* p_out = (float*)(hp + 2 * kPinIn);
         int32_t* p_dst = (int32_t*)(hp + 2 * kPinIn + kPinOut);
-        rc = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, 1, p_out, (dst || slot) ? p_dst : nullptr, s);
-        if (rc) return rc;
+        auto pass = [&]() {
+            return run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, n, p_out, (dst || slot) ? p_dst : nullptr, s);
+        };
+        if ((rc = pass())) return rc;
         HIPCHK(c, hipStreamSynchronize(s));
         if (*c->h_range) {                            // left the f16 range: the same pass on the exact-f32 kernels
             *c->h_range = 0;
             c->range_fallbacks++;
             const long keep = c->opt_precision;
             c->opt_precision = 0;
-            rc = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, 1, p_out, (dst || slot) ? p_dst : nullptr, s);
+            rc = pass();
             c->opt_precision = keep;
             if (rc) return rc;
             HIPCHK(c, hipStreamSynchronize(s));
         }
-        if (out) memcpy(out, p_out, w2 * 4);
-        if (dst)
-            for (int y = 0; y < w; y++) memcpy(dst + (size_t)y * dst_stride, p_dst + (size_t)y * w, (size_t)w * 4);
+        if (out) memcpy(out, p_out, (size_t)n * w2 * 4);
+        if (dst) {
+            if (dst_stride == w) memcpy(dst, p_dst, (size_t)n * w2 * 4);
+            else for (int y = 0; y < w; y++) memcpy(dst + (size_t)y * dst_stride, p_dst + (size_t)y * w, (size_t)w * 4);   // n == 1 (checked by the caller)
+        }
         if (slot) {
             slot->in.resize(na + nl);
             memcpy(slot->in.data(), above, na * 4);

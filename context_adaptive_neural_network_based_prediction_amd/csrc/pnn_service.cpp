@@ -66,6 +66,7 @@ bool valid_header(const ReqHeader& h)
 
 struct Client {
     int fd = -1;
+    int pid = 0;                     // peer process (SO_PEERCRED): an encoder holds one connection per session, one request at a time
     std::vector<char> rx;            // bytes of the request being received
     std::vector<char> tx;            // reply bytes not yet accepted by the socket
     size_t tx_off = 0;
@@ -225,6 +226,9 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
                     set_nonblocking(cfd);
                     Client c;
                     c.fd = cfd;
+                    ucred cred;
+                    socklen_t len = sizeof cred;
+                    if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
                     clients.emplace(cfd, std::move(c));
                     ++accepted;
                 }
@@ -244,11 +248,25 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     while (!*stop) {
         poll_once(n_pending ? 0 : 50000);
         if (!n_pending) continue;
-        if (window_us > 0 && (long)n_pending < max_batch) {   // give stragglers a moment to join the batch
+        // Give stragglers a moment to join the batch -- unless every peer PROCESS already has a request in flight: an encoder is
+        // single-threaded and blocks on its request, so nobody else can arrive and waiting would only add latency.
+        auto everyone_waits = [&]() {
+            std::vector<int> pids, waiting;
+            for (const auto& kv : clients) {
+                pids.push_back(kv.second.pid);
+                if (kv.second.in_flight) waiting.push_back(kv.second.pid);
+            }
+            std::sort(pids.begin(), pids.end());
+            pids.erase(std::unique(pids.begin(), pids.end()), pids.end());
+            std::sort(waiting.begin(), waiting.end());
+            waiting.erase(std::unique(waiting.begin(), waiting.end()), waiting.end());
+            return waiting.size() >= pids.size();
+        };
+        if (window_us > 0 && (long)n_pending < max_batch && !everyone_waits()) {
             const auto t0 = Clock::now();
             for (;;) {
                 const long left_us = window_us - (long)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
-                if (left_us <= 0 || (long)n_pending >= max_batch || *stop) break;
+                if (left_us <= 0 || (long)n_pending >= max_batch || *stop || everyone_waits()) break;
                 poll_once(left_us);
             }
         }

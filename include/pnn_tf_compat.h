@@ -223,6 +223,21 @@ public:
             else rc = pnn_predict_fc(ctx_, w, x, n, y);
             if (rc != PNN_OK) return errors::Internal(client_ ? "the PNN batching service failed" : pnn_last_error(ctx_));
             outputs->assign(1, out);
+        } else if (ctx && !above && !left && w <= 8) {
+            // Extension: HM feeds widths 4 and 8 as ONE flattened tensor [above w x 3w | left 2w x w] (TComPattern.cpp:344-354)
+            // because its production models for them are fully-connected; the reference also trains CONVOLUTIONAL nets for
+            // these widths (pnn/results/width_target_{4,8}/convolutional/..., the only trained weights it ships).  A table
+            // entry may point at such a model: the flattened tensor is simply its two portions back to back.
+            if (ctx->NumElements() % (5 * w2)) return errors::InvalidArgument("node_flattened_context must be [N, ", 5 * w2, "]");
+            const int n = (int)(ctx->NumElements() / (5 * w2));
+            Tensor out(DT_FLOAT, TensorShape({n, w, w, 1}));
+            const float* x = ctx->flat<float>().data();
+            float* y = out.flat<float>().data();
+            for (int i = 0; i < n && rc == PNN_OK; i++)
+                rc = client_ ? pnn_client_predict_f32(client_, w, x + i * 5 * w2, x + i * 5 * w2 + 3 * w2, y + i * w2)
+                             : pnn_predict_conv(ctx_, w, x + i * 5 * w2, x + i * 5 * w2 + 3 * w2, 1, y + i * w2);
+            if (rc != PNN_OK) return errors::Internal(client_ ? "the PNN batching service failed" : pnn_last_error(ctx_));
+            outputs->assign(1, out);
         } else {
             if (!above || !left || fetch.find("convolutional/merger/transpose_convolution_") != 0)
                 return errors::NotFound("FetchOutputs node ", fetch, ": not found");

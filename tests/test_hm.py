@@ -130,6 +130,22 @@ def test_hm_encode_decode_roundtrip_on_gpu(hm_built, variant, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hm_with_the_trained_checkpoints(hm_built, tmp_path):
+    """The only trained weights the reference ships (convolutional 4x4 / 8x8, tests/golden/conv{4,8}_single.pnnw) inside the
+    codec: the model table points widths 4 and 8 at them (the look-alike accepts HM's flattened feed for a convolutional
+    model, see pnn_tf_compat.h), widths 16-64 stay random-init.  A trained predictor is a real competitor of the 34 HEVC
+    modes, so the encoder selects it on natural-looking content and the decoder must reproduce every such block."""
+    table, mean_path = run_hm.make_models(str(tmp_path / "models"), trained_small=True)
+    from tests import util
+    frame = np.clip(util.make_plane(128, 192, seed=12).astype(np.int32), 0, 255).astype(np.uint8)   # smooth 8x8 patches + noise
+    res = run_hm.encode_decode("substitution", frame, 27, table, mean_path, str(tmp_path))
+    print(res)
+    assert res["decoder_equals_encoder"] and not res["decoder_hash_error"], res
+    assert res["enc_pnn"][4]["kind"].startswith("convolutional") and res["enc_pnn"][8]["kind"].startswith("convolutional")
+    assert res["dec_pnn"][4]["runs"] + res["dec_pnn"][8]["runs"] > 0, "the trained 4x4 / 8x8 predictors were never selected: %r" % (res,)
+
+
+@pytest.mark.gpu
 def test_hm_concurrent_encodes_through_the_batching_service(hm_built, tmp_path):
     """configs[4] in small: four encoder processes share the GPU through ONE batching-service process
     (PNN_SERVICE_SOCKET; their single-block requests are coalesced into batched launches); each bitstream is then decoded
