@@ -144,7 +144,7 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True):
         torch.cuda.synchronize()
     for _ in range(warmup):
         step()
-    regions = [sharding.timed_steps(step, steps, torch.cuda.synchronize, dist, "cuda") for _ in range(repeats)]
+    regions = [sharding.timed_steps(step, steps, torch.cuda.synchronize, dist, None if os.environ.get("PNN_BENCH_SHARE_GPU") == "1" else "cuda") for _ in range(repeats)]
     if L.pnn_check_range(net.ctx, sp, None) != 0:
         raise RuntimeError(L.pnn_last_error(net.ctx))
     stats = net.last_call_stats()
@@ -267,7 +267,7 @@ def cpu_legs(wl, budget_s=2.0):
     """the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
     an independent PyTorch-CPU formulation (oneDNN / MKL), each batched and at batch 1 sequential (what HM does per TB).
     Bounded samples: every leg runs for about `budget_s` in its own process, at the best of a few thread counts
-    ({all, 64, 16} cores batched, {8, 1} at batch 1: a single block rarely profits from many cores)."""
+    ({all, 64, 32, 16} cores batched, {8, 1} at batch 1: a single block rarely profits from many cores)."""
     import subprocess
     ncores = os.cpu_count()
 
@@ -283,7 +283,7 @@ def cpu_legs(wl, budget_s=2.0):
     for kind, tag in (("oracle", "oracle"), ("torch", "torch_cpu")):
         # the best thread count per leg: on the 256-core GPU box every core is NOT the fastest choice for these sizes
         # (measured: PyTorch-CPU FC 8x8 x 4096 on 256 threads 1.9 k blocks/s, slower than its own batch-1 leg)
-        cands = [run(kind, False, t) for t in sorted({ncores, min(ncores, 64), min(ncores, 16)}, reverse=True)]
+        cands = [run(kind, False, t) for t in sorted({ncores, min(ncores, 64), min(ncores, 32), min(ncores, 16)}, reverse=True)]
         legs[tag + "_batched"] = max(cands, key=lambda r: r.get("blocks_per_s", 0.0))
         legs[tag + "_batched"]["threads_tried"] = [c.get("threads") for c in cands]
         cands = [run(kind, True, t) for t in sorted({min(ncores, 8), 1}, reverse=True)]
@@ -324,8 +324,13 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Plumbing check on a ONE-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): PNN_BENCH_SHARE_GPU=1 puts
+    # every rank on device 0 and joins them over gloo (RCCL refuses two ranks on one device).  Never a measurement.
+    share = os.environ.get("PNN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = sharding.init_ranks("nccl", torch.device("cuda", local_rank))      # "nccl" = RCCL on ROCm; None at N = 1
+    dist = sharding.init_ranks("gloo" if share else "nccl", None if share else torch.device("cuda", local_rank))   # "nccl" = RCCL on ROCm; None at N = 1
 
     precision = int(os.environ.get("PNN_PRECISION", "1"))
     wl = Workload(args.workload, args.batch, rank, local_rank)
@@ -341,7 +346,7 @@ def main():
             "config": {"workload": wl.cfg_name, "width": wl.width, "arch": "fully_connected" if wl.is_fc else "convolutional",
                        "batch_per_gpu": wl.batch, "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
                        "weights": "seeded random init with the reference initialisers' statistics",
-                       "parallelism": "independent blocks sharded over ranks, no data-path collective",
+                       "parallelism": "independent blocks sharded over ranks, no data-path collective" + (" [PNN_BENCH_SHARE_GPU=1: all ranks on ONE device, plumbing check only]" if share else ""),
                        "tile_autotune": "on first use, before the warm-up steps (pnn_set_option autotune)",
                        "device_ramp": "%.2f s of untimed steps before the W warm-up steps (clock ramp)" % RAMP_SECONDS,
                        "timed_regions": "%d regions of exactly K steps, each bracketed by barrier + synchronize; value = median region" % REPEATS},

@@ -806,3 +806,29 @@ def test_python_evaluator_real_weights(pnn, oracle):
     assert res['mean_psnr_pnn'] > 25.0
     with pytest.raises(TypeError):
         evaluation.compute_psnr(img.astype(np.float32), img)
+
+
+def test_bench_two_ranks_on_one_gpu(precision, tmp_path):
+    """bench.py's N > 1 path end to end on the hardware that is there: `python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2` with PNN_BENCH_SHARE_GPU=1 (both ranks on device 0, joined over gloo -- RCCL refuses two ranks on one
+    device): rank / world plumbing, per-rank workloads, barriers, the max-over-ranks clock, ONE JSON line from rank 0 whose
+    value counts both ranks' blocks.  A plumbing check, not a measurement (the driver measures real multi-GPU scaling)."""
+    import json
+    import subprocess
+    import sys
+    if precision != "split_f16":
+        pytest.skip("once is enough")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNN_BENCH_SHARE_GPU="1", PNN_AUTOTUNE="0")
+    env.pop("PNN_PRECISION", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "1024"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 10
+    assert d["config"]["batch_per_gpu"] == 1024
+    assert abs(d["value"] - 2 * 1024 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]   # whole-job blocks over the slowest rank's time
+    assert d["cpu_baseline"] is None and "f32_exact" not in d       # the extras are N = 1 only
