@@ -763,7 +763,13 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     // autotune: 1 = every split GEMM, 2 (default) = only launches of >= 4 GFLOP, where trying all configurations once
     // (~70 x 4 launches) costs a few tens of milliseconds and the choice is worth 10-20 %; 0 = rule-based choice only.
     // All configurations give bit-identical results, so the choice never shows in the predictions.
-    const bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
+    bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
+    if (tune && c->tuned.find(std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M)) == c->tuned.end()) {
+        // timing configurations means synchronising on the caller's stream: never while that stream is being captured
+        // into a hipGraph (the rule-based choice is used instead, nothing is remembered)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
+    }
     if (tune && c->opt_sp_cfg < 0) {
         // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
         // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.

@@ -76,7 +76,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * "autotune" (the first call that meets a new (layer, batch size) pair times every legal configuration of the three
  * split-precision GEMM kernels on the device and keeps the fastest -- all of them give bit-identical results, so only
  * the speed depends on it; 2, default: only for launches of >= 4 GFLOP, i.e. big batches, where it costs a few tens
- * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region),
+ * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region; while the
+ * stream is being captured into a hipGraph nothing is timed -- the rule-based choice is used),
  * "fuse_first" (1, default: a convolutional net's second layer, when it runs on the LDS-resident-image kernel, computes
  * the branch's first (one-input-channel) convolution itself instead of reading it back from memory; 0: separate launch.
  * Bit-identical either way),
