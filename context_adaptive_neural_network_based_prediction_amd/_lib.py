@@ -28,6 +28,7 @@ BACKEND = ctypes.CFUNCTYPE(ci, vp, ci, f32p, f32p, ci, i32p, f32p)   # pnn_servi
 SERVICE_SIGNATURES = {
     "pnn_service_run_backend": (ci, [ctypes.c_char_p, BACKEND, vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
     "pnn_service_run": (ci, [ctypes.c_char_p, vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
+    "pnn_service_run_table": (ci, [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.c_float, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_long)]),
     "pnn_client_connect": (ci, [ctypes.POINTER(vp), ctypes.c_char_p]),
     "pnn_client_predict_pel": (ci, [vp, ci, f32p, f32p, i32p, ci]),
     "pnn_client_predict_f32": (ci, [vp, ci, f32p, f32p, f32p]),

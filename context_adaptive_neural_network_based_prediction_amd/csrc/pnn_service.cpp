@@ -1,15 +1,18 @@
 // Cross-process batching service (include/pnn_service.h): Unix-domain socket server that coalesces the single-block
 // PNN requests of many encoder processes into batched calls, and the matching client stub.  Plain POSIX, no HIP here.
 //
-// The server is one thread and never blocks on a client: sockets are non-blocking, every client has its own receive and
-// send buffer, a request is queued for the GPU only once its last byte has arrived, and a client whose reply cannot be
-// written for kStallMs (it stopped reading) or that sends a malformed header is dropped without disturbing the others.
-// The batching window is timed with ppoll (microsecond resolution).
+// The server never blocks on a client: one thread does all socket work with non-blocking sockets and per-client receive /
+// send buffers (a request is queued for the GPU only once its last byte has arrived; a client whose reply cannot be written
+// for kStallMs or that sends a malformed header is dropped without disturbing the others), worker threads do the backend
+// calls -- one per width when the server owns its contexts (pnn_service_run_table), so that passes of different widths
+// overlap each other and the socket work.
 #include "pnn_service.h"
 
 #include <errno.h>
 #include <fcntl.h>
 #include <poll.h>
+#include <sys/epoll.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
@@ -19,7 +22,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -74,7 +81,6 @@ struct Client {
     bool in_flight = false;          // a complete request of this client is queued or being computed
 };
 
-struct Pending { int fd; bool want_f32; std::vector<float> above, left; };
 
 int make_addr(const char* path, sockaddr_un* a)
 {
@@ -118,139 +124,119 @@ static uint64_t fnv1a64(const void* data, size_t bytes)
     return h;
 }
 
-extern "C" {
+namespace {
 
-int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend, void* user, int max_batch, int window_us,
-                            volatile int* stop, long* stats)
-{
-    if (!backend || !stop || max_batch < 1 || window_us < 0) return PNN_E_ARG;
-    sockaddr_un addr;
-    if (make_addr(socket_path, &addr)) return PNN_E_ARG;
-    const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
-    if (lfd < 0) return PNN_E_IO;
-    unlink(socket_path);
-    if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 256) < 0) { close(lfd); return PNN_E_IO; }
-    set_nonblocking(lfd);
-    std::map<int, Client> clients;
-    long served = 0, calls = 0, largest = 0, accepted = 0, dropped = 0;
-    // complete requests per (width, has_left): a batch shares one model
-    std::map<std::pair<int, int>, std::vector<Pending>> pending;
-    size_t n_pending = 0;
+// ---- the server ---------------------------------------------------------------------------------------------------------------
+// The calling thread does all socket work (accept, receive, reply); `nworkers` worker threads do the backend calls: with one
+// worker per width (pnn_service_run_table: five contexts, one model each) the GPU passes of different widths overlap each
+// other AND the socket work, and while a worker is busy the requests for its width pile up -- the next batch forms by itself.
+// Requests and replies carry a client ID, never a file descriptor (a dropped client's descriptor may be reused at once).
+struct Server {
+    pnn_service_backend backend;
+    void* users[5];
+    int nworkers;                    // 1: one worker serves every width (a single context is not shared between threads); 5: one per width
+    int max_batch, window_us;
+    volatile int* stop;
 
-    auto drop = [&](int fd) {
-        for (auto& kv : pending) {
-            auto& v = kv.second;
-            const size_t before = v.size();
-            v.erase(std::remove_if(v.begin(), v.end(), [fd](const Pending& p) { return p.fd == fd; }), v.end());
-            n_pending -= before - v.size();
-        }
-        close(fd);
-        clients.erase(fd);
-        ++dropped;
-    };
-    // Moves whatever the socket holds into the client's buffer; queues the request when it is complete.
-    // false = client gone or protocol violation.
-    auto receive = [&](Client& c) {
+    struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; };
+    struct Reply { uint64_t id; std::vector<char> bytes; };
+    std::mutex mu;
+    std::condition_variable cv[5];
+    std::vector<Req> queue[5];       // by worker
+    std::vector<Reply> done;
+    int n_peers = 0, n_waiting_peers = 0;   // distinct peer processes connected / with a request in flight (maintained by the I/O thread)
+    bool quit = false;
+    int wake_fd[2] = {-1, -1};       // workers -> I/O thread
+    long served = 0, calls = 0, largest = 0;
+    double busy_s[5] = {0, 0, 0, 0, 0};   // time inside the backend, per worker (PNN_SERVICE_DEBUG)
+
+    static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
+    int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
+
+    void worker(int k)
+    {
+        std::vector<Req> batch;
+        std::vector<float> above, left, out;
+        std::vector<int32_t> dst;
         for (;;) {
-            size_t want = sizeof(ReqHeader);
-            if (c.rx.size() >= sizeof(ReqHeader)) {
-                ReqHeader h;
-                memcpy(&h, c.rx.data(), sizeof h);
-                if (!valid_header(h)) return false;
-                want = sizeof h + ((size_t)h.n_above + h.n_left) * 4;
-                if (c.rx.size() == want) {
-                    if (c.in_flight) return false;            // one outstanding request per client
-                    Pending p;
-                    p.fd = c.fd; p.want_f32 = (h.flags & kWantF32) != 0;
-                    p.above.resize(h.n_above); p.left.resize(h.n_left);
-                    memcpy(p.above.data(), c.rx.data() + sizeof h, (size_t)h.n_above * 4);
-                    if (h.n_left) memcpy(p.left.data(), c.rx.data() + sizeof h + (size_t)h.n_above * 4, (size_t)h.n_left * 4);
-                    pending[{h.width, h.n_left ? 1 : 0}].push_back(std::move(p));
-                    ++n_pending;
-                    c.in_flight = true;
-                    c.rx.clear();
-                    return true;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv[k].wait(lk, [&] { return quit || !queue[k].empty(); });
+                if (quit) return;
+                // an idle worker gives stragglers a moment to join -- unless every peer process already waits for an answer
+                // (an encoder is single-threaded and blocks on its request: nobody else can arrive)
+                if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers < n_peers) {
+                    const auto until = Clock::now() + std::chrono::microseconds(window_us);
+                    cv[k].wait_until(lk, until, [&] { return quit || (int)queue[k].size() >= max_batch || n_waiting_peers >= n_peers; });
+                    if (quit) return;
+                }
+                // one batch = requests of ONE width and ONE input kind, in arrival order
+                const int w = queue[k][0].width;
+                const bool has_left = !queue[k][0].left.empty();
+                batch.clear();
+                for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
+                    if (queue[k][i].width == w && !queue[k][i].left.empty() == has_left) {
+                        batch.push_back(std::move(queue[k][i]));
+                        queue[k].erase(queue[k].begin() + (long)i);
+                    } else {
+                        ++i;
+                    }
                 }
             }
-            const size_t have = c.rx.size();
-            c.rx.resize(want);
-            const ssize_t r = recv(c.fd, c.rx.data() + have, want - have, 0);
-            if (r <= 0) {
-                c.rx.resize(have);
-                if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) return true;   // rest comes later
-                return false;                                 // closed or broken
+            const int w = batch[0].width;
+            const size_t n = batch.size(), w2 = (size_t)w * w, na = batch[0].above.size(), nl = batch[0].left.size();
+            bool any_f32 = false, any_pel = false;
+            above.resize(n * na); left.resize(n * nl);
+            for (size_t i = 0; i < n; i++) {
+                memcpy(above.data() + i * na, batch[i].above.data(), na * 4);
+                if (nl) memcpy(left.data() + i * nl, batch[i].left.data(), nl * 4);
+                (batch[i].want_f32 ? any_f32 : any_pel) = true;
             }
-            c.rx.resize(have + (size_t)r);
-        }
-    };
-    auto flush = [&](Client& c) {                             // false = broken
-        while (c.tx_off < c.tx.size()) {
-            const ssize_t r = send(c.fd, c.tx.data() + c.tx_off, c.tx.size() - c.tx_off, MSG_NOSIGNAL);
-            if (r < 0) {
-                if (errno == EINTR) continue;
-                if (errno == EAGAIN || errno == EWOULDBLOCK) return true;
-                return false;
-            }
-            c.tx_off += (size_t)r;
-        }
-        c.tx.clear(); c.tx_off = 0;
-        return true;
-    };
-    auto poll_once = [&](long timeout_us) {
-        std::vector<pollfd> fds;
-        fds.reserve(clients.size() + 1);
-        fds.push_back({lfd, POLLIN, 0});
-        for (auto& kv : clients) {
-            short ev = 0;
-            if (!kv.second.in_flight) ev |= POLLIN;           // an answered client may send its next request
-            if (!kv.second.tx.empty()) ev |= POLLOUT;
-            fds.push_back({kv.first, ev, 0});
-        }
-        timespec ts{timeout_us / 1000000, (timeout_us % 1000000) * 1000};
-        const int r = ppoll(fds.data(), fds.size(), &ts, nullptr);
-        std::vector<int> gone;
-        if (r > 0) {
-            for (size_t i = 1; i < fds.size(); i++) {
-                if (!fds[i].revents) continue;
-                Client& c = clients[fds[i].fd];
-                bool ok = true;
-                if (fds[i].revents & POLLOUT) ok = flush(c);
-                if (ok && (fds[i].revents & POLLIN)) ok = receive(c);
-                else if (ok && (fds[i].revents & (POLLHUP | POLLERR | POLLNVAL))) ok = false;
-                if (!ok) gone.push_back(fds[i].fd);
-            }
-            if (fds[0].revents & POLLIN) {
-                for (;;) {
-                    const int cfd = accept(lfd, nullptr, nullptr);
-                    if (cfd < 0) break;
-                    set_nonblocking(cfd);
-                    Client c;
-                    c.fd = cfd;
-                    ucred cred;
-                    socklen_t len = sizeof cred;
-                    if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
-                    clients.emplace(cfd, std::move(c));
-                    ++accepted;
+            if (any_pel) dst.resize(n * w2);
+            if (any_f32) out.resize(n * w2);
+            const auto tb0 = Clock::now();
+            const int rc = backend(users[nworkers == 1 ? 0 : k], w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
+                                   any_f32 ? out.data() : nullptr);
+            busy_s[k] += std::chrono::duration<double>(Clock::now() - tb0).count();
+            std::vector<Reply> replies(n);
+            for (size_t i = 0; i < n; i++) {
+                const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
+                replies[i].id = batch[i].id;
+                const char* hp = reinterpret_cast<const char*>(&rh);
+                replies[i].bytes.assign(hp, hp + sizeof rh);
+                if (rc == 0) {
+                    const char* pp = batch[i].want_f32 ? reinterpret_cast<const char*>(out.data() + i * w2) : reinterpret_cast<const char*>(dst.data() + i * w2);
+                    replies[i].bytes.insert(replies[i].bytes.end(), pp, pp + w2 * 4);
                 }
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (auto& r : replies) done.push_back(std::move(r));
+                served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
+            }
+            const char one = 1;
+            (void)!write(wake_fd[1], &one, 1);
         }
-        const auto now = Clock::now();
-        for (auto& kv : clients)
-            if (!kv.second.tx.empty() && std::chrono::duration_cast<std::chrono::milliseconds>(now - kv.second.tx_since).count() > kStallMs)
-                gone.push_back(kv.first);
-        std::sort(gone.begin(), gone.end());
-        gone.erase(std::unique(gone.begin(), gone.end()), gone.end());
-        for (int fd : gone) drop(fd);
-    };
+    }
 
-    std::vector<float> above, left, out;
-    std::vector<int32_t> dst;
-    while (!*stop) {
-        poll_once(n_pending ? 0 : 50000);
-        if (!n_pending) continue;
-        // Give stragglers a moment to join the batch -- unless every peer PROCESS already has a request in flight: an encoder is
-        // single-threaded and blocks on its request, so nobody else can arrive and waiting would only add latency.
-        auto everyone_waits = [&]() {
+    int run(const char* socket_path, long* stats)
+    {
+        sockaddr_un addr;
+        if (make_addr(socket_path, &addr)) return PNN_E_ARG;
+        const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
+        if (lfd < 0) return PNN_E_IO;
+        unlink(socket_path);
+        if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 512) < 0 || pipe(wake_fd) < 0) { close(lfd); return PNN_E_IO; }
+        set_nonblocking(lfd);
+        set_nonblocking(wake_fd[0]);
+        set_nonblocking(wake_fd[1]);
+        std::map<uint64_t, Client> clients;          // by client ID
+        uint64_t next_id = 2;                        // 0 and 1 are the listener and the wake pipe in the epoll set
+        long accepted = 0;
+        std::vector<std::thread> threads;
+        for (int k = 0; k < nworkers; k++) threads.emplace_back([this, k] { worker(k); });
+
+        auto recount_peers = [&]() {                 // under the lock: distinct peer processes, and those with a request in flight
             std::vector<int> pids, waiting;
             for (const auto& kv : clients) {
                 pids.push_back(kv.second.pid);
@@ -260,70 +246,231 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
             pids.erase(std::unique(pids.begin(), pids.end()), pids.end());
             std::sort(waiting.begin(), waiting.end());
             waiting.erase(std::unique(waiting.begin(), waiting.end()), waiting.end());
-            return waiting.size() >= pids.size();
+            n_peers = (int)pids.size(); n_waiting_peers = (int)waiting.size();
         };
-        if (window_us > 0 && (long)n_pending < max_batch && !everyone_waits()) {
-            const auto t0 = Clock::now();
+        auto drop = [&](uint64_t id) {
+            auto it = clients.find(id);
+            if (it == clients.end()) return;
+            close(it->second.fd);
+            clients.erase(it);
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& q : queue) q.erase(std::remove_if(q.begin(), q.end(), [id](const Req& r) { return r.id == id; }), q.end());
+            recount_peers();
+        };
+        // Moves whatever the socket holds into the client's buffer; queues the request when it is complete.
+        // false = client gone or protocol violation.
+        auto receive = [&](uint64_t id, Client& c) {
             for (;;) {
-                const long left_us = window_us - (long)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
-                if (left_us <= 0 || (long)n_pending >= max_batch || *stop || everyone_waits()) break;
-                poll_once(left_us);
-            }
-        }
-        for (auto& kv : pending) {
-            std::vector<Pending>& v = kv.second;
-            const int w = kv.first.first;
-            const size_t w2 = (size_t)w * w;
-            while (!v.empty()) {
-                const size_t n = std::min<size_t>(v.size(), (size_t)max_batch);
-                const size_t na = v[0].above.size(), nl = v[0].left.size();
-                bool any_f32 = false, any_pel = false;
-                above.resize(n * na); left.resize(n * nl);
-                for (size_t i = 0; i < n; i++) {
-                    memcpy(above.data() + i * na, v[i].above.data(), na * 4);
-                    if (nl) memcpy(left.data() + i * nl, v[i].left.data(), nl * 4);
-                    (v[i].want_f32 ? any_f32 : any_pel) = true;
+                size_t want = sizeof(ReqHeader);
+                if (c.rx.size() >= sizeof(ReqHeader)) {
+                    ReqHeader h;
+                    memcpy(&h, c.rx.data(), sizeof h);
+                    if (!valid_header(h)) return false;
+                    want = sizeof h + ((size_t)h.n_above + h.n_left) * 4;
+                    if (c.rx.size() == want) {
+                        if (c.in_flight) return false;        // one outstanding request per client
+                        Req r;
+                        r.id = id; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0;
+                        r.above.resize(h.n_above); r.left.resize(h.n_left);
+                        memcpy(r.above.data(), c.rx.data() + sizeof h, (size_t)h.n_above * 4);
+                        if (h.n_left) memcpy(r.left.data(), c.rx.data() + sizeof h + (size_t)h.n_above * 4, (size_t)h.n_left * 4);
+                        c.in_flight = true;
+                        c.rx.clear();
+                        const int k = worker_of(h.width);
+                        bool all_wait;
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            queue[k].push_back(std::move(r));
+                            recount_peers();
+                            all_wait = n_waiting_peers >= n_peers;
+                        }
+                        cv[k].notify_one();
+                        // the other workers only care when "every peer waits" has just become true (they may be sitting in their window)
+                        if (nworkers > 1 && all_wait) for (int o = 0; o < nworkers; o++) if (o != k) cv[o].notify_one();
+                        return true;
+                    }
                 }
-                if (any_pel) dst.resize(n * w2);
-                if (any_f32) out.resize(n * w2);
-                const int rc = backend(user, w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
-                                       any_f32 ? out.data() : nullptr);
-                ++calls;
-                largest = std::max<long>(largest, (long)n);
-                for (size_t i = 0; i < n; i++) {
-                    auto it = clients.find(v[i].fd);
-                    ++served;
+                const size_t have = c.rx.size();
+                c.rx.resize(want);
+                const ssize_t r = recv(c.fd, c.rx.data() + have, want - have, 0);
+                if (r <= 0) {
+                    c.rx.resize(have);
+                    if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) return true;   // rest comes later
+                    return false;                             // closed or broken
+                }
+                c.rx.resize(have + (size_t)r);
+            }
+        };
+        auto flush = [&](Client& c) {                         // false = broken
+            while (c.tx_off < c.tx.size()) {
+                const ssize_t r = send(c.fd, c.tx.data() + c.tx_off, c.tx.size() - c.tx_off, MSG_NOSIGNAL);
+                if (r < 0) {
+                    if (errno == EINTR) continue;
+                    if (errno == EAGAIN || errno == EWOULDBLOCK) return true;
+                    return false;
+                }
+                c.tx_off += (size_t)r;
+            }
+            c.tx.clear(); c.tx_off = 0;
+            return true;
+        };
+        // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was
+        // what bounded the server (32 encoders: 65 k requests/s); event data = client ID (0: listener, 1: the workers' pipe)
+        const int ep = epoll_create1(0);
+        if (ep < 0) { close(lfd); return PNN_E_IO; }
+        auto ep_ctl = [&](int op, int fd, uint32_t events, uint64_t id) {
+            epoll_event ev;
+            memset(&ev, 0, sizeof ev);
+            ev.events = events; ev.data.u64 = id;
+            epoll_ctl(ep, op, fd, &ev);
+        };
+        ep_ctl(EPOLL_CTL_ADD, lfd, EPOLLIN, 0);
+        ep_ctl(EPOLL_CTL_ADD, wake_fd[0], EPOLLIN, 1);
+        auto arm = [&](uint64_t id, Client& c) { ep_ctl(EPOLL_CTL_MOD, c.fd, EPOLLIN | (c.tx.empty() ? 0u : (uint32_t)EPOLLOUT), id); };
+        epoll_event evs[256];
+        auto last_sweep = Clock::now();
+        std::vector<uint64_t> gone;
+        while (!*stop) {
+            const int r = epoll_wait(ep, evs, 256, 50);
+            gone.clear();
+            for (int i = 0; i < r; i++) {
+                const uint64_t id = evs[i].data.u64;
+                const uint32_t e = evs[i].events;
+                if (id == 0) {
+                    for (;;) {
+                        const int cfd = accept(lfd, nullptr, nullptr);
+                        if (cfd < 0) break;
+                        set_nonblocking(cfd);
+                        Client c;
+                        c.fd = cfd;
+                        ucred cred;
+                        socklen_t len = sizeof cred;
+                        if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
+                        const uint64_t nid = next_id++;
+                        clients.emplace(nid, std::move(c));
+                        ep_ctl(EPOLL_CTL_ADD, cfd, EPOLLIN, nid);
+                        ++accepted;
+                    }
+                    std::lock_guard<std::mutex> lk(mu);
+                    recount_peers();
+                } else if (id == 1) {                         // replies from the workers
+                    char buf[256];
+                    while (read(wake_fd[0], buf, sizeof buf) > 0) {}
+                    std::vector<Reply> ready;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        ready.swap(done);
+                    }
+                    for (Reply& rp : ready) {
+                        auto it = clients.find(rp.id);
+                        if (it == clients.end()) continue;    // dropped meanwhile
+                        Client& c = it->second;
+                        if (c.tx.empty()) c.tx_since = Clock::now();
+                        c.tx.insert(c.tx.end(), rp.bytes.begin(), rp.bytes.end());
+                        c.in_flight = false;
+                        if (!flush(c)) gone.push_back(rp.id);
+                        else if (!c.tx.empty()) arm(rp.id, c);   // the socket took only part of it: wait for EPOLLOUT
+                    }
+                    std::lock_guard<std::mutex> lk(mu);
+                    recount_peers();
+                } else {
+                    auto it = clients.find(id);
                     if (it == clients.end()) continue;
                     Client& c = it->second;
-                    const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
-                    if (c.tx.empty()) c.tx_since = Clock::now();
-                    const char* hp = reinterpret_cast<const char*>(&rh);
-                    c.tx.insert(c.tx.end(), hp, hp + sizeof rh);
-                    if (rc == 0) {
-                        const char* pp = v[i].want_f32 ? reinterpret_cast<const char*>(out.data() + i * w2)
-                                                       : reinterpret_cast<const char*>(dst.data() + i * w2);
-                        c.tx.insert(c.tx.end(), pp, pp + w2 * 4);
-                    }
-                    c.in_flight = false;
-                    if (!flush(c)) { close(c.fd); clients.erase(it); ++dropped; }
+                    bool ok = true;
+                    if (e & EPOLLOUT) { ok = flush(c); if (ok && c.tx.empty()) arm(id, c); }
+                    if (ok && (e & EPOLLIN)) ok = receive(id, c);
+                    else if (ok && (e & (EPOLLHUP | EPOLLERR))) ok = false;
+                    if (!ok) gone.push_back(id);
                 }
-                v.erase(v.begin(), v.begin() + (long)n);
-                n_pending -= n;
             }
+            const auto now = Clock::now();
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(now - last_sweep).count() >= 250) {   // replies nobody reads
+                last_sweep = now;
+                for (auto& kv : clients)
+                    if (!kv.second.tx.empty() && std::chrono::duration_cast<std::chrono::milliseconds>(now - kv.second.tx_since).count() > kStallMs)
+                        gone.push_back(kv.first);
+            }
+            std::sort(gone.begin(), gone.end());
+            gone.erase(std::unique(gone.begin(), gone.end()), gone.end());
+            for (uint64_t id : gone) drop(id);
         }
+        close(ep);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        for (int k = 0; k < nworkers; k++) cv[k].notify_all();
+        for (auto& t : threads) t.join();
+        for (auto& kv : clients) close(kv.second.fd);
+        close(lfd);
+        close(wake_fd[0]); close(wake_fd[1]);
+        unlink(socket_path);
+        if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted; }
+        if (getenv("PNN_SERVICE_DEBUG"))
+            fprintf(stderr, "[pnn-service] seconds inside the backend per worker: %.2f %.2f %.2f %.2f %.2f\n", busy_s[0], busy_s[1], busy_s[2], busy_s[3], busy_s[4]);
+        return PNN_OK;
     }
-    for (auto& kv : clients) close(kv.first);
-    close(lfd);
-    unlink(socket_path);
-    if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted; }
-    (void)dropped;
-    return PNN_OK;
+};
+
+}  // namespace
+
+extern "C" {
+
+int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend, void* user, int max_batch, int window_us,
+                            volatile int* stop, long* stats)
+{
+    if (!backend || !stop || max_batch < 1 || window_us < 0) return PNN_E_ARG;
+    Server sv;
+    sv.backend = backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+    for (void*& u : sv.users) u = user;
+    return sv.run(socket_path, stats);
 }
 
 int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats)
 {
     if (!ctx) return PNN_E_ARG;
     return pnn_service_run_backend(socket_path, ctx_backend, ctx, max_batch, window_us, stop, stats);
+}
+
+int pnn_service_run_table(const char* socket_path, const char* model_table_path, int use_pair, float mean, int device, int max_batch,
+                          int window_us, volatile int* stop, long* stats)
+{
+    if (!stop || max_batch < 1 || window_us < 0 || !model_table_path) return PNN_E_ARG;
+    // one context per width, each with that width's model only: five worker threads, five streams on one GPU
+    int widths[64], pairs[64], chans[64];
+    const char* paths[64];
+    const int n = pnn_parse_model_table(model_table_path, widths, pairs, chans, paths, 64);
+    if (n < 0) return n;
+    bool have_pair = false;
+    for (int i = 0; i < n; i++) have_pair |= pairs[i] != 0;
+    const int want_pair = (have_pair && use_pair) ? 1 : 0;       // TComPrediction.cpp:156
+    std::string dir(model_table_path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    pnn_ctx* ctxs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const int kWidths[5] = {4, 8, 16, 32, 64};
+    int rc = PNN_OK;
+    for (int k = 0; k < 5 && rc == PNN_OK; k++) {
+        const char* hit = nullptr;
+        for (int i = 0; i < n; i++) if (widths[i] == kWidths[k] && pairs[i] == want_pair && chans[i] == 0) hit = paths[i];   // later lines win
+        if (!hit) { rc = PNN_E_MODEL; break; }
+        std::string p(hit);
+        if (!p.empty() && p[0] != '/') {
+            FILE* f = fopen((dir + "/" + p).c_str(), "rb");
+            if (f) { fclose(f); p = dir + "/" + p; }
+        }
+        rc = pnn_create_empty(&ctxs[k], mean, device);
+        if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k], p.c_str());
+    }
+    if (rc == PNN_OK) {
+        Server sv;
+        sv.backend = ctx_backend; sv.nworkers = 5; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+        for (int k = 0; k < 5; k++) sv.users[k] = ctxs[k];
+        rc = sv.run(socket_path, stats);
+    }
+    for (pnn_ctx* c : ctxs) if (c) pnn_destroy(c);
+    return rc;
 }
 
 int pnn_client_connect(pnn_client** out, const char* socket_path)

@@ -20,9 +20,11 @@ from . import _lib
 class Server:
     """The C server loop (`pnn_service_run` / `pnn_service_run_backend`) in a background thread."""
 
-    def __init__(self, socket_path, ctx=None, backend=None, max_batch=256, window_us=200):
-        if (ctx is None) == (backend is None):
-            raise ValueError("give exactly one of `ctx` (a pnn context handle) and `backend` (a Python callable)")
+    def __init__(self, socket_path, ctx=None, backend=None, table=None, max_batch=256, window_us=200, pair=0,
+                 mean=117.8952234192841, device=0):
+        if sum(x is not None for x in (ctx, backend, table)) != 1:
+            raise ValueError("give exactly one of `ctx` (a pnn context handle), `backend` (a Python callable) and `table` (a model table: "
+                             "the server then owns five contexts, one per width, each on its own worker thread)")
         self._L = _lib.lib()
         self._stop = ctypes.c_int(0)
         self._stats = (ctypes.c_long * 4)()
@@ -47,6 +49,9 @@ class Server:
                     return -1
             self._cb = _lib.BACKEND(trampoline)       # keep the callback object alive
             target = lambda: self._L.pnn_service_run_backend(path, self._cb, None, max_batch, window_us, ctypes.byref(self._stop), self._stats)
+        elif table is not None:
+            target = lambda: self._L.pnn_service_run_table(path, table.encode(), pair, ctypes.c_float(mean), device, max_batch, window_us,
+                                                           ctypes.byref(self._stop), self._stats)
         else:
             target = lambda: self._L.pnn_service_run(path, ctx, max_batch, window_us, ctypes.byref(self._stop), self._stats)
 
@@ -117,24 +122,27 @@ def main():
     ap.add_argument("--max-batch", type=int, default=256)
     ap.add_argument("--window-us", type=int, default=200)
     args = ap.parse_args()
-    L = _lib.lib()
-    ctx = ctypes.c_void_p()
-    _lib.check(L.pnn_create(ctypes.byref(ctx), args.table.encode(), args.pair, ctypes.c_float(args.mean), args.device))
-    # a block must get the same prediction whatever batch it travels in (encoder behind the service, decoder alone)
-    _lib.check(L.pnn_set_option(ctx, b"canonical_order", 1), ctx)
     import signal
     import time
-    srv = Server(args.socket, ctx=ctx, max_batch=args.max_batch, window_us=args.window_us)
+    # five contexts (one per width, each with its own worker thread and stream) inside the C server; a block gets the same
+    # prediction whatever batch it travels in (one summation order at every batch size is the library's default)
+    srv = Server(args.socket, table=args.table, pair=args.pair, mean=args.mean, device=args.device, max_batch=args.max_batch,
+                 window_us=args.window_us)
     done = threading.Event()
     for sig in (signal.SIGTERM, signal.SIGINT):       # handlers run in this (main) thread; the C loop runs in the server's thread
         signal.signal(sig, lambda *_: done.set())
+    import os
+    t0 = time.time()
+    while srv.rc is None and not os.path.exists(args.socket) and time.time() - t0 < 300:   # the models load before the socket is bound
+        time.sleep(0.02)
+    if srv.rc is not None or not os.path.exists(args.socket):
+        raise SystemExit("pnn service: cannot start (%s): %s" % (srv.rc, (_lib.lib().pnn_last_error(None) or b"").decode()))
     print("pnn service: listening on %s" % args.socket, flush=True)
     while not done.is_set() and srv.rc is None:
         time.sleep(0.05)
     st = srv.stop()
     print("pnn service: %(requests)d requests in %(backend_calls)d batched calls (largest batch %(largest_batch)d), %(clients)d clients" % st,
           flush=True)
-    L.pnn_destroy(ctx)
 
 
 if __name__ == "__main__":

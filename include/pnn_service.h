@@ -33,6 +33,12 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
  * blocks on one client: a client that stalls in the middle of a request, stops reading its replies or sends a malformed
  * header is dropped and the others go on. */
 int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats);
+/* The production form: the server creates its own contexts from the model table (selection rule of pnn_create:
+ * TComPrediction.cpp:143-178) -- FIVE of them, one per width with that width's model only, each served by its own worker
+ * thread and stream, so that passes of different widths overlap on the GPU and with the socket work.  While a worker is
+ * busy the requests for its width accumulate: the next batch forms by itself. */
+int pnn_service_run_table(const char* socket_path, const char* model_table_path, int use_pair, float mean, int device, int max_batch,
+                          int window_us, volatile int* stop, long* stats);
 
 /* Client side: what an encoder process links instead of owning a GPU context. */
 typedef struct pnn_client pnn_client;

@@ -28,8 +28,12 @@ int oracle_fc_forward(const float* params, int w, const float* ctx, int B, float
 int oracle_conv_forward(const float* params, int w, const float* above, const float* left, int B, float* out);
 void oracle_epilogue(const float* pred, long n, float mean, int32_t* dst);
 uint32_t oracle_block_cost(const int32_t* org, int org_stride, const int32_t* cur, int cur_stride, int w, int hadamard);
-// the one GPU entry point pnn_service.cpp references; never called here (pnn_service_run_backend gets a stand-in)
+// the GPU entry points pnn_service.cpp references; never called here (pnn_service_run_backend gets a stand-in)
 int pnn_predict_f32_pel(pnn_ctx*, int, const float*, const float*, int, float*, int32_t*) { return PNN_E_HIP; }
+// ... and the context calls of pnn_service_run_table (not exercised here: they need the GPU)
+int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
+int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
+void pnn_destroy(pnn_ctx*) {}
 }
 namespace pnn { void set_create_error(const std::string&) {} }
 
