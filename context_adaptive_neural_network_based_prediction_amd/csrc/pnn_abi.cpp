@@ -130,6 +130,7 @@ struct pnn_ctx {
     // entry points report PNN_E_RANGE at the next call / pnn_check_range.
     int* h_range = nullptr;
     long range_fallbacks = 0;
+    const float* host_input = nullptr;                // host_predict: the caller's f32 input rows (FC nets), valid during the call
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
@@ -695,12 +696,12 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
             r.kind = 5; r.flops = flops;
             const LaunchEvents ev{r.e0, r.e1};
             g_launch_events = &ev;
-            const hipError_t le = launch_tapgemm_small(p, x_is_f32, seg_chunks, s);
+            const hipError_t le = launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr);
             g_launch_events = nullptr;
             HIPCHK(c, le);
             c->launch_recs.push_back(r);
         } else {
-            HIPCHK(c, launch_tapgemm_small(p, x_is_f32, seg_chunks, s));
+            HIPCHK(c, launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr));
         }
         c->stat_gemm_launches++; c->stat_launches++;
         c->stat_gemm_flops += flops;
@@ -1453,7 +1454,10 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         float* p_out = (float*)(hp + 2 * kPinIn);
         int32_t* p_dst = (int32_t*)(hp + 2 * kPinIn + kPinOut);
         auto pass = [&]() {
-            return run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, n, p_out, (dst || slot) ? p_dst : nullptr, s);
+            c->host_input = m->is_fc ? above : nullptr;   // small inputs ride in the first kernel's argument block
+            const int r = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, n, p_out, (dst || slot) ? p_dst : nullptr, s);
+            c->host_input = nullptr;
+            return r;
         };
         if ((rc = pass())) return rc;
         HIPCHK(c, hipStreamSynchronize(s));

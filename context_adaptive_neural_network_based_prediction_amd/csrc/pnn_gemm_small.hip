@@ -28,6 +28,8 @@
 // per-column-tile partials the ring kernel's fused output layer produces (pnn_gemm_ring.hip, FUSE, BN = 16 * seg), so
 // fuse_reduce_kernel finishes both the same way.
 #include "pnn_kernels.h"
+#include <cstddef>
+#include <cstring>
 #include <type_traits>
 #include "pnn_device_common.h"
 
@@ -46,8 +48,20 @@ __device__ __forceinline__ void small_wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool AF32>
-__global__ __launch_bounds__(256) void tapgemm_small_kernel(const TapGemmParams p, const int seg)
+// INL (with AF32): the f32 input rows travel INSIDE the kernel-argument block (a single-block FC call: 320 B / 1280 B).  The
+// argument block lives in device memory, written by the host with the launch packet, so the first layer's loaders read the
+// input like any device buffer instead of fetching it from pinned host memory across PCIe (measured on the K = 80 / 320 first
+// layers: 7.5 / 8.4 us with the PCIe read, profiles/r02_batch1_w{4,8}_timeline.txt).
+constexpr int kSmallInlineFloats = 512;
+struct SmallArgs { TapGemmParams p; int seg; };
+struct SmallArgsInline { TapGemmParams p; int seg; float in[kSmallInlineFloats]; };
+
+// The parameter block is read in place, through the CONSTANT address space (the kernel-argument segment): every field, also
+// the runtime-indexed tap table, is then a scalar load and nothing is copied to private memory.
+typedef const __attribute__((address_space(4))) TapGemmParams CSmallParams;
+
+template <bool AF32, bool INL>
+__device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int seg)
 {
     touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int CS = kSmallCS, LA = kSmallLA, D = kSmallD;
@@ -80,7 +94,9 @@ __global__ __launch_bounds__(256) void tapgemm_small_kernel(const TapGemmParams 
     if (wave != 0) {
         // ---- loader wave j: chunk j of every stage ---------------------------------------------------------------------------
         const int j = wave - 1;
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const void* xbase = p.X;
+        if (INL) xbase = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallArgsInline, in);   // generic pointer to the argument block
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, p.x_bytes, 0x00020000);
         const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0x7fffffffu, 0x00020000);
         const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
@@ -227,19 +243,36 @@ __global__ __launch_bounds__(256) void tapgemm_small_kernel(const TapGemmParams 
     if (p.Yhi) report_range(p.range_flag, amax);
 }
 
+template <bool AF32>
+__global__ __launch_bounds__(256) void tapgemm_small_kernel(const SmallArgs args)
+{
+    (void)args;                                      // == the kernel-argument segment, read in place
+    const auto* k = (const __attribute__((address_space(4))) SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    tapgemm_small_body<AF32, false>(k->p, k->seg);
+}
+__global__ __launch_bounds__(256) void tapgemm_small_inline_kernel(const SmallArgsInline args)
+{
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) SmallArgsInline*)__builtin_amdgcn_kernarg_segment_ptr();
+    tapgemm_small_body<true, true>(k->p, k->seg);
+}
+
 size_t tapgemm_small_lds_bytes() { return (size_t)kSmallD * kSmallCS * 4 * 64 * 16; }
 
 // Number of workgroups (one 32 x 32 tile each) the layer needs (what the caller compares with the chip): row tiles x column tiles x classes.
 long tapgemm_small_tiles(const TapGemmParams& p) { return (long)((p.M + 31) / 32) * ((p.Cout + 31) / 32) * p.ncls; }
 
-hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s)
+hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input)
 {
     if (p.M <= 0) return hipSuccess;
     static bool attr_done = false;
     if (!attr_done) {                                // 60 KiB of dynamic LDS: above the 48 KiB a kernel gets without asking
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_small_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
-        if (e != hipSuccess) return e;
+        const void* fns[3] = {reinterpret_cast<const void*>(&tapgemm_small_kernel<false>), reinterpret_cast<const void*>(&tapgemm_small_kernel<true>),
+                              reinterpret_cast<const void*>(&tapgemm_small_inline_kernel)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     unsigned gz = (unsigned)p.ncls;
@@ -249,8 +282,17 @@ hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_c
         gz = (unsigned)((nchunks + seg_chunks - 1) / seg_chunks);
     }
     const dim3 grid((p.M + 31) / 32, (p.Cout + 31) / 32, gz);
-    if (a_is_f32) pnn_launch(tapgemm_small_kernel<true>, grid, dim3(256), tapgemm_small_lds_bytes(), s, p, seg_chunks);
-    else pnn_launch(tapgemm_small_kernel<false>, grid, dim3(256), tapgemm_small_lds_bytes(), s, p, seg_chunks);
+    const size_t nin = (size_t)p.M * p.IH * p.IW * p.Cin;
+    if (a_is_f32 && host_input && nin <= (size_t)kSmallInlineFloats) {   // the input rides in the argument block
+        SmallArgsInline a;
+        a.p = p; a.seg = seg_chunks;
+        memcpy(a.in, host_input, nin * sizeof(float));
+        pnn_launch(tapgemm_small_inline_kernel, grid, dim3(256), tapgemm_small_lds_bytes(), s, a);
+        return hipGetLastError();
+    }
+    const SmallArgs a{p, seg_chunks};
+    if (a_is_f32) pnn_launch(tapgemm_small_kernel<true>, grid, dim3(256), tapgemm_small_lds_bytes(), s, a);
+    else pnn_launch(tapgemm_small_kernel<false>, grid, dim3(256), tapgemm_small_lds_bytes(), s, a);
     return hipGetLastError();
 }
 

@@ -90,7 +90,8 @@ hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_f
 // order as the three big-tile kernels.  a_is_f32: p.X holds plain f32 rows (split in registers); seg_chunks > 0: K-segment
 // mode of an FC output layer (<= 64 outputs), raw partials to p.part[segment][M][64] for launch_fuse_reduce.
 long tapgemm_small_tiles(const TapGemmParams& p);
-hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s);
+// host_input (optional, with a_is_f32): the same rows in HOST memory; when they fit they travel inside the argument block
+hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input = nullptr);
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
