@@ -119,6 +119,7 @@ struct pnn_ctx {
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
     long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
+    long opt_pair = 1;                                // 1: small conv passes run the same layer of both branches as ONE launch
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
     std::map<std::pair<const void*, long>, int> tuned;
@@ -988,11 +989,59 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     const bool par = branches_overlap(c, m, nb) && c->side_stream && c->ws[4].bytes >= (size_t)nb * m->pmax * 4 &&
                      c->ws[5].bytes >= (size_t)nb * m->pmax * 4;   // ensure_ws sized them for this pass's chunk
     hipStream_t const main_stream = s;
-    if (par) {
+    // Small passes (single-block calls, the service's handfuls): the two branches are independent chains of launches that
+    // cost ~4 us each whatever they do.  Layer i of both branches goes into ONE launch (conv_cin1_pair_kernel, then
+    // tapgemm_small_pair_kernel): 13 -> 9 launches for the 16x16 net, no event traffic between streams.  Same kernels' bodies,
+    // same arithmetic: bit-identical to the separate launches.
+    bool pair = sp && c->opt_pair && c->opt_small && c->opt_sp_cfg < 0 && !c->opt_time_launches && !getenv("PNN_PROFILE") &&
+                m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
+    for (size_t i = 0; pair && i < m->branch[0].size(); i++) {
+        long tiles = 0;
+        for (int br = 0; br < 2; br++) {
+            const TapGemmParams& q = m->branch[br][i].proto;
+            tiles += ((nb * q.SH * q.SW + 31) / 32) * ((q.Cout + 31) / 32) * q.ncls;
+        }
+        pair = tiles <= c->opt_small_tiles;
+    }
+    if (pair) {
+        if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
+        if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
+        float* Q[2][2] = {{P[0], P[1]}, {(float*)c->ws[4].p, (float*)c->ws[5].p}};
+        Conv1Params f[2];
+        for (int br = 0; br < 2; br++) {
+            f[br] = m->first[br].proto;
+            f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
+            f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 1;
+        }
+        HIPCHK(c, launch_conv_cin1_pair(f[0], f[1], s));
+        c->stat_launches++;
+        const size_t nl = m->branch[0].size();
+        int cur = 0;
+        for (size_t i = 0; i < nl; i++) {
+            const bool last = i + 1 == nl;
+            TapGemmParams q[2];
+            for (int br = 0; br < 2; br++) {
+                const GemmLayer& L = m->branch[br][i];
+                q[br] = L.proto;
+                q[br].X = Q[br][cur]; q[br].Wp = L.d_w_sp; q[br].bias = L.d_bias; q[br].mean = c->mean; q[br].out_scale = L.sp_inv_scale;
+                q[br].range_flag = c->h_range; q[br].zero = c->d_zero;
+                if (last) q[br].Y = F[br]; else q[br].Yhi = Q[br][cur ^ 1];
+                q[br].M = (int)(nb * q[br].SH * q[br].SW);
+                q[br].x_bytes = (unsigned)(4.0 * (double)nb * q[br].IH * q[br].IW * q[br].Cin);
+                c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
+            }
+            static const bool dbg = getenv("PNN_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[pnn] sp-gemm pair: branch layer %zu, M = %d / %d -> one small-kernel launch\n", i + 1, q[0].M, q[1].M);
+            HIPCHK(c, launch_tapgemm_small_pair(q[0], q[1], s));
+            c->stat_gemm_launches++; c->stat_launches++;
+            cur ^= 1;
+        }
+    }
+    if (par && !pair) {
         HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
-    for (int br = 0; br < 2; br++) {
+    for (int br = 0; br < 2 && !pair; br++) {
         if (par) {
             s = br == 0 ? main_stream : c->side_stream;
             if (br == 1) { P[0] = (float*)c->ws[4].p; P[1] = (float*)c->ws[5].p; }
@@ -1019,7 +1068,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             cur ^= 1;
         }
     }
-    if (par) {
+    if (par && !pair) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
         s = main_stream;
@@ -1243,6 +1292,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
     else if (!strcmp(name, "small")) c->opt_small = value;
     else if (!strcmp(name, "small_max_tiles")) c->opt_small_tiles = value;
+    else if (!strcmp(name, "pair")) c->opt_pair = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;

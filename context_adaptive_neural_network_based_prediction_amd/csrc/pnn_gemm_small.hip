@@ -61,24 +61,23 @@ struct SmallArgsInline { TapGemmParams p; int seg; float in[kSmallInlineFloats];
 typedef const __attribute__((address_space(4))) TapGemmParams CSmallParams;
 
 template <bool AF32, bool INL>
-__device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int seg)
+__device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int seg, const int bx, const int by, const int bz)
 {
-    touch_kernargs<sizeof(TapGemmParams)>();
     constexpr int CS = kSmallCS, LA = kSmallLA, D = kSmallD;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][4 pieces][64 lanes]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: everything derived from it (chunk, tap) stays in SGPRs
     const int l31 = lane & 31, h = lane >> 5;
-    const int cls = seg > 0 ? 0 : (int)blockIdx.z;
-    const int n0 = blockIdx.y * 32;
-    const int mblk = blockIdx.x * 32;
+    const int cls = seg > 0 ? 0 : bz;
+    const int n0 = by * 32;
+    const int mblk = bx * 32;
     const int SP = p.SH * p.SW;
     const int cpt = p.Cin >> 4;
     const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
     const int nchunks = (t1 - t0) * cpt;
     int c0 = 0, c1 = nchunks;                        // this workgroup's chunks [c0, c1) of the class
     if (seg > 0) {
-        c0 = (int)blockIdx.z * seg;
+        c0 = bz * seg;
         c1 = c0 + seg < nchunks ? c0 + seg : nchunks;
     }
     const int nst = (c1 - c0 + CS - 1) / CS;
@@ -206,7 +205,7 @@ __device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int se
 
     if (seg > 0) {                                   // raw partial sums of this K segment (scale, bias, epilogue: fuse_reduce_kernel)
         if (rowok) {
-            float* __restrict__ part = p.part + ((size_t)blockIdx.z * p.M + mg) * 64;
+            float* __restrict__ part = p.part + ((size_t)bz * p.M + mg) * 64;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int n = n0 + 8 * g + 4 * h;
@@ -246,15 +245,35 @@ __device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int se
 template <bool AF32>
 __global__ __launch_bounds__(256) void tapgemm_small_kernel(const SmallArgs args)
 {
+    touch_kernargs<sizeof(SmallArgs)>();
     (void)args;                                      // == the kernel-argument segment, read in place
     const auto* k = (const __attribute__((address_space(4))) SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_small_body<AF32, false>(k->p, k->seg);
+    tapgemm_small_body<AF32, false>(k->p, k->seg, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 __global__ __launch_bounds__(256) void tapgemm_small_inline_kernel(const SmallArgsInline args)
 {
+    touch_kernargs<sizeof(TapGemmParams)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) SmallArgsInline*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_small_body<true, true>(k->p, k->seg);
+    tapgemm_small_body<true, true>(k->p, k->seg, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent layers in ONE launch (the same layer of the two branches of a convolutional net): workgroups [0, na) work
+// on `a`, the rest on `b`.  At small batch a launch costs ~4 us whatever it does; the branches then run side by side
+// instead of one after the other (single-block call of the 16x16 net: 13 -> 9 launches).
+struct SmallArgs2 { TapGemmParams a, b; int na; };
+__global__ __launch_bounds__(256) void tapgemm_small_pair_kernel(const SmallArgs2 args)
+{
+    touch_kernargs<sizeof(SmallArgs2)>();
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) SmallArgs2*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int na = k->na;
+    const bool second = (int)blockIdx.x >= na;
+    CSmallParams* p = second ? &k->b : &k->a;
+    const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
+    const int gx = (p->M + 31) >> 5, gy = (p->Cout + 31) >> 5;
+    const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
+    tapgemm_small_body<false, false>(*p, 0, r % gx, r / gx, bz);
 }
 
 size_t tapgemm_small_lds_bytes() { return (size_t)kSmallD * kSmallCS * 4 * 64 * 16; }
@@ -264,17 +283,17 @@ long tapgemm_small_tiles(const TapGemmParams& p) { return (long)((p.M + 31) / 32
 
 hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input)
 {
-    if (p.M <= 0) return hipSuccess;
     static bool attr_done = false;
     if (!attr_done) {                                // 60 KiB of dynamic LDS: above the 48 KiB a kernel gets without asking
-        const void* fns[3] = {reinterpret_cast<const void*>(&tapgemm_small_kernel<false>), reinterpret_cast<const void*>(&tapgemm_small_kernel<true>),
-                              reinterpret_cast<const void*>(&tapgemm_small_inline_kernel)};
+        const void* fns[4] = {reinterpret_cast<const void*>(&tapgemm_small_kernel<false>), reinterpret_cast<const void*>(&tapgemm_small_kernel<true>),
+                              reinterpret_cast<const void*>(&tapgemm_small_inline_kernel), reinterpret_cast<const void*>(&tapgemm_small_pair_kernel)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_small_lds_bytes());
             if (e != hipSuccess) return e;
         }
         attr_done = true;
     }
+    if (p.M <= 0) return hipSuccess;
     unsigned gz = (unsigned)p.ncls;
     if (seg_chunks > 0) {
         if (p.ncls != 1 || p.Cout > 64 || !p.part) return hipErrorInvalidValue;
@@ -293,6 +312,18 @@ hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_c
     const SmallArgs a{p, seg_chunks};
     if (a_is_f32) pnn_launch(tapgemm_small_kernel<true>, grid, dim3(256), tapgemm_small_lds_bytes(), s, a);
     else pnn_launch(tapgemm_small_kernel<false>, grid, dim3(256), tapgemm_small_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s)
+{
+    if (a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
+    SmallArgs2 args;
+    args.a = a; args.b = b;
+    args.na = (int)tapgemm_small_tiles(a);
+    const hipError_t e = launch_tapgemm_small(TapGemmParams{}, false, 0, s);   // M = 0: only makes sure the LDS attribute is set
+    if (e != hipSuccess) return e;
+    pnn_launch(tapgemm_small_pair_kernel, dim3((unsigned)(args.na + tapgemm_small_tiles(b))), dim3(256), tapgemm_small_lds_bytes(), s, args);
     return hipGetLastError();
 }
 

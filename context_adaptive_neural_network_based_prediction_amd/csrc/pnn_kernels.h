@@ -92,6 +92,7 @@ hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_f
 long tapgemm_small_tiles(const TapGemmParams& p);
 // host_input (optional, with a_is_f32): the same rows in HOST memory; when they fit they travel inside the argument block
 hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input = nullptr);
+hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
@@ -105,6 +106,7 @@ struct Conv1Params {
     int* range_flag; // split output only: raised when a value leaves the f16 range
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
+hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s);   // both branches in one launch (same batch, same kernel size)
 
 // Cout == 1 transposed convolution (last merger layer), optional fused HM epilogue.
 struct TConv1Params {

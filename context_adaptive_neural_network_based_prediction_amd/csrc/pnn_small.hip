@@ -18,17 +18,17 @@ namespace pnn {
 // each lane keeps its 4 output channels' k*k weights in registers, Cout/4 lanes share a pixel so a wave
 // stores 1 KiB (Cout 64) of contiguous NHWC output per instruction.  HBM-bound on the output write.
 // ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) Conv1Params CConv1;   // read in place in the kernel-argument segment: scalar loads
 template <int K>
-__global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
+__device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const int by)
 {
-    touch_kernargs<sizeof(Conv1Params)>();
     extern __shared__ __attribute__((aligned(16))) float xs[];
     // blockIdx.y = band of p.band_rows output rows (small batches: one image is spread over several workgroups; a
     // single workgroup per image took 72 us for a 64x192 portion at batch 1)
-    const int oy0 = blockIdx.y * p.band_rows;
+    const int oy0 = by * p.band_rows;
     const int oy1 = oy0 + p.band_rows < p.OH ? oy0 + p.band_rows : p.OH;
     const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
-    const long b = blockIdx.x;
+    const long b = bx;
     const float* xb = p.X + b * p.IH * p.IW;
     for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
         const int r = idx / PW, c = idx - r * PW;
@@ -60,19 +60,62 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
     if (p.split) report_range(p.range_flag, amax);
 }
 
+template <int K>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const Conv1Params p)
+{
+    touch_kernargs<sizeof(Conv1Params)>();
+    (void)p;
+    conv_cin1_body<K>(*(CConv1*)__builtin_amdgcn_kernarg_segment_ptr(), blockIdx.x, blockIdx.y);
+}
+
+// Both branches' first convolutions in ONE launch (blockIdx.z = branch): at small batch every launch costs ~4 us whatever it
+// does, and the two branches do not depend on each other.
+struct Conv1Pair { Conv1Params a, b; };
+template <int K>
+__global__ __launch_bounds__(256) void conv_cin1_pair_kernel(const Conv1Pair pr)
+{
+    touch_kernargs<sizeof(Conv1Pair)>();
+    (void)pr;
+    const auto* k = (const __attribute__((address_space(4))) Conv1Pair*)__builtin_amdgcn_kernarg_segment_ptr();
+    CConv1* p = blockIdx.z ? &k->b : &k->a;
+    if ((int)blockIdx.y * p->band_rows >= p->OH) return;          // the other branch has more row bands
+    conv_cin1_body<K>(*p, blockIdx.x, blockIdx.y);
+}
+
+static bool conv_cin1_bands(const Conv1Params& p, Conv1Params* q, int* bands_out, size_t* lds_out)
+{
+    *q = p;
+    int bands = 1;                                    // enough workgroups to fill the chip at small batch
+    while ((long)p.B * bands < 512 && bands * 2 <= p.OH) bands *= 2;
+    q->band_rows = (p.OH + bands - 1) / bands;
+    *bands_out = (p.OH + q->band_rows - 1) / q->band_rows;
+    *lds_out = (size_t)((q->band_rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
+    return *lds_out <= 64 * 1024 && (p.Cout == 32 || p.Cout == 64) && (p.k == 3 || p.k == 5);
+}
+
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)
 {
     if (p.B <= 0) return hipSuccess;
-    Conv1Params q = p;
-    int bands = 1;                                    // enough workgroups to fill the chip at small batch
-    while ((long)p.B * bands < 512 && bands * 2 <= p.OH) bands *= 2;
-    q.band_rows = (p.OH + bands - 1) / bands;
-    bands = (p.OH + q.band_rows - 1) / q.band_rows;
-    const size_t lds = (size_t)((q.band_rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
-    if (lds > 64 * 1024 || (p.Cout != 32 && p.Cout != 64)) return hipErrorInvalidValue;
+    Conv1Params q;
+    int bands;
+    size_t lds;
+    if (!conv_cin1_bands(p, &q, &bands, &lds)) return hipErrorInvalidValue;
     if (p.k == 3) hipLaunchKernelGGL(conv_cin1_kernel<3>, dim3(p.B, bands), dim3(256), lds, s, q);
-    else if (p.k == 5) hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3(p.B, bands), dim3(256), lds, s, q);
-    else return hipErrorInvalidValue;
+    else hipLaunchKernelGGL(conv_cin1_kernel<5>, dim3(p.B, bands), dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s)
+{
+    if (a.B <= 0) return hipSuccess;
+    Conv1Pair pr;
+    int ba, bb;
+    size_t la, lb;
+    if (a.B != b.B || a.k != b.k || !conv_cin1_bands(a, &pr.a, &ba, &la) || !conv_cin1_bands(b, &pr.b, &bb, &lb)) return hipErrorInvalidValue;
+    const dim3 grid(a.B, ba > bb ? ba : bb, 2);
+    const size_t lds = la > lb ? la : lb;
+    if (a.k == 3) hipLaunchKernelGGL(conv_cin1_pair_kernel<3>, grid, dim3(256), lds, s, pr);
+    else hipLaunchKernelGGL(conv_cin1_pair_kernel<5>, grid, dim3(256), lds, s, pr);
     return hipGetLastError();
 }
 

@@ -89,6 +89,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * "small" (1, default: split-precision GEMMs with at most "small_max_tiles" (512) output tiles of 32 x 32 -- single-block
  * calls, small batches -- run on tapgemm_small_kernel, one wave per tile spread over the chip, in the SAME per-output
  * summation order as the big-tile kernels; 0: big-tile kernels only),
+ * "pair" (1, default: such small passes of a convolutional net run layer i of BOTH branches as one launch -- they do not
+ * depend on each other and a launch costs ~4 us whatever it does; bit-identical to separate launches; 0: one launch each),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs

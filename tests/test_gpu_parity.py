@@ -747,6 +747,10 @@ def test_one_summation_order_at_every_batch_size(pnn, precision, w, is_fc, big):
     few = run(above[:3], left[:3])
     net.set_option("small", 1)
     assert np.array_equal(few, full[:3])
+    net.set_option("pair", 0)                                        # conv nets: the two branches as separate launches
+    assert np.array_equal(run(above[:3], left[:3]), full[:3])
+    assert np.array_equal(run(above[4:5], left[4:5])[0], full[4])
+    net.set_option("pair", 1)
     for n in (1, 2, 3, 17, 33, min(160, big)):
         lo = big - n
         got = run(above[lo:], left[lo:])
