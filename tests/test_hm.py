@@ -130,6 +130,22 @@ def test_hm_encode_decode_roundtrip_on_gpu(hm_built, variant, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hm_switch_420_chroma_blocks(hm_built, tmp_path):
+    """4:2:0 input through hm_16_15_switch: mode 35 is also a chroma candidate there (TComDataCU.cpp:1373-1375), so the
+    luma-trained nets predict chroma blocks of width 4-32 whose contexts HM gathers with unitWidth = unitHeight = 2
+    (TEncSearch.cpp:1197-1200).  All three planes of the decoder's picture must equal the encoder's."""
+    table, mean_path = run_hm.make_models(str(tmp_path / "models"))
+    y = run_hm.make_frame(128, 192, 31)
+    cb = run_hm.make_frame(64, 96, 32)
+    cr = run_hm.make_frame(64, 96, 33)
+    res = run_hm.encode_decode("switch", y, 32, table, mean_path, str(tmp_path), chroma=(cb, cr))
+    print(res)
+    assert res["chroma_format"] == "420"
+    assert res["decoder_equals_encoder"] and not res["decoder_hash_error"], res
+    assert sum(v["runs"] for v in res["dec_pnn"].values()) > 0
+
+
+@pytest.mark.gpu
 def test_hm_with_the_trained_checkpoints(hm_built, tmp_path):
     """The only trained weights the reference ships (convolutional 4x4 / 8x8, tests/golden/conv{4,8}_single.pnnw) inside the
     codec: the model table points widths 4 and 8 at them (the look-alike accepts HM's flattened feed for a convolutional

@@ -116,15 +116,22 @@ def parse_stats(stderr_text):
     return out
 
 
-def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None, decoder_env=None, timeout=3600):
-    """One encode + decode of `frame` (uint8 [H][W], 4:0:0).  Returns a dict; raises on a codec failure."""
+def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None, decoder_env=None, timeout=3600, chroma=None):
+    """One encode + decode of `frame` (uint8 [H][W], 4:0:0; with `chroma` = (Cb, Cr) planes [H/2][W/2]: 4:2:0, where the PNN also
+    predicts chroma blocks with 2-pixel availability units).  Returns a dict; raises on a codec failure."""
     os.makedirs(work, exist_ok=True)
     h, w = frame.shape
+    fmt = "400" if chroma is None else "420"
+    nbytes = h * w if chroma is None else h * w * 3 // 2
     base = os.path.join(work, "%s_%s_qp%d" % (variant, tag, qp))
     cfg = os.path.join(work, "intra_rext_400.cfg")
     if not os.path.exists(cfg):
         write_cfg(cfg)
-    frame.tofile(base + "_in.yuv")
+    with open(base + "_in.yuv", "wb") as f:
+        f.write(frame.tobytes())
+        if chroma is not None:
+            f.write(np.ascontiguousarray(chroma[0], np.uint8).tobytes())
+            f.write(np.ascontiguousarray(chroma[1], np.uint8).tobytes())
     pnn_args = ["--PathToAdditionalDirectory=%s" % work, "--PathToMeanTraining=%s" % mean_path,
                 "--PathToFilePathsToGraphsOutput=%s" % table]
     e = dict(os.environ)
@@ -132,7 +139,7 @@ def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None,
     e.update(env or {})
     t0 = time.time()
     enc = subprocess.run([exe(variant, "Encoder"), "-c", cfg, "-i", base + "_in.yuv", "-b", base + ".bin", "-o", base + "_rec.yuv",
-                          "-wdt", str(w), "-hgt", str(h), "--InputBitDepth=8", "--InputChromaFormat=400", "--FramesToBeEncoded=1",
+                          "-wdt", str(w), "-hgt", str(h), "--InputBitDepth=8", "--InputChromaFormat=%s" % fmt, "--FramesToBeEncoded=1",
                           "--QP=%d" % qp] + pnn_args, env=e, capture_output=True, text=True, timeout=timeout)
     t_enc = time.time() - t0
     if enc.returncode != 0:
@@ -147,8 +154,9 @@ def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None,
     t_dec = time.time() - t0
     if dec.returncode != 0:
         raise RuntimeError("decoder failed (%d):\n%s\n%s" % (dec.returncode, dec.stdout[-2000:], dec.stderr[-2000:]))
-    rec = np.fromfile(base + "_rec.yuv", np.uint8)[:h * w].reshape(h, w)
-    dcd = np.fromfile(base + "_dec.yuv", np.uint8)[:h * w].reshape(h, w)
+    rec_all = np.fromfile(base + "_rec.yuv", np.uint8)[:nbytes]
+    dcd_all = np.fromfile(base + "_dec.yuv", np.uint8)[:nbytes]
+    rec = rec_all[:h * w].reshape(h, w)
     m = re.search(r"Total Time:\s*([0-9.]+)\s*sec", enc.stdout)                 # hevc/performance.py:33
     md = re.search(r"Total Time:\s*([0-9.]+)\s*sec", dec.stdout)
     md5_bad = "ERROR" in dec.stdout or "***ERROR***" in dec.stdout               # SEIDecodedPictureHash mismatch report
@@ -158,7 +166,8 @@ def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None,
         "dec_total_time_s": float(md.group(1)) if md else None, "dec_wall_s": round(t_dec, 3),
         "bits": 8 * os.path.getsize(base + ".bin"),
         "psnr_rec_db": round(psnr(frame, rec), 3),
-        "decoder_equals_encoder": bool(np.array_equal(rec, dcd)), "decoder_hash_error": md5_bad,
+        "chroma_format": fmt,
+        "decoder_equals_encoder": bool(rec_all.size == nbytes and np.array_equal(rec_all, dcd_all)), "decoder_hash_error": md5_bad,
         "enc_pnn": parse_stats(enc.stderr), "dec_pnn": parse_stats(dec.stderr),
     }
 
