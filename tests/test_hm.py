@@ -95,6 +95,16 @@ def test_python_shadow_reads_the_mean_like_pickle(tmp_path):
         assert r.returncode == 1 and msg in r.stderr, (argv, r.returncode, r.stderr)
 
 
+def test_regular_hm_roundtrip_on_the_cpu(hm_built, tmp_path):
+    """The harness itself, on the codec that needs no GPU: the reference's hm_16_15_regular (stock HM-16.15) encodes and
+    decodes a synthetic 4:0:0 picture; decoder == encoder reconstruction, HM's picture hash agrees."""
+    if not os.path.exists(os.path.join(HM, "_build", "regular", "TAppEncoderStatic")):
+        pytest.skip("regular variant not built")
+    res = run_hm.encode_decode("regular", run_hm.make_frame(128, 192, 5), 32, None, None, str(tmp_path))
+    assert res["decoder_equals_encoder"] and not res["decoder_hash_error"] and res["psnr_rec_db"] > 30.0, res
+    assert res["enc_pnn"] == {} and res["enc_total_time_s"] is not None
+
+
 def test_hm_without_gpu_fails_like_a_missing_graph(hm_built, tmp_path):
     import torch
     if torch.cuda.is_available():

@@ -132,8 +132,9 @@ def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None,
         if chroma is not None:
             f.write(np.ascontiguousarray(chroma[0], np.uint8).tobytes())
             f.write(np.ascontiguousarray(chroma[1], np.uint8).tobytes())
-    pnn_args = ["--PathToAdditionalDirectory=%s" % work, "--PathToMeanTraining=%s" % mean_path,
-                "--PathToFilePathsToGraphsOutput=%s" % table]
+    # hm_16_15_regular = the reference's stock HM-16.15 (+ mode statistics): no PNN, no extra options; the CPU-only yardstick
+    pnn_args = [] if variant == "regular" else ["--PathToAdditionalDirectory=%s" % work, "--PathToMeanTraining=%s" % mean_path,
+                                                "--PathToFilePathsToGraphsOutput=%s" % table]
     e = dict(os.environ)
     e["PNN_STATS"] = "1"
     e.update(env or {})
@@ -174,7 +175,7 @@ def encode_decode(variant, frame, qp, table, mean_path, work, tag="0", env=None,
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--variant", default="substitution", choices=["substitution", "switch"])
+    ap.add_argument("--variant", default="substitution", choices=["substitution", "switch", "regular"])
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--qp", type=int, default=32)
@@ -185,7 +186,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    table, mean_path = make_models(os.path.join(args.out, "models"), trained_small=args.trained_small)
+    table, mean_path = (None, None) if args.variant == "regular" else make_models(os.path.join(args.out, "models"), trained_small=args.trained_small)
     env = {}
     srv = None
     if args.service:
