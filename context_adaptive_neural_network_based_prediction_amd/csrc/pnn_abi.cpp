@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace pnn;
@@ -184,16 +185,32 @@ int upload(pnn_ctx* c, Model* m, const float* host, size_t n, float** out)
     return PNN_OK;
 }
 
+// Weight packing runs once per model load, but a process of the reference's kind (one HM encoder or decoder) loads five
+// models at start-up: 27 M parameters, each written into two strided layouts.  The chunks are independent: a few threads.
+template <typename F>
+void parallel_chunks(long nchunks, F fn)
+{
+    const long work = nchunks;
+    int nt = (int)std::min<long>(8, std::max<long>(1, work / 64));
+    nt = std::min<int>(nt, (int)std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) { fn(0, nchunks); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([=] { fn(nchunks * t / nt, nchunks * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
+
 // [K][N] row-major -> [K/16][4][Npad][4] (k = 16*chunk + 4*q + e), zero-padded columns.
 std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad)
 {
     std::vector<float> out((size_t)K * npad, 0.f);
-    for (long k = 0; k < K; k++) {
-        const long ch = k >> 4; const int q = (k >> 2) & 3, e = k & 3;
-        float* dst = out.data() + (((size_t)ch * 4 + q) * npad) * 4 + e;
-        const float* src = kn.data() + (size_t)k * N;
-        for (int n = 0; n < N; n++) dst[(size_t)n * 4] = src[n];
-    }
+    parallel_chunks(K / 16, [&](long c0, long c1) {
+        for (long k = 16 * c0; k < 16 * c1; k++) {
+            const long ch = k >> 4; const int q = (k >> 2) & 3, e = k & 3;
+            float* dst = out.data() + (((size_t)ch * 4 + q) * npad) * 4 + e;
+            const float* src = kn.data() + (size_t)k * N;
+            for (int n = 0; n < N; n++) dst[(size_t)n * 4] = src[n];
+        }
+    });
     return out;
 }
 
@@ -202,17 +219,19 @@ std::vector<float> pack_kn_split(const std::vector<float>& kn, long K, int N, in
 {
     std::vector<float> out((size_t)K * npad, 0.f);              // same byte count as the f32 pack
     _Float16* o = reinterpret_cast<_Float16*>(out.data());
-    for (long k = 0; k < K; k++) {
-        const long ch = k >> 4; const int h = (k >> 3) & 1, j = k & 7;
-        const float* src = kn.data() + (size_t)k * N;
-        for (int n = 0; n < N; n++) {
-            const float w = src[n] * scale;
-            const _Float16 hi = (_Float16)w;
-            const _Float16 lo = (_Float16)(w - (float)hi);
-            o[((((size_t)ch * 2 + 0) * 2 + h) * npad + n) * 8 + j] = hi;
-            o[((((size_t)ch * 2 + 1) * 2 + h) * npad + n) * 8 + j] = lo;
+    parallel_chunks(K / 16, [&](long c0, long c1) {
+        for (long k = 16 * c0; k < 16 * c1; k++) {
+            const long ch = k >> 4; const int h = (k >> 3) & 1, j = k & 7;
+            const float* src = kn.data() + (size_t)k * N;
+            for (int n = 0; n < N; n++) {
+                const float w = src[n] * scale;
+                const _Float16 hi = (_Float16)w;
+                const _Float16 lo = (_Float16)(w - (float)hi);
+                o[((((size_t)ch * 2 + 0) * 2 + h) * npad + n) * 8 + j] = hi;
+                o[((((size_t)ch * 2 + 1) * 2 + h) * npad + n) * 8 + j] = lo;
+            }
         }
-    }
+    });
     return out;
 }
 
