@@ -5,7 +5,9 @@
 // hevc/hm_16_15_substitution/source/Lib/TLibCommon/TComPrediction.cpp:181-236, same lines in hm_16_15_switch;
 // the Python side is the four-line hevc/hm_common/loading.py: `pickle.load(open(path, 'rb'))`).
 // This header gives those two files the 17 CPython names they use, backed by a parser for a pickled float, so that
-// both HM variants compile unchanged and link with neither libpython nor TensorFlow:
+// both HM variants compile unchanged and link with neither libpython nor TensorFlow (plus the seven more names the
+// reference's own test program uses -- hevc/hm_common/c++/source_test/tests.cpp:3-90,823-892: PyList_Check / _Size /
+// _GetItem, PyString_AsString, PyInt_CheckExact / PyInt_AsLong for its pickled integer; tools/hm builds that program too):
 //
 //   Py_Initialize / Py_IsInitialized / Py_Finalize
 //   PySys_GetObject("path"), PyString_FromString, PyList_Insert, Py_DECREF          (append_sys_path)
@@ -37,13 +39,14 @@
 #define PY_VERSION "2.7-pnn-shadow"
 
 struct _object {
-    enum Kind { STRING, LIST, MODULE, FUNCTION, FLOAT, ERROR_STATE };
+    enum Kind { STRING, LIST, MODULE, FUNCTION, FLOAT, INT, ERROR_STATE };
     long ob_refcnt;
     Kind kind;
     std::string s;                      // STRING: value; MODULE / FUNCTION: name; ERROR_STATE: message
     std::vector<_object*> items;        // LIST
     double d;                           // FLOAT
-    explicit _object(Kind k) : ob_refcnt(1), kind(k), d(0.) {}
+    long i;                             // INT
+    explicit _object(Kind k) : ob_refcnt(1), kind(k), d(0.), i(0) {}
 };
 typedef struct _object PyObject;
 
@@ -73,11 +76,14 @@ inline PyObject* set_error(const std::string& msg)
     return NULL;
 }
 
-// pickle.load of a float: protocol 0 ('F' + repr + '\n'), protocols 1-4 ('G' + big-endian IEEE double), with the
-// PROTO / FRAME / MEMOIZE / PUT framing opcodes a float pickle can carry; anything else is "not a float pickle".
-inline bool unpickle_float(const std::vector<unsigned char>& b, double* out)
+// pickle.load of a float or an int: protocol 0 ('F' / 'I' + repr + '\n'), protocols 1-4 ('G' + big-endian IEEE double; 'K' /
+// 'M' / 'J' = 1- / 2- / 4-byte little-endian int, 0x8a = LONG1), with the PROTO / FRAME / MEMOIZE / PUT framing opcodes such a
+// pickle can carry; anything else is "not a number pickle".  *is_int tells which of *out / *iout holds the value.
+inline bool unpickle_number(const std::vector<unsigned char>& b, double* out, long* iout, bool* is_int)
 {
     size_t i = 0;
+    *is_int = false;
+    auto ends = [&](size_t j) { return j < b.size() && (b[j] == '.' || b[j] == 'q' || b[j] == 0x94 || b[j] == 'p'); };
     while (i < b.size()) {
         const unsigned char op = b[i++];
         switch (op) {
@@ -92,14 +98,30 @@ inline bool unpickle_float(const std::vector<unsigned char>& b, double* out)
             unsigned long long u = 0;
             for (int k = 0; k < 8; k++) u = (u << 8) | b[i + k];
             memcpy(out, &u, 8);
-            i += 8;
-            return i < b.size() && (b[i] == '.' || b[i] == 'q' || b[i] == 0x94 || b[i] == 'p');
+            return ends(i + 8);
         }
         case 'F': {
             std::string t;
             while (i < b.size() && b[i] != '\n') t.push_back((char)b[i++]);
             char* end = NULL;
             *out = strtod(t.c_str(), &end);
+            return end != t.c_str();
+        }
+        case 'K': case 'M': case 'J': case 0x8a: {
+            size_t n = op == 'K' ? 1 : op == 'M' ? 2 : 4;
+            if (op == 0x8a) { if (i >= b.size()) return false; n = b[i++]; }
+            if (n > 8 || i + n > b.size()) return false;
+            unsigned long long u = 0;
+            for (size_t k = 0; k < n; k++) u |= (unsigned long long)b[i + k] << (8 * k);
+            if ((op == 'J' || op == 0x8a) && n > 0 && n < 8 && (b[i + n - 1] & 0x80)) u |= ~0ull << (8 * n);   // sign extension
+            *iout = (long)u; *is_int = true;
+            return ends(i + n);
+        }
+        case 'I': case 'L': {
+            std::string t;
+            while (i < b.size() && b[i] != '\n') t.push_back((char)b[i++]);
+            char* end = NULL;
+            *iout = strtol(t.c_str(), &end, 10); *is_int = true;
             return end != t.c_str();
         }
         default: return false;
@@ -118,7 +140,9 @@ inline PyObject* load_via_pickle(const std::string& path)
     while ((n = fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
     fclose(f);
     double v = 0.;
-    if (!unpickle_float(bytes, &v)) {
+    long iv = 0;
+    bool is_int = false;
+    if (!unpickle_number(bytes, &v, &iv, &is_int)) {
         // extension: the mean as text ("117.8952234192841")
         const std::string t(bytes.begin(), bytes.end());
         char* end = NULL;
@@ -127,8 +151,8 @@ inline PyObject* load_via_pickle(const std::string& path)
         if (bytes.empty() || end == t.c_str() || (end && *end))
             return set_error("UnpicklingError: '" + path + "' holds neither a pickled float nor a number");
     }
-    PyObject* o = new _object(_object::FLOAT);
-    o->d = v;
+    PyObject* o = new _object(is_int ? _object::INT : _object::FLOAT);
+    o->d = v; o->i = iv;
     return o;
 }
 
@@ -226,6 +250,28 @@ inline PyObject* PyObject_CallFunctionObjArgs(PyObject* callable, ...)
         return pnn_py::set_error("TypeError: load_via_pickle() takes exactly 1 argument (a path)");
     return pnn_py::load_via_pickle(arg0->s);
 }
+
+typedef long Py_ssize_t;
+inline int PyList_Check(PyObject* o) { return o && o->kind == _object::LIST; }
+inline Py_ssize_t PyList_Size(PyObject* o) { return PyList_Check(o) ? (Py_ssize_t)o->items.size() : -1; }
+inline PyObject* PyList_GetItem(PyObject* o, Py_ssize_t i)                      // borrowed
+{
+    if (!PyList_Check(o) || i < 0 || i >= (Py_ssize_t)o->items.size()) return pnn_py::set_error("IndexError: list index out of range");
+    return o->items[(size_t)i];
+}
+inline char* PyString_AsString(PyObject* o)
+{
+    if (!o || o->kind != _object::STRING) { pnn_py::set_error("TypeError: expected string"); return NULL; }
+    return const_cast<char*>(o->s.c_str());
+}
+inline int PyInt_CheckExact(PyObject* o) { return o && o->kind == _object::INT; }
+inline int PyLong_CheckExact(PyObject* o) { return PyInt_CheckExact(o); }
+inline long PyInt_AsLong(PyObject* o)
+{
+    if (!PyInt_CheckExact(o)) { pnn_py::set_error("TypeError: an integer is required"); return -1; }
+    return o->i;
+}
+inline long PyLong_AsLong(PyObject* o) { return PyInt_AsLong(o); }
 
 inline int PyFloat_CheckExact(PyObject* o) { return o && o->kind == _object::FLOAT; }
 inline int PyFloat_Check(PyObject* o) { return PyFloat_CheckExact(o); }

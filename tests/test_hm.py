@@ -95,6 +95,115 @@ def test_python_shadow_reads_the_mean_like_pickle(tmp_path):
         assert r.returncode == 1 and msg in r.stderr, (argv, r.returncode, r.stderr)
 
 
+REF_TEST_EXE = os.path.join(HM, "_build", "hm_common", "executable")
+
+
+def _reference_tree(tmp_path, models=()):
+    """A scratch tree laid out like the reference checkout, as far as its test program reads it (it is run from the root
+    with relative paths, hevc/hm_common/c++/README.md:18-33): the three small data files of hevc/hm_common/c++/pseudo_data
+    (committed copies: tests/golden/hm_common_pseudo_data) and, in place of its frozen test graphs -- which are not in the
+    checkout -- seeded .pnnw models under the very names it opens."""
+    import shutil
+    from context_adaptive_neural_network_based_prediction_amd import weights as wts
+    root = tmp_path / "ref_root"
+    data = root / "hevc" / "hm_common" / "c++" / "pseudo_data"
+    (root / "hevc" / "hm_common" / "c++" / "pseudo_visualization").mkdir(parents=True)
+    data.mkdir(parents=True)
+    for f in os.listdir(os.path.join(ROOT, "tests", "golden", "hm_common_pseudo_data")):
+        shutil.copy(os.path.join(ROOT, "tests", "golden", "hm_common_pseudo_data", f), str(data / f))
+    params = {}
+    for w, is_fc in models:
+        (data / ("width_target_%d" % w)).mkdir()
+        params[w] = wts.init_params(w, is_fc, seed=40 + w, bias_std=0.05)
+        wts.save_pnnw(str(data / ("width_target_%d" % w) / "graph_output.pbtxt"), params[w], w, is_fc)
+    return str(root), params
+
+
+def _run_ref_test(root, *argv):
+    r = subprocess.run([REF_TEST_EXE] + list(argv), cwd=root, capture_output=True, text=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_reference_test_program_on_the_boundary_cpu(hm_built, tmp_path):
+    """The reference's OWN test program of its HM glue (hevc/hm_common/c++/source_test, built unchanged by tools/hm): the
+    tests that need no network run here -- tensor creation through the look-alike, the context gather against the
+    expectations printed beside it, the model-table parsers on the reference's fixtures, the embedded-Python calls
+    (sys.path, get_callable, the pickled integer -1 whose value is also PyInt_AsLong's error code)."""
+    if not os.path.exists(REF_TEST_EXE):
+        pytest.skip("hm_common test program not built")
+    root, _ = _reference_tree(tmp_path)
+    rc, out, err = _run_ref_test(root, "create_tensors_flattened_context")
+    assert rc == 0 and "Dimension of index 1: 80" in out and "Dimension of index 1: 320" in out
+    rc, out, err = _run_ref_test(root, "create_tensors_context_portion")
+    assert rc == 0 and out.count("Dimension of index 3: 1") == 6 and "Dimension of index 2: 192" in out and "Dimension of index 1: 128" in out
+    rc, out, err = _run_ref_test(root, "parse_file_strings_three_keys")
+    assert rc == 0
+    for line in ("Key: {4, 0}, value: path_0", "Key: {32, 1}, value: path_4", "Key: {64, 2}, value: path_3", "Key: {8, 2}, value: path_2",
+                 "Key: {32, 1}, value: path_1"):
+        assert line in out, out
+    rc, out, err = _run_ref_test(root, "parse_file_strings_one_key")
+    assert rc == 0 and "Key: 0, value: path_1" in out and "Key: 1, value: path_0" in out
+    rc, out, err = _run_ref_test(root, "append_sys_path", "hevc/hm_common")
+    assert rc == 0 and "hevc/hm_common" in out
+    rc, out, err = _run_ref_test(root, "get_callable", "hevc/hm_common")
+    assert rc == 0 and "No error occurs" in out
+    rc, out, err = _run_ref_test(root, "load_via_pickle", "hevc/hm_common")
+    assert rc == 0 and "Loaded integer: -1" in out
+    rc, out, err = _run_ref_test(root, "extract_context_portions")
+    assert rc == 0 and out.count("Expected buffer:") >= 9
+    rc, out, err = _run_ref_test(root, "check_overlapping_intra_pattern_context_portions")
+    assert rc == 0 and "No error occurs" in out
+    # without a GPU, loading a graph fails the way a missing TensorFlow graph does: an error Status, test returns -1
+    import torch
+    if not torch.cuda.is_available():
+        root2, _ = _reference_tree(tmp_path / "b", models=((4, True),))
+        rc, out, err = _run_ref_test(root2, "load_graph")
+        assert rc != 0 and "no CPU fallback" in err
+
+
+def _parse_block(out, w):
+    rows = [l.split() for l in out.splitlines() if len(l.split()) == w]
+    vals = []
+    for r in rows:
+        try:
+            vals.append([float(v) for v in r])
+        except ValueError:
+            pass
+    assert len(vals) >= w, out
+    return np.array(vals[-w:], np.float32)
+
+
+@pytest.mark.gpu
+def test_reference_test_program_on_the_boundary_gpu(hm_built, tmp_path, oracle):
+    """The network tests of the same program on the MI355X: load_graph / load_graphs, and its two prediction tests -- an FC
+    4x4 net fed a flat -100 context with a 0 line in the column above the block, a conv 16x16 net fed -80 with a +20 line
+    (tests.cpp:943-1156).  The trained graphs it was written for are not in the checkout, so the models are seeded
+    random-init ones and the printed predictions are compared with the oracle on the same inputs instead of with the
+    "second column close to 0 / 20" remark."""
+    if not os.path.exists(REF_TEST_EXE):
+        pytest.skip("hm_common test program not built")
+    root, params = _reference_tree(tmp_path, models=((4, True), (8, True), (16, False)))
+    for name in ("load_graph", "load_graphs"):
+        rc, out, err = _run_ref_test(root, name)
+        assert rc == 0, err
+    rc, out, err = _run_ref_test(root, "prediction_neural_network_fully_connected")
+    assert rc == 0, err
+    w = 4
+    ctx = np.full((1, 5 * w * w), -100.0, np.float32)
+    for i in range(w):
+        ctx[0, w + 1 + i * 3 * w] = 0.0
+    want = oracle.fc_forward(params[4], w, ctx)[0]
+    np.testing.assert_allclose(_parse_block(out, w), want, rtol=0, atol=2e-3)
+    rc, out, err = _run_ref_test(root, "prediction_neural_network_convolutional")
+    assert rc == 0, err
+    w = 16
+    above = np.full((1, w, 3 * w), -80.0, np.float32)
+    left = np.full((1, 2 * w, w), -80.0, np.float32)
+    above[0, :, w + 1] = 20.0
+    want = oracle.conv_forward(params[16], w, above, left)[0]
+    np.testing.assert_allclose(_parse_block(out, w), want, rtol=0, atol=2e-3)
+
+
 def test_regular_hm_roundtrip_on_the_cpu(hm_built, tmp_path):
     """The harness itself, on the codec that needs no GPU: the reference's hm_16_15_regular (stock HM-16.15) encodes and
     decodes a synthetic 4:0:0 picture; decoder == encoder reconstruction, HM's picture hash agrees."""
