@@ -470,3 +470,70 @@ def test_host_code_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sanitize_host: ok" in r.stdout
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_model_table_parser_against_the_reference_parser(tmp_path):
+    """pnn_parse_model_table (csrc/pnn_host.cpp) vs the REFERENCE's parse_file_strings_three_keys (tools.cpp:52-111, built into
+    oracle/_ref/libref_tools.so by oracle/Makefile) on fuzzed tables: runs of ',' / ';' delimiters, blank and whitespace-only
+    lines, padded fields, keys with trailing text, CRLF line ends, duplicate keys (later lines win), files with and without a
+    final newline.  Where the reference throws (a line with fewer than four fields, a key that is not a number) this
+    parser returns PNN_E_IO."""
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libref_tools.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libref_tools.so not built (no /root/reference here)")
+    R = ctypes.CDLL(ref_path)
+    R.ref_parse_three_keys.restype = ctypes.c_int
+    R.ref_parse_three_keys.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    L = _lib.lib()
+    rng = np.random.RandomState(11)
+    ws = [" ", "  ", "\t", ""]
+
+    def pad(tok):
+        return ws[rng.randint(len(ws))] + tok + ws[rng.randint(len(ws))]
+
+    def good_line():
+        w = str(rng.choice([4, 8, 16, 32, 64]))
+        if rng.rand() < 0.15:
+            w += "px"                                  # std::stoul stops at the first non-digit
+        fields = [w, str(rng.randint(0, 3)), str(rng.randint(0, 3)), "dir %d/model_%d.pnnw" % (rng.randint(3), rng.randint(50))]
+        seps = ["".join(rng.choice([",", ";"], rng.randint(1, 3))) for _ in range(3)]
+        return pad(fields[0]) + seps[0] + pad(fields[1]) + seps[1] + pad(fields[2]) + seps[2] + pad(fields[3])
+
+    n_ok = n_bad = 0
+    for case in range(300):
+        lines = []
+        for _ in range(rng.randint(0, 12)):
+            r = rng.rand()
+            if r < 0.2:
+                lines.append(ws[rng.randint(len(ws))] * rng.randint(0, 3))          # blank / whitespace-only
+            elif r < 0.27 and case % 3 == 0:
+                lines.append(rng.choice(["4,0,0", "x,0,0,p", "4,,0", "8;1"]))        # malformed
+            else:
+                lines.append(good_line())
+        eol = "\r\n" if case % 5 == 0 else "\n"
+        text = eol.join(lines) + (eol if case % 2 else "")
+        path = str(tmp_path / ("t%d.txt" % case))
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        buf = ctypes.create_string_buffer(1 << 16)
+        nref = R.ref_parse_three_keys(path.encode(), b",;", buf, len(buf))
+        widths, pairs, chans = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
+        paths = (ctypes.c_char_p * 64)()
+        n = L.pnn_parse_model_table(path.encode(), widths, pairs, chans, paths, 64)
+        if nref == -2:                                  # the reference threw
+            assert n == -2, (case, text, n)
+            n_bad += 1
+            continue
+        assert nref >= 0 and n >= 0, (case, text, nref, n)
+        want = {}
+        for l in buf.value.decode().splitlines():
+            w, p, c, v = l.split(" ", 3)
+            want[(int(w), int(p), int(c))] = v
+        got = {}
+        for i in range(n):
+            got[(widths[i], pairs[i], chans[i])] = paths[i].decode()               # later lines overwrite, as in std::map
+        assert got == want, (case, text, got, want)
+        n_ok += 1
+    assert n_ok > 150 and n_bad > 10
+    assert R.ref_parse_three_keys(str(tmp_path / "absent.txt").encode(), b",;", buf, len(buf)) == -1
+    assert L.pnn_parse_model_table(str(tmp_path / "absent.txt").encode(), widths, pairs, chans, paths, 64) == -2
