@@ -836,3 +836,25 @@ def test_bench_two_ranks_on_one_gpu(precision, tmp_path):
     assert d["config"]["batch_per_gpu"] == 1024
     assert abs(d["value"] - 2 * 1024 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]   # whole-job blocks over the slowest rank's time
     assert d["cpu_baseline"] is None and "f32_exact" not in d       # the extras are N = 1 only
+
+
+@pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (8, False), (16, False), (32, False)])
+def test_known_answer_behaviours_on_gpu(pnn, oracle, w, is_fc):
+    """SURVEY 8(c) behaviours on the HIP path: an all-zero (= flat training-mean) context through a net with zero biases gives
+    exactly zero -- the "grey square" of test_pnn.py:456-459, Pel = round(mean) = 118 after the HM epilogue -- alone and in
+    any batch position; scaling the context by a positive factor scales the prediction of a bias-free net (LeakyReLU is
+    positively homogeneous) -- a cheap check that no stage adds a stray constant."""
+    params = wts.init_params(w, is_fc, seed=77, bias_std=0.0)        # the reference's initialisation: zero biases
+    n = 5
+    above, left = util.make_contexts(w, n, 78, masked_fraction=0.0)
+    above[2] = 0.0
+    left[2] = 0.0
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    out = run(above, left)
+    assert np.all(out[2] == 0.0)
+    assert np.all(run(above[2:3], left[2:3]) == 0.0)
+    pel = net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))
+    assert np.all(pel[2] == 118)
+    half = run(0.5 * above, 0.5 * left)
+    np.testing.assert_allclose(half, 0.5 * out, rtol=0, atol=FLOAT_ATOL)
