@@ -1464,11 +1464,20 @@ int pnn_predict_tbs_cost_device(pnn_ctx* c, int width, const void* d_plane, cons
 
 // ---- host-buffer entry points ----------------------------------------------------------------------------
 
-static uint64_t fnv1a(const void* data, size_t bytes, uint64_t h = 1469598103934665603ull)
+// Hash of the input bytes for the prediction cache: 8 bytes per step (a byte-wise FNV-1a cost 1.3 us per 8x8 lookup and 80 us
+// per 64x64 one -- HM's RD search makes ~100 k lookups per picture); the entry is confirmed with memcmp, so only the spread matters.
+static uint64_t hash_bytes(const void* data, size_t bytes, uint64_t h = 0x9e3779b97f4a7c15ull)
 {
     const unsigned char* p = static_cast<const unsigned char*>(data);
-    for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
-    return h;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    for (; i < bytes; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h ^ (h >> 29);
 }
 
 static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst,
@@ -1490,8 +1499,8 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
             const size_t entry = (na + nl + 2 * w2) * 4 + 64;
             table.resize(std::max<size_t>(16, ((size_t)c->opt_cache_mb << 20) / 5 / entry));
         }
-        hash = fnv1a(above, na * 4);
-        if (nl) hash = fnv1a(left, nl * 4, hash);
+        hash = hash_bytes(above, na * 4);
+        if (nl) hash = hash_bytes(left, nl * 4, hash);
         slot = &table[hash % table.size()];
         if (slot->valid && slot->hash == hash && !memcmp(slot->in.data(), above, na * 4) && (!nl || !memcmp(slot->in.data() + na, left, nl * 4))) {
             c->cache_hits++;

@@ -116,12 +116,20 @@ struct pnn_client {
     long hits = 0, misses = 0;
 };
 
-static uint64_t fnv1a64(const void* data, size_t bytes)
+// Hash of the input bytes for the prediction cache: 8 bytes per step (a byte-wise FNV-1a cost 1.3 us per 8x8 lookup and 80 us
+// per 64x64 one -- HM's RD search makes ~100 k lookups per picture); the entry is confirmed with memcmp, so only the spread matters.
+static uint64_t hash_bytes(const void* data, size_t bytes, uint64_t h = 0x9e3779b97f4a7c15ull)
 {
     const unsigned char* p = static_cast<const unsigned char*>(data);
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
-    return h;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    for (; i < bytes; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h ^ (h >> 29);
 }
 
 namespace {
@@ -507,7 +515,7 @@ static int client_call(pnn_client* c, int width, const float* above, const float
         const int wi = width == 4 ? 0 : width == 8 ? 1 : width == 16 ? 2 : width == 32 ? 3 : 4;
         auto& table = c->cache[wi][flags & 1u];
         if (table.empty()) table.resize(std::max<size_t>(16, c->cache_bytes / 10 / (in_bytes + (size_t)w2 * 4 + 64)));
-        hash = fnv1a64(in, in_bytes);
+        hash = hash_bytes(in, in_bytes);
         slot = &table[hash % table.size()];
         if (slot->valid && slot->hash == hash && slot->in.size() == in_bytes && !memcmp(slot->in.data(), in, in_bytes)) {
             memcpy(vals, slot->vals.data(), (size_t)w2 * 4);
