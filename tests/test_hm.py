@@ -316,3 +316,22 @@ def test_hm_concurrent_encodes_through_the_batching_service(hm_built, tmp_path):
     requests, calls, largest, clients = map(int, m.groups())
     assert clients == 20 and requests > 0                           # 4 encoders x 5 sessions
     assert calls < requests and largest >= 2                         # requests of concurrent encoders were coalesced
+
+
+@pytest.mark.gpu
+def test_hm_encodes_dealt_over_one_service_per_device(hm_built, tmp_path):
+    """The multi-GPU form of the HM path is replicas: one batching service per device, encoder j talks to service
+    j % n_devices, no exchange between devices.  One GPU here, so both services sit on device 0 -- what is checked is the
+    dealing: both services got clients, every picture decodes to the encoder's reconstruction."""
+    import json, re
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hm", "run_hm.py"), "--variant", "switch", "--width", "192",
+                          "--height", "128", "--jobs", "4", "--service", "--devices", "0,0", "--out", str(tmp_path / "run")],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    runs = [json.loads(l) for l in lines if l.startswith("{") and "decoder_equals_encoder" in l]
+    assert len(runs) == 4 and all(r["decoder_equals_encoder"] and not r["decoder_hash_error"] for r in runs), out.stdout
+    served = [int(m.group(1)) for m in re.finditer(r"(\d+) requests in \d+ batched calls \(largest batch \d+\), (\d+) clients", out.stdout)]
+    clients = [int(m.group(2)) for m in re.finditer(r"(\d+) requests in \d+ batched calls \(largest batch \d+\), (\d+) clients", out.stdout)]
+    assert len(served) == 2 and min(served) > 0, out.stdout
+    assert clients == [20, 20], clients                              # 2 encoders + 2 decoders per service, 5 sessions each

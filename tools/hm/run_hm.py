@@ -180,36 +180,46 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--jobs", type=int, default=1, help="concurrent encodes (different seeds)")
-    ap.add_argument("--service", action="store_true", help="serve all encodes from one batching service process")
+    ap.add_argument("--service", action="store_true", help="serve all encodes from batching service processes (one per entry of --devices)")
+    ap.add_argument("--devices", default="0", help="comma-separated HIP devices, one service each; encodes are dealt round-robin "
+                                                     "(the multi-GPU form of the HM path: replicas, no collective)")
     ap.add_argument("--trained-small", action="store_true", help="widths 4 / 8 use the trained conv checkpoints")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hm"))
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     table, mean_path = (None, None) if args.variant == "regular" else make_models(os.path.join(args.out, "models"), trained_small=args.trained_small)
-    env = {}
-    srv = None
+    devices = [int(d) for d in args.devices.split(",")]
+    servers, socks = [], []
     if args.service:
-        sock = os.path.join(args.out, "pnn.sock")
-        srv = subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
-                                "--table", table, "--max-batch", "64", "--window-us", "100"], cwd=ROOT, stdout=subprocess.PIPE, text=True)
-        line = srv.stdout.readline()
-        assert "listening" in line, line
-        env["PNN_SERVICE_SOCKET"] = sock
+        for k, dev in enumerate(devices):
+            sock = os.path.join(args.out, "pnn%d.sock" % k)
+            servers.append(subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
+                                             "--table", table, "--device", str(dev), "--max-batch", "64", "--window-us", "100"], cwd=ROOT,
+                                            stdout=subprocess.PIPE, text=True))
+            socks.append(sock)
+        for srv in servers:
+            line = srv.stdout.readline()
+            assert "listening" in line, line
+
+    def job_env(j):                                    # encode j -> service (or device) j % len(devices)
+        k = j % len(devices)
+        return {"PNN_SERVICE_SOCKET": socks[k]} if args.service else {"PNN_DEVICE": str(devices[k])}
     try:
         from concurrent.futures import ThreadPoolExecutor
         frames = [make_frame(args.height, args.width, args.seed + j) for j in range(args.jobs)]
         t0 = time.time()
         with ThreadPoolExecutor(args.jobs) as ex:
-            res = list(ex.map(lambda j: encode_decode(args.variant, frames[j], args.qp, table, mean_path, args.out, tag=str(j), env=env),
+            res = list(ex.map(lambda j: encode_decode(args.variant, frames[j], args.qp, table, mean_path, args.out, tag=str(j), env=job_env(j)),
                               range(args.jobs)))
         wall = time.time() - t0
         for r in res:
             print(json.dumps(r))
-        print(json.dumps({"jobs": args.jobs, "service": bool(args.service), "wall_s": round(wall, 2)}))
+        print(json.dumps({"jobs": args.jobs, "service": bool(args.service), "devices": devices, "wall_s": round(wall, 2)}))
     finally:
-        if srv:
+        for srv in servers:
             srv.terminate()
+        for srv in servers:
             print(srv.stdout.read().strip())
             srv.wait(10)
 
