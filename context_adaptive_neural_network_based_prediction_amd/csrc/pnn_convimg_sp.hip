@@ -87,10 +87,9 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 #pragma unroll
                     for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
                 acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                typedef f16x4 h4;
                 h4 hi, lo;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { hi[i] = (_Float16)acc[i]; lo[i] = (_Float16)(acc[i] - (float)hi[i]); }
+                split4(acc, hi, lo);
                 amax0 = amax4(amax0, acc);
                 _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (cg >> 2) * 32 + (cg & 3) * 4;
                 *reinterpret_cast<h4*>(dst) = hi;
@@ -309,9 +308,55 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                 }
         }
     };
+    // Split-only output (every layer but a net's last): through LDS, like the ring kernel.  A lane of the accumulator layout
+    // owns 8-byte fragments of 32 different output rows; stored from there a 48 KB tile took ~10k cycles.  The images are
+    // dead after the tap loop, so the tile is laid out in their place as [rows][BN/16 chunks][hi 16 | lo 16] (what a row
+    // segment looks like in memory) and leaves in 16-byte pieces, consecutive lanes = consecutive pieces of a pixel.
+    constexpr int BM = 32 * RT * WM, OPP = BN / 4 + 1;   // +1 piece of pitch: spreads the rows over the banks
+#ifdef PNN_CI_DIRECT_EPILOGUE   // A/B build: the stores from the accumulator layout
+    const bool tile_fits = false;
+#else
+    const bool tile_fits = (size_t)BM * OPP <= (size_t)2 * KC * E + ((size_t)G * NPIN + 1) * PITCH;
+#endif
+    if (p.Yhi && !p.Y && !p.Yi && tile_fits) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int lrow = wm * (32 * RT) + rt * 32 + l31;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int nl = wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+                    f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bvs[nt][g];
+                    if (act) {
+                        v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    }
+                    if (mv[rt] && n0 + nl < p.Cout) amax = amax4(amax, v);      // padding rows / columns hold no activation
+                    f16x4 hi, lo;
+                    split4(v, hi, lo);                 // same values and rounding as store_split4
+                    _Float16* dst = reinterpret_cast<_Float16*>(lds + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    *reinterpret_cast<f16x4*>(dst + 16) = lo;
+                }
+        }
+        __syncthreads();
+        f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Yhi);
+        const int cq = p.Cout >> 2;
+#pragma unroll 2
+        for (int i = tid; i < BM * (BN / 4); i += 256) {
+            const int row = i / (BN / 4), q = i - row * (BN / 4);
+            const int g = row / SP, nq = (n0 >> 2) + q;
+            if (g >= nimg || nq >= cq) continue;
+            const int r = row - g * SP;
+            const int ri = r / p.SW, rj = r - ri * p.SW;
+            const size_t opix = (((size_t)img0 + g) * p.OH + ri * p.os + py) * p.OW + rj * p.os + px;
+            store16_through(yo + (opix * cq + nq), lds[row * OPP + q]);
+        }
+    } else
     if (p.Yhi && !p.Y && !p.Yi) groups(std::integral_constant<int, 0>{});
     else if (p.Y && !p.Yhi && !p.Yi) groups(std::integral_constant<int, 1>{});
     else groups(std::integral_constant<int, 2>{});
+    report_range(p.range_flag, amax);
 #ifdef PNN_CI_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.Xlo && tid == 0) {

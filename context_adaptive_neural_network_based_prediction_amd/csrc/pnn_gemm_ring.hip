@@ -92,6 +92,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     constexpr int RPS = 16 / PPR > 0 ? 16 / PPR : 1;   // rows per swizzle step
     static_assert((KC * E) % 64 == 0 && (BM * PPR) % 256 == 0, "stage pieces must split into whole wave instructions");
     static_assert((D - 2) * NI <= 63, "vmcnt range");
+    constexpr bool kBiasLds = BN <= 256 && (size_t)(D * SS + 64) * 16 <= 160 * 1024;   // room for the bias tile (64 pieces) behind the ring
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D][A pieces | B pieces]
 
 #ifdef PNN_RING_DIAG2           // coarse stamps (tools/ring_prof.hip): entry / loop begin / loop end / exit of wave 0
@@ -147,7 +148,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 const int piq = rq / p.SW, pjq = rq - piq * p.SW;
                 opix = ((size_t)pbq * p.OH + piq * p.os + cpy) * p.OW + pjq * p.os + cpx;
             }
-            yo[opix * (p.Cout >> 2) + nq] = ring[row * OPP + q];
+            store16_through(yo + (opix * (p.Cout >> 2) + nq), ring[row * OPP + q]);
         }
     };
 
@@ -190,6 +191,13 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 aoff[r] = ok ? ((pix * (unsigned)p.Cin) << 2) + (unsigned)(lpiece[r] << 4) : 0x80000000u;
             }
         };
+        // this workgroup's BN bias values, behind the ring (one instruction of loader wave 0, the oldest of its queue: landed
+        // long before the epilogue; columns past Cout read as zeros).  Fetched by the MFMA waves at the end of the tap loop
+        // they were 20 global loads whose latency (~1k cycles) sat between the last MFMA and the first store.
+        if (kBiasLds && wave == 0) {
+            const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (unsigned)p.Cout * 4u, 0x00020000);
+            blds16(brsrc, (unsigned)(n0 + 4 * lane) << 2, ring + D * SS);
+        }
         unsigned boff[NLB];
 #pragma unroll
         for (int r = 0; r < NLB; r++) {
@@ -453,16 +461,19 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     // ---- epilogue, first half (MFMA waves): scale, bias, LeakyReLU; f32 / HM outputs straight from the accumulator layout,
     // the split-f16 output through LDS (copy_out above) ------------------------------------------------------------
     const int py = p.py[cls], px = p.px[cls];
-    // all bias values first: a load placed next to its use cannot be hoisted over the stores in between (the compiler
-    // must assume they alias), and the groups below then pay one L2 round trip EACH (measured: 600 cycles per group)
+    // all bias values first (a load placed next to its use cannot be hoisted over the stores in between: the compiler must
+    // assume they alias) -- from the tile the loader side left in LDS, or, where the ring fills the LDS, from memory (one L2
+    // round trip, ~1k cycles between the last MFMA and the first store)
     f32x4 bvs[NT][4];
+    if (!kBiasLds) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
-            bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));   // columns past Cout: any valid address, never stored
-        }
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + wn * (32 * NT) + nt * 32 + 8 * g + 4 * h;
+                bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));   // columns past Cout: any valid address, never stored
+            }
+    }
     __builtin_amdgcn_s_barrier();                    // barrier A: every wave is done with the ring
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
@@ -474,6 +485,12 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     // footprint: with all three output kinds behind per-group branches it was ~20 KB and 7.9k cycles for 20 groups.
     const bool act = p.act != 0;
     float amax = 0.f;                                // range guard of the split outputs (pnn_device_common.h)
+    if (kBiasLds) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) bvs[nt][g] = ring[D * SS + ((wn * (32 * NT) + nt * 32 + 8 * g + 4 * h) >> 2)];
+    }
     auto groups = [&](auto direct_tag) {
         constexpr bool kDirect = decltype(direct_tag)::value;        // f32 / HM outputs straight from the accumulator layout
 #pragma unroll
@@ -506,11 +523,10 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                     continue;
 #endif
                     if (!kDirect || p.Yhi || fuse) {  // same values and rounding as store_split4
-                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        typedef f16x4 h4;
                         h4 hi, lo;
                         amax = amax4(amax, v);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+                        split4(v, hi, lo);
                         _Float16* dst = reinterpret_cast<_Float16*>(ring + lrow * OPP) + (nl >> 4) * 32 + (nl & 15);
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + 16) = lo;
@@ -526,7 +542,26 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 }
         }
     };
+#ifdef PNN_RING_DIAG4           // experiment: the group loop a second time, from a warm instruction cache (tools/ring_prof.hip)
+    unsigned long long dg4[2] = {0, 0};
+#pragma nounroll
+    for (int rep = 0; rep < 2; rep++) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        groups(std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dg4[rep] = __builtin_amdgcn_s_memtime() - t4;
+        asm volatile("" : "+s"(rep));
+    }
+    if (p.Xlo && tid == 0) {
+        unsigned long long* e4 = (unsigned long long*)p.Xlo + (1 << 20) + 2 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        e4[0] = dg4[0]; e4[1] = dg4[1];
+    }
+#else
     if (p.Y || p.Yi) groups(std::true_type{}); else groups(std::false_type{});
+#endif
     report_range(p.range_flag, amax);
 #ifdef PNN_RING_DIAG2
     __builtin_amdgcn_sched_barrier(0);
@@ -643,7 +678,8 @@ TileCfg tapgemm_ring_cfg(int idx) { return kCfgsRing[idx]; }
 size_t tapgemm_ring_lds_bytes(const TileCfg& t)
 {
     const size_t bm = 32 * (size_t)t.rt * t.wm, bn = 32 * (size_t)t.nt * (4 / t.wm);
-    return (size_t)t.d * (bm * 4 * t.kc + (size_t)t.kc * 4 * bn) * 16;
+    const size_t ring = (size_t)t.d * (bm * 4 * t.kc + (size_t)t.kc * 4 * bn) * 16;
+    return ring + 1024 <= 160 * 1024 ? ring + 1024 : ring;                        // + the bias tile (64 pieces) where it fits
 }
 
 // Sums the column tiles' partial products of a fused layer in tile order, undoes the weight scale, adds the bias and

@@ -445,8 +445,8 @@ def test_trained_checkpoints_through_the_split_kernels(pnn, oracle, precision, w
         net2.close()
 
 
-@pytest.mark.parametrize("w,is_fc,n", [(8, True, 600), (8, True, 1), (16, False, 90)])
-def test_f16_range_guard(pnn, oracle, precision, w, is_fc, n):
+@pytest.mark.parametrize("w,is_fc,n,layer", [(8, True, 600, 0), (8, True, 1, 0), (16, False, 90, 0), (16, False, 90, 1), (16, False, 1, 1)])
+def test_f16_range_guard(pnn, oracle, precision, w, is_fc, n, layer):
     """Split precision carries activations as f16 pairs: |v| >= 65504 must never turn into a silent NaN -> 255.  First-layer
     weights are scaled until hidden activations pass 1e5 (the last layer is scaled back, so the prediction stays in range):
     host calls must still match the oracle (they repeat the pass on the exact-f32 kernels and count it), device calls
@@ -459,7 +459,9 @@ def test_f16_range_guard(pnn, oracle, precision, w, is_fc, n):
     sizes = [int(np.prod(sh)) for _, sh, _ in specs]
     offs = np.concatenate([[0], np.cumsum(sizes)])
     gain = 3000.0 if is_fc else 30000.0
-    params[offs[0]:offs[2]] *= gain                                  # first layer: weights and biases (LeakyReLU is positively homogeneous)
+    # first layer (or, layer = 1, the second: its outputs leave through the GEMM kernels' own epilogues): weights and biases
+    # (LeakyReLU is positively homogeneous)
+    params[offs[2 * layer]:offs[2 * layer + 2]] *= gain
     params[offs[-3]:offs[-2]] /= gain                                # last layer's weights undo it
     above, left = util.make_contexts(w, n, 82)
     net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)

@@ -73,6 +73,15 @@ int main(int argc, char** argv)
             }
             printf("      stage barrier wait (MFMA wave 0): %5.0f cycles per stage\n", e[5] / nwg / nst);
 #endif
+#ifdef PNN_RING_DIAG4
+            {
+                std::vector<unsigned long long> h4(2 * (size_t)nwg);
+                hipMemcpy(h4.data(), (char*)dd + 8 * (1 << 20), h4.size() * 8, hipMemcpyDeviceToHost);
+                double a = 0, b = 0;
+                for (int w = 0; w < nwg; w++) { a += (double)h4[2 * w]; b += (double)h4[2 * w + 1]; }
+                printf("      group loop: first pass %5.0f cycles, second pass (warm instruction cache) %5.0f\n", a / nwg, b / nwg);
+            }
+#endif
             printf("      epilogue: barrier A %5.0f | scale/bias/split -> LDS %5.0f | barrier B %5.0f | copy-out issue %5.0f | store drain %5.0f\n", e[0] / nwg, e[1] / nwg,
                    e[2] / nwg, e[3] / nwg, e[4] / nwg);
         }
