@@ -80,6 +80,9 @@ __device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo)
 // layer at batch 4096 are ~3 us at the rate the write-back runs.  Written through, the early workgroups' tiles drain
 // while the late ones still compute (measured, same box, plain -> through: FC-8 pass 103.8 -> 102.1 us, conv-16 pass
 // 400.8 -> 397.4 us; `nt` alone changes nothing: it is a cache hint, not write-through).  -DPNN_PLAIN_STORES: the A/B build.
+// NOT for values that come straight out of an MFMA: the compiler pads the MFMA -> vector-memory read hazard only for its
+// own instructions, an asm operand gets no wait states (tried on the fused layer's partial sums: garbage).  The same holds
+// for split4 / leaky above -- every caller has a compiler-generated v_fma (scale, bias) between the matrix result and them.
 __device__ __forceinline__ void store16_through(f32x4* dst, f32x4 v)
 {
 #ifdef PNN_PLAIN_STORES
