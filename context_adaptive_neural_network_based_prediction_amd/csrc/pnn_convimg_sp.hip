@@ -342,15 +342,24 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         __syncthreads();
         f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Yhi);
         const int cq = p.Cout >> 2;
-#pragma unroll 2
-        for (int i = tid; i < BM * (BN / 4); i += 256) {
-            const int row = i / (BN / 4), q = i - row * (BN / 4);
-            const int g = row / SP, nq = (n0 >> 2) + q;
-            if (g >= nimg || nq >= cq) continue;
-            const int r = row - g * SP;
-            const int ri = r / p.SW, rj = r - ri * p.SW;
-            const size_t opix = (((size_t)img0 + g) * p.OH + ri * p.os + py) * p.OW + rj * p.os + px;
-            store16_through(yo + (opix * cq + nq), lds[row * OPP + q]);
+        for (int i0 = tid; i0 < BM * (BN / 4); i0 += 2 * 256) {   // two pieces per thread in flight (the store is an asm statement)
+            f32x4 v[2];
+            f32x4* dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + u * 256;
+                const int ic = i < BM * (BN / 4) ? i : tid;
+                const int row = ic / (BN / 4), q = ic - row * (BN / 4);
+                const int g = row / SP, nq = (n0 >> 2) + q;
+                const int r = row - g * SP;
+                const int ri = r / p.SW, rj = r - ri * p.SW;
+                const size_t opix = (((size_t)img0 + g) * p.OH + ri * p.os + py) * p.OW + rj * p.os + px;
+                v[u] = lds[row * OPP + q];
+                dst[u] = (i < BM * (BN / 4) && g < nimg && nq < cq) ? yo + (opix * cq + nq) : nullptr;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (dst[u]) store16_through(dst[u], v[u]);
         }
     } else
     if (p.Yhi && !p.Y && !p.Yi) groups(std::integral_constant<int, 0>{});

@@ -135,20 +135,31 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
         if (!p.Yhi) return;
         const int cpy = p.py[cls], cpx = p.px[cls];
         f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Yhi);
-#pragma unroll 2
-        for (int i = tid; i < BM * (BN / 4); i += 512) {
-            const int row = i / (BN / 4), q = i - row * (BN / 4);
-            const int mg = mblk + row;
-            const int nq = (n0 >> 2) + q;             // piece index within the output pixel's [Cout/4] pieces
-            if (mg >= p.M || nq >= (p.Cout >> 2)) continue;
-            size_t opix = mg;
-            if (SP != 1 || p.os != 1) {
-                const int pbq = mg / SP;
-                const int rq = mg - pbq * SP;
-                const int piq = rq / p.SW, pjq = rq - piq * p.SW;
-                opix = ((size_t)pbq * p.OH + piq * p.os + cpy) * p.OW + pjq * p.os + cpx;
+        // two pieces per thread in flight (the store is an asm statement: the compiler neither unrolls across it nor moves the
+        // LDS reads over it)
+        for (int i0 = tid; i0 < BM * (BN / 4); i0 += 2 * 512) {
+            f32x4 v[2];
+            f32x4* dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + u * 512;
+                const int ic = i < BM * (BN / 4) ? i : tid;
+                const int row = ic / (BN / 4), q = ic - row * (BN / 4);
+                const int mg = mblk + row;
+                const int nq = (n0 >> 2) + q;         // piece index within the output pixel's [Cout/4] pieces
+                size_t opix = mg;
+                if (SP != 1 || p.os != 1) {
+                    const int pbq = mg / SP;
+                    const int rq = mg - pbq * SP;
+                    const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+                    opix = ((size_t)pbq * p.OH + piq * p.os + cpy) * p.OW + pjq * p.os + cpx;
+                }
+                v[u] = ring[row * OPP + q];
+                dst[u] = (i < BM * (BN / 4) && mg < p.M && nq < (p.Cout >> 2)) ? yo + (opix * (p.Cout >> 2) + nq) : nullptr;
             }
-            store16_through(yo + (opix * (p.Cout >> 2) + nq), ring[row * OPP + q]);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (dst[u]) store16_through(dst[u], v[u]);
         }
     };
 

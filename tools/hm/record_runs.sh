@@ -1,0 +1,31 @@
+#!/bin/bash
+# Records the HM runs quoted in DESIGN.md section 5b into one text file (default profiles/r02_hm_runs.txt).  GPU box.
+#   tools/hm/record_runs.sh [out-file]
+out=${1:-profiles/r02_hm_runs.txt}
+work=${TMPDIR:-/tmp}/hm_runs.$$
+mkdir -p "$work"
+run() {   # title, then run_hm.py arguments; result lines cut after the first fields
+    echo "== $1" >> "$out"; shift
+    python3 tools/hm/run_hm.py --out "$work/r" "$@" 2>&1 | grep -v amdgpu.ids | grep -v '^$' | cut -c1-900 >> "$out"
+    rm -rf "$work/r"
+}
+cat > "$out" <<HDR
+# HM-16.15 (reference sources, unchanged) on libpnn_hip.so: tools/hm/record_runs.sh on one MI355X box ($(nproc) host cores).
+# Synthetic 4:0:0 pictures (run_hm.make_frame), seeded random-init models in the reference's architectures, intra_main_rext settings, QP 32.
+# enc_total_time_s = HM's own 'Total Time' (clock(): CPU time of the encoder process -- time blocked on the service socket is not in it);
+# enc_wall_s = wall clock of the encoder process; decoder_equals_encoder = decoded picture == encoder reconstruction, byte for byte;
+# enc_pnn / dec_pnn = Session::Run calls per width and how many were answered from the prediction cache.
+# Lines are cut after the first fields; "jobs ... wall_s" = all encodes + decodes of the run, "pnn service" = the server's own count.
+
+HDR
+run "yardstick: hm_16_15_regular (the reference's stock HM-16.15, no PNN, CPU only), ONE synthetic 768x512 4:0:0 picture, QP 32" --variant regular --width 768 --height 512 --jobs 1
+run "configs[3]-like: hm_16_15_substitution, ONE synthetic 768x512 4:0:0 picture, QP 32, in-process contexts" --variant substitution --width 768 --height 512 --jobs 1
+run "the same through hm_16_15_switch" --variant switch --width 768 --height 512 --jobs 1
+run "configs[3]-like: hm_16_15_substitution, 4 synthetic 768x512 pictures at a time, in-process contexts (4 x 5 on one GPU)" --variant substitution --width 768 --height 512 --jobs 4
+run "the same 4 through ONE batching service process (encoders and decoders)" --variant substitution --width 768 --height 512 --jobs 4 --service
+for j in 1 4 16 32; do
+    run "configs[4]-like: hm_16_15_switch, $j x 480x320 at a time, ONE batching service" --variant switch --width 480 --height 320 --jobs $j --service
+done
+run "configs[4]-like, the multi-GPU form (replicas): 16 x 480x320, TWO batching services (here both on device 0), encodes dealt round-robin" --variant switch --width 480 --height 320 --jobs 16 --service --devices 0,0
+rm -rf "$work"
+grep -c decoder_equals_encoder "$out"; grep -c '"decoder_equals_encoder": true' "$out"
