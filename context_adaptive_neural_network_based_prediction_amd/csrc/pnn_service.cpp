@@ -244,26 +244,36 @@ struct Server {
         std::vector<std::thread> threads;
         for (int k = 0; k < nworkers; k++) threads.emplace_back([this, k] { worker(k); });
 
-        auto recount_peers = [&]() {                 // under the lock: distinct peer processes, and those with a request in flight
-            std::vector<int> pids, waiting;
-            for (const auto& kv : clients) {
-                pids.push_back(kv.second.pid);
-                if (kv.second.in_flight) waiting.push_back(kv.second.pid);
-            }
-            std::sort(pids.begin(), pids.end());
-            pids.erase(std::unique(pids.begin(), pids.end()), pids.end());
-            std::sort(waiting.begin(), waiting.end());
-            waiting.erase(std::unique(waiting.begin(), waiting.end()), waiting.end());
-            n_peers = (int)pids.size(); n_waiting_peers = (int)waiting.size();
+        // distinct peer processes and those with a request in flight, kept incrementally (under the lock).  This used to be a
+        // recount over all connections per message: with 160 connections that sort was most of what the I/O thread did
+        // (16 encoders on one server were slower than 8 + 8 on two).
+        struct Peer { int conns = 0, in_flight = 0; };
+        std::map<int, Peer> peers;
+        auto peer_conn = [&](int pid, int d) {       // a connection of `pid` opened (+1) / closed (-1)
+            Peer& pr = peers[pid];
+            pr.conns += d;
+            if (pr.conns <= 0) { if (pr.in_flight > 0) --n_waiting_peers; peers.erase(pid); }
+            n_peers = (int)peers.size();
+        };
+        auto peer_flight = [&](int pid, int d) {     // a request of `pid` queued (+1) / answered or dropped (-1)
+            auto it = peers.find(pid);
+            if (it == peers.end()) return;
+            const bool was = it->second.in_flight > 0;
+            it->second.in_flight += d;
+            const bool is = it->second.in_flight > 0;
+            if (is != was) n_waiting_peers += is ? 1 : -1;
         };
         auto drop = [&](uint64_t id) {
             auto it = clients.find(id);
             if (it == clients.end()) return;
             close(it->second.fd);
+            const int pid = it->second.pid;
+            const bool was_in_flight = it->second.in_flight;
             clients.erase(it);
             std::lock_guard<std::mutex> lk(mu);
             for (auto& q : queue) q.erase(std::remove_if(q.begin(), q.end(), [id](const Req& r) { return r.id == id; }), q.end());
-            recount_peers();
+            if (was_in_flight) peer_flight(pid, -1);
+            peer_conn(pid, -1);
         };
         // Moves whatever the socket holds into the client's buffer; queues the request when it is complete.
         // false = client gone or protocol violation.
@@ -289,7 +299,7 @@ struct Server {
                         {
                             std::lock_guard<std::mutex> lk(mu);
                             queue[k].push_back(std::move(r));
-                            recount_peers();
+                            peer_flight(c.pid, +1);
                             all_wait = n_waiting_peers >= n_peers;
                         }
                         cv[k].notify_one();
@@ -355,12 +365,13 @@ struct Server {
                         socklen_t len = sizeof cred;
                         if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
                         const uint64_t nid = next_id++;
+                        const int pid = c.pid;
                         clients.emplace(nid, std::move(c));
                         ep_ctl(EPOLL_CTL_ADD, cfd, EPOLLIN, nid);
                         ++accepted;
+                        std::lock_guard<std::mutex> lk(mu);
+                        peer_conn(pid, +1);
                     }
-                    std::lock_guard<std::mutex> lk(mu);
-                    recount_peers();
                 } else if (id == 1) {                         // replies from the workers
                     char buf[256];
                     while (read(wake_fd[0], buf, sizeof buf) > 0) {}
@@ -375,12 +386,14 @@ struct Server {
                         Client& c = it->second;
                         if (c.tx.empty()) c.tx_since = Clock::now();
                         c.tx.insert(c.tx.end(), rp.bytes.begin(), rp.bytes.end());
-                        c.in_flight = false;
+                        if (c.in_flight) {
+                            c.in_flight = false;
+                            std::lock_guard<std::mutex> lk(mu);
+                            peer_flight(c.pid, -1);
+                        }
                         if (!flush(c)) gone.push_back(rp.id);
                         else if (!c.tx.empty()) arm(rp.id, c);   // the socket took only part of it: wait for EPOLLOUT
                     }
-                    std::lock_guard<std::mutex> lk(mu);
-                    recount_peers();
                 } else {
                     auto it = clients.find(id);
                     if (it == clients.end()) continue;

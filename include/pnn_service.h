@@ -25,7 +25,8 @@ typedef int (*pnn_service_backend)(void* user, int width, const float* above, co
 
 /* Serves `socket_path` until *stop becomes non-zero (checked at least every 50 ms).  max_batch: largest batch handed to
  * the backend; window_us: after the first pending request the server waits up to this long for more before it
- * dispatches (0 = dispatch whatever is pending right now).  stats (optional, 4 longs): requests served, backend
+ * dispatches (0 = dispatch whatever is pending right now -- the recommended setting: while a batch is on the GPU the next
+ * one forms by itself, and with 4 / 16 HM encoders on one server a 100 us window cost 27 / 33 % of the wall time).  stats (optional, 4 longs): requests served, backend
  * calls, largest batch, clients accepted. */
 int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend, void* user, int max_batch, int window_us,
                             volatile int* stop, long* stats);

@@ -290,7 +290,7 @@ def test_hm_concurrent_encodes_through_the_batching_service(hm_built, tmp_path):
     table, mean_path = run_hm.make_models(str(tmp_path / "models"))
     sock = str(tmp_path / "pnn.sock")
     srv = subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
-                            "--table", table, "--max-batch", "64", "--window-us", "100"], cwd=ROOT, stdout=subprocess.PIPE, text=True)
+                            "--table", table, "--max-batch", "64"], cwd=ROOT, stdout=subprocess.PIPE, text=True)
     try:
         assert "listening" in srv.stdout.readline()
         frames = [run_hm.make_frame(128, 192, 20 + j) for j in range(4)]

@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--jobs", type=int, default=1, help="concurrent encodes (different seeds)")
     ap.add_argument("--service", action="store_true", help="serve all encodes from batching service processes (one per entry of --devices)")
+    ap.add_argument("--window-us", type=int, default=0, help="batching window of the service(s); 0 measured fastest (DESIGN.md 5b)")
     ap.add_argument("--devices", default="0", help="comma-separated HIP devices, one service each; encodes are dealt round-robin "
                                                      "(the multi-GPU form of the HM path: replicas, no collective)")
     ap.add_argument("--trained-small", action="store_true", help="widths 4 / 8 use the trained conv checkpoints")
@@ -195,7 +196,7 @@ def main():
         for k, dev in enumerate(devices):
             sock = os.path.join(args.out, "pnn%d.sock" % k)
             servers.append(subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
-                                             "--table", table, "--device", str(dev), "--max-batch", "64", "--window-us", "100"], cwd=ROOT,
+                                             "--table", table, "--device", str(dev), "--max-batch", "64", "--window-us", str(args.window_us)], cwd=ROOT,
                                             stdout=subprocess.PIPE, text=True))
             socks.append(sock)
         for srv in servers:
