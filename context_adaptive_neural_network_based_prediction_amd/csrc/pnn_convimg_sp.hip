@@ -77,9 +77,11 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             f32x4 w[K * K];
 #pragma unroll
             for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W0 + (size_t)t * p.Cin + 4 * cg);
+            // (image, row, column) of this thread's pixel, advanced by ppi pixels per iteration without divisions: the index
+            // arithmetic was more than half of the ~250 instructions per pixel
+            int li = (tid / CG) / NPIN, oy, ox;
+            { const int q = tid / CG - li * NPIN; oy = q / p.IW; ox = q - oy * p.IW; }
             for (int pix = tid / CG; pix < nimg * NPIN; pix += ppi) {
-                const int li = pix / NPIN, q = pix - li * NPIN;
-                const int oy = q / p.IW, ox = q - oy * p.IW;
                 const float* xr = raw + li * PH * PW + (oy * S0) * PW + ox * S0;
                 f32x4 acc = bv;
 #pragma unroll
@@ -94,6 +96,9 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                 _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (cg >> 2) * 32 + (cg & 3) * 4;
                 *reinterpret_cast<h4*>(dst) = hi;
                 *reinterpret_cast<h4*>(dst + 16) = lo;
+                ox += ppi;
+                while (ox >= p.IW) { ox -= p.IW; ++oy; }
+                while (oy >= p.IH) { oy -= p.IH; ++li; }
             }
         };
         if (K0 == 5) conv0(std::integral_constant<int, 5>{}); else conv0(std::integral_constant<int, 3>{});
