@@ -68,6 +68,17 @@ int main(int argc, char** argv)
                     s0 = st < s0 ? st : s0; s1 = st > s1 ? st : s1; e0 = en < e0 ? en : e0; e1 = en > e1 ? en : e1;
                     lmin = life < lmin ? life : lmin; lmax = life > lmax ? life : lmax;
                 }
+                {   // where the slow workgroups are: mean lifetime by XCD (linear workgroup id % 8) and by column tile
+                    double bx[8] = {0}, nx[8] = {0};
+                    const int gx = (M + bm - 1) / bm, gy = (N + bn - 1) / bn;
+                    std::vector<double> by(gy, 0.0);
+                    for (int w = 0; w < nwg; w++) { bx[w % 8] += h[4 * w + 3] / 100.0; nx[w % 8] += 1; by[(w / gx) % gy] += h[4 * w + 3] / 100.0 / gx; }
+                    printf("      mean lifetime by XCD:");
+                    for (int x = 0; x < 8; x++) printf(" %.1f", bx[x] / (nx[x] > 0 ? nx[x] : 1));
+                    printf(" us; by column tile:");
+                    for (int y = 0; y < gy; y++) printf(" %.1f", by[y]);
+                    printf(" us\n");
+                }
                 printf("      workgroup starts spread over %.1f us, ends over %.1f us, first start -> last end %.1f us, lifetime min %.1f / max %.1f us\n",
                        (s1 - s0) / 100.0, (e1 - e0) / 100.0, (e1 - s0) / 100.0, lmin / 100.0, lmax / 100.0);
             }
