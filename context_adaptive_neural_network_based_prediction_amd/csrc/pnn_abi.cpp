@@ -800,7 +800,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
             hipEvent_t e0, e1;
             HIPCHK(c, hipEventCreate(&e0));
             HIPCHK(c, hipEventCreate(&e1));
-            float best_ms = 1e30f;
+            float best_ms = 1e30f, rule_ms = 1e30f;
             int best = cfg;
             for (int i = 0; i < nsp + nci + nrg; i++) {
                 if (!legal(i)) continue;
@@ -812,8 +812,14 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
                 if (getenv("PNN_DEBUG_TUNE")) fprintf(stderr, "[pnn]   code %d: %.1f us\n", i, ms * 1e3 / 3);
+                if (i == cfg) rule_ms = ms;
                 if (ms < best_ms) { best_ms = ms; best = i; }
             }
+            // Three back-to-back launches of one configuration are a noisy yardstick (no producer in front, caches warm from
+            // the same launch): a configuration has to beat the rule-based choice by more than 3 % to replace it.  (Seen on the
+            // K = 320 layer of the 8x8 FC net: the tuner took the 3-deep ring for "14.6 vs 14.7 us" where the 4-deep ring of
+            // the rule runs the layer in 13.4 us inside the real pass.)
+            if (best != cfg && rule_ms < 1e29f && rule_ms <= best_ms * 1.03f) { best = cfg; best_ms = rule_ms; }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             it = c->tuned.emplace(key, best).first;
