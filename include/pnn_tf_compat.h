@@ -20,6 +20,7 @@
 //                             (include/pnn_service.h) -- many encoder processes then share one GPU in batched launches
 //   PNN_CACHE_MB=<n>          per-session prediction cache (repeated identical Runs of HM's RD search), default 64
 //   PNN_STATS=1               print Run / cache-hit counts per session on stderr when the session is destroyed
+//   PNN_ASYNC_LOAD=0          read / pack / upload the weights inside Session::Create (default: in a thread that the first Run joins)
 // Sessions always run with canonical_order = 1: a block's prediction does not depend on the batch it travels in, so an
 // encoder behind the batching service and a stand-alone decoder reconstruct the same picture.
 #ifndef PNN_TF_COMPAT_H
@@ -39,6 +40,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <thread>
 
 namespace tensorflow {
 
@@ -146,9 +148,10 @@ public:
 
 class PnnSession : public Session {
 public:
-    explicit PnnSession(const SessionOptions& o) : opts_(o), ctx_(nullptr), client_(nullptr), width_(0), is_fc_(0), runs_(0) {}
+    explicit PnnSession(const SessionOptions& o) : opts_(o), ctx_(nullptr), client_(nullptr), width_(0), is_fc_(0), runs_(0), load_rc_(PNN_OK) {}
     ~PnnSession() override
     {
+        finish_load();
         if (std::getenv("PNN_STATS") && width_) {
             long hits = 0, misses = 0;
             if (ctx_) pnn_cache_stats(ctx_, &hits, &misses);
@@ -159,46 +162,65 @@ public:
         if (ctx_) pnn_destroy(ctx_);
         if (client_) pnn_client_close(client_);
     }
-    pnn_ctx* pnn_context() const { return ctx_; }
+    pnn_ctx* pnn_context() { finish_load(); return ctx_; }
 
     Status Create(const GraphDef& graph) override
     {
+        finish_load();
         if (ctx_) { pnn_destroy(ctx_); ctx_ = nullptr; }
         if (client_) { pnn_client_close(client_); client_ = nullptr; }
         width_ = 0;
-        if (const char* sock = std::getenv("PNN_SERVICE_SOCKET")) {
-            // served remotely: only the model's header is needed here (width, kind)
-            struct { char magic[4]; uint32_t version, width, is_fc; } h;
-            FILE* f = std::fopen(graph.pnn_model_path.c_str(), "rb");
-            if (!f) return errors::NotFound(graph.pnn_model_path, "; No such file or directory");
-            const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "PNNW", 4);
-            std::fclose(f);
-            if (!ok) return errors::InvalidArgument(graph.pnn_model_path, " is not a PNNW file");
+        // the model's header (width, kind): what a missing or foreign file costs is paid here, like a frozen graph that does not parse
+        struct { char magic[4]; uint32_t version, width, is_fc; } h;
+        FILE* f = std::fopen(graph.pnn_model_path.c_str(), "rb");
+        if (!f) return errors::NotFound(graph.pnn_model_path, "; No such file or directory");
+        const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "PNNW", 4);
+        std::fclose(f);
+        if (!ok) return errors::InvalidArgument(graph.pnn_model_path, " is not a PNNW file");
+        if (const char* sock = std::getenv("PNN_SERVICE_SOCKET")) {   // served remotely: nothing else is needed here
             if (pnn_client_connect(&client_, sock) != PNN_OK) return errors::Internal("no PNN batching service at ", sock);
             width_ = (int)h.width; is_fc_ = (int)h.is_fc;
             return Status::OK();
         }
         int dev = opts_.pnn_device;
         if (dev < 0) { const char* e = std::getenv("PNN_DEVICE"); dev = e ? std::atoi(e) : 0; }
-        int rc = pnn_create_empty(&ctx_, opts_.pnn_mean, dev);
+        int rc = pnn_create_empty(&ctx_, opts_.pnn_mean, dev);       // no HIP device: fails HERE, loudly
         if (rc != PNN_OK) return errors::Internal(pnn_last_error(nullptr));
-        rc = pnn_load_model_file(ctx_, graph.pnn_model_path.c_str());
-        if (rc != PNN_OK) return errors::InvalidArgument(pnn_last_error(ctx_));
         long cache_mb = opts_.pnn_cache_mb;
         if (cache_mb < 0) { const char* e = std::getenv("PNN_CACHE_MB"); cache_mb = e ? std::atol(e) : 64; }
-        pnn_set_option(ctx_, "canonical_order", 1);
-        pnn_set_option(ctx_, "cache_mb", cache_mb);
-        for (int w = 4; w <= 64; w *= 2) {
+        width_ = (int)h.width; is_fc_ = (int)h.is_fc;
+        // Reading, packing and uploading the weights (0.02 ... 0.2 s per model, 0.5 s for HM's five) runs in a thread of its own:
+        // HM creates its five sessions one after the other and needs none of them before the first intra block, so the five
+        // loads overlap each other and the rest of the codec's start-up.  The first Run() (or the destructor) joins.
+        // PNN_ASYNC_LOAD=0: load here, synchronously.
+        const std::string path = graph.pnn_model_path;
+        load_rc_ = PNN_OK;
+        auto load = [this, path, cache_mb]() {
+            load_rc_ = pnn_load_model_file(ctx_, path.c_str());
+            if (load_rc_ != PNN_OK) { load_err_ = pnn_last_error(ctx_); return; }
+            pnn_set_option(ctx_, "canonical_order", 1);
+            pnn_set_option(ctx_, "cache_mb", cache_mb);
             int fc = 0;
-            if (pnn_model_info(ctx_, w, &fc, nullptr, nullptr) == PNN_OK) { width_ = w; is_fc_ = fc; }
+            if (pnn_model_info(ctx_, width_, &fc, nullptr, nullptr) != PNN_OK || fc != is_fc_) {
+                load_rc_ = PNN_E_MODEL; load_err_ = "model header and contents disagree in " + path;
+            }
+        };
+        const char* as = std::getenv("PNN_ASYNC_LOAD");
+        if (as && std::atoi(as) == 0) {
+            load();
+            if (load_rc_ != PNN_OK) return errors::InvalidArgument(load_err_);
+        } else {
+            loader_ = std::thread(load);
         }
-        return width_ ? Status::OK() : errors::Internal("no model in ", graph.pnn_model_path);
+        return Status::OK();
     }
 
     Status Run(const std::vector<std::pair<string, Tensor> >& inputs, const std::vector<string>& output_tensor_names,
                const std::vector<string>&, std::vector<Tensor>* outputs) override
     {
         if (!ctx_ && !client_) return errors::Internal("Session::Run before Session::Create");
+        finish_load();
+        if (load_rc_ != PNN_OK) return errors::InvalidArgument(load_err_);
         if (!outputs || output_tensor_names.size() != 1) return errors::InvalidArgument("exactly one fetch is supported");
         const Tensor* ctx = nullptr; const Tensor* above = nullptr; const Tensor* left = nullptr;
         for (const auto& kv : inputs) {
@@ -257,11 +279,15 @@ public:
     }
 
 private:
+    void finish_load() { if (loader_.joinable()) loader_.join(); }
     SessionOptions opts_;
     pnn_ctx* ctx_;
     pnn_client* client_;
     int width_, is_fc_;
     long runs_;
+    std::thread loader_;           // the model load started by Create()
+    int load_rc_;
+    std::string load_err_;
 };
 
 inline Session* NewSession(const SessionOptions& options) { return new PnnSession(options); }

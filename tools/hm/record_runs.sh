@@ -18,6 +18,8 @@ cat > "$out" <<HDR
 # Lines are cut after the first fields; "jobs ... wall_s" = all encodes + decodes of the run, "pnn service" = the server's own count.
 
 HDR
+# one throw-away encode first: the very first HIP process on a fresh box pays for the driver's own warm-up (~0.5 s)
+python3 tools/hm/run_hm.py --out "$work/warm" --variant switch --width 192 --height 128 --jobs 1 > /dev/null 2>&1; rm -rf "$work/warm"
 run "yardstick: hm_16_15_regular (the reference's stock HM-16.15, no PNN, CPU only), ONE synthetic 768x512 4:0:0 picture, QP 32" --variant regular --width 768 --height 512 --jobs 1
 run "configs[3]-like: hm_16_15_substitution, ONE synthetic 768x512 4:0:0 picture, QP 32, in-process contexts" --variant substitution --width 768 --height 512 --jobs 1
 run "the same through hm_16_15_switch" --variant switch --width 768 --height 512 --jobs 1
