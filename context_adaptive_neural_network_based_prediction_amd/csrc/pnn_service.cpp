@@ -157,6 +157,7 @@ struct Server {
     int wake_fd[2] = {-1, -1};       // workers -> I/O thread
     long served = 0, calls = 0, largest = 0;
     double busy_s[5] = {0, 0, 0, 0, 0};   // time inside the backend, per worker (PNN_SERVICE_DEBUG)
+    long calls_w[5] = {0, 0, 0, 0, 0}, served_w[5] = {0, 0, 0, 0, 0};   // backend calls / requests per worker
 
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
     int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
@@ -221,6 +222,7 @@ struct Server {
                 std::lock_guard<std::mutex> lk(mu);
                 for (auto& r : replies) done.push_back(std::move(r));
                 served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
+                ++calls_w[k]; served_w[k] += (long)n;
             }
             const char one = 1;
             (void)!write(wake_fd[1], &one, 1);
@@ -429,7 +431,9 @@ struct Server {
         unlink(socket_path);
         if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted; }
         if (getenv("PNN_SERVICE_DEBUG"))
-            fprintf(stderr, "[pnn-service] seconds inside the backend per worker: %.2f %.2f %.2f %.2f %.2f\n", busy_s[0], busy_s[1], busy_s[2], busy_s[3], busy_s[4]);
+            for (int k = 0; k < nworkers; k++)
+                fprintf(stderr, "[pnn-service] worker %d: %.2f s inside the backend, %ld calls (%.1f us each), %ld requests (%.2f per call)\n", k, busy_s[k],
+                        calls_w[k], calls_w[k] ? busy_s[k] * 1e6 / calls_w[k] : 0.0, served_w[k], calls_w[k] ? (double)served_w[k] / calls_w[k] : 0.0);
         return PNN_OK;
     }
 };
