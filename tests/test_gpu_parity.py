@@ -785,6 +785,17 @@ def test_tf_compat_session_run(pnn, oracle, tmp_path):
     ab = ((np.arange(768) * 37 % 256).astype(np.float32) - mean).reshape(1, 16, 48)
     lf = (((np.arange(512) * 53 + 11) % 256).astype(np.float32) - mean).reshape(1, 32, 16)
     np.testing.assert_allclose(got_cv, oracle.conv_forward(pc, 16, ab, lf)[0], rtol=0, atol=FLOAT_ATOL)
+    # Session::Create loads the weights in a background thread (PNN_ASYNC_LOAD, default) that the first Run joins: the same
+    # output with the load inside Create, and a model file that is cut off behind its header passes Create (the header is
+    # read there) but fails at the first Run with a message -- no crash, no hang
+    env = dict(os.environ, PNN_ASYNC_LOAD="0")
+    assert subprocess.check_output([exe, str(tmp_path / "fc8.pnnw"), "8", str(tmp_path / "conv16.pnnw"), "16"], env=env).decode() == out
+    blob = open(str(tmp_path / "fc8.pnnw"), "rb").read()
+    open(str(tmp_path / "cut.pnnw"), "wb").write(blob[:len(blob) // 3])
+    for mode in ("1", "0"):
+        r = subprocess.run([exe, str(tmp_path / "cut.pnnw"), "8", str(tmp_path / "conv16.pnnw"), "16"], env=dict(os.environ, PNN_ASYNC_LOAD=mode),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "cut.pnnw" in r.stderr, (mode, r.returncode, r.stderr)
 
 
 def test_python_evaluator_real_weights(pnn, oracle):
