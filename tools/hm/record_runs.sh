@@ -25,6 +25,8 @@ run "configs[3]-like: hm_16_15_substitution, ONE synthetic 768x512 4:0:0 picture
 run "the same through hm_16_15_switch" --variant switch --width 768 --height 512 --jobs 1
 run "configs[3]-like: hm_16_15_substitution, 4 synthetic 768x512 pictures at a time, in-process contexts (4 x 5 on one GPU)" --variant substitution --width 768 --height 512 --jobs 4
 run "the same 4 through ONE batching service process (encoders and decoders)" --variant substitution --width 768 --height 512 --jobs 4 --service
+run "4:2:0 through hm_16_15_switch (the PNN also predicts chroma blocks, contexts in 2-pixel availability units), ONE 480x320 picture" --variant switch --width 480 --height 320 --jobs 1 --yuv420
+run "with the reference's trained convolutional 4x4 / 8x8 checkpoints in the table (the only trained weights it ships), hm_16_15_switch, ONE 480x320 picture" --variant switch --width 480 --height 320 --jobs 1 --trained-small
 for j in 1 4 16 32; do
     run "configs[4]-like: hm_16_15_switch, $j x 480x320 at a time, ONE batching service" --variant switch --width 480 --height 320 --jobs $j --service
 done

@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--devices", default="0", help="comma-separated HIP devices, one service each; encodes are dealt round-robin "
                                                      "(the multi-GPU form of the HM path: replicas, no collective)")
     ap.add_argument("--trained-small", action="store_true", help="widths 4 / 8 use the trained conv checkpoints")
+    ap.add_argument("--yuv420", action="store_true", help="4:2:0 pictures (the PNN then also predicts chroma blocks, 2-pixel availability units)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hm"))
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -211,8 +212,10 @@ def main():
         frames = [make_frame(args.height, args.width, args.seed + j) for j in range(args.jobs)]
         t0 = time.time()
         with ThreadPoolExecutor(args.jobs) as ex:
-            res = list(ex.map(lambda j: encode_decode(args.variant, frames[j], args.qp, table, mean_path, args.out, tag=str(j), env=job_env(j)),
-                              range(args.jobs)))
+            chroma = [(make_frame(args.height // 2, args.width // 2, args.seed + 1000 + j), make_frame(args.height // 2, args.width // 2, args.seed + 2000 + j))
+                      if args.yuv420 else None for j in range(args.jobs)]
+            res = list(ex.map(lambda j: encode_decode(args.variant, frames[j], args.qp, table, mean_path, args.out, tag=str(j), env=job_env(j),
+                                                      chroma=chroma[j]), range(args.jobs)))
         wall = time.time() - t0
         for r in res:
             print(json.dumps(r))
