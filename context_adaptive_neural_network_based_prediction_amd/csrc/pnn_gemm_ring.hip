@@ -28,6 +28,13 @@
 // through buffer descriptors (blds16 below) and issue a stage in ~640 cycles; the 128x160 stage takes 1097 cycles.  With
 // that, EIGHT loader waves on the small tiles (64x128, 128x64: few registers, three waves per SIMD fit) gain only 2-6 %
 // (stage 653 -> 639, 725 -> 677 cycles for 384 of MFMA work): the CU takes ~38 B/clk of LDS-DMA however many waves ask.
+//
+// Round 2, epilogue (tools/ring_prof.hip stamps, FC 1200x1200 at batch 4096): the workgroup's bias tile is fetched into LDS
+// behind the ring by loader wave 0's first instruction (the 20 global bias loads used to sit between the last MFMA and the
+// first store: 1.2k cycles -> 40); the hi / lo conversion is v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 (pnn_device_common.h);
+// the tile leaves through L2 (store16_through: slower inside the workgroup, 2.8k -> 3.7k cycles of issue, but the next launch
+// no longer waits for ~20 MB of dirty lines: kernel-to-kernel 39.1 -> 37.5 us).  The workgroups of a launch end 2.4-3.8 us
+// apart although they execute the same cycle count: the spread is by XCD (each holds its own clock under the power limit).
 #include "pnn_kernels.h"
 #include <type_traits>
 #include "pnn_device_common.h"
