@@ -600,6 +600,15 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
         const bool wide = p.Cout % 128 == 0 && k_total / p.ncls >= 1152.0;
         const double col_tiles = (double)((p.Cout + 127) / 128) * p.ncls;
         const bool underfilled = k_total >= 1600.0 && (double)((M + 63) / 64) * col_tiles <= 256.0;
+        // stride-2 transposed convolutions to 64 channels (four output-parity classes of 4-9 taps each: short K per class, the
+        // classes as blockIdx.z): from 8192 rows on the tuner takes the 128 x 64 ring tile over the LDS-resident-image kernel
+        // at every batch looked at (16x16 / 32x32 nets, 512 ... 1024 / 128 ... 256 blocks: 26-28 us against 39 at M = 16384)
+        if (p.ncls == 4 && p.Cout == 64 && M >= 8192) {
+            for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
+                const TileCfg t = tapgemm_ring_cfg(i);
+                if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 4 && t.d == 4) return i;
+            }
+        }
         if (!wide && !underfilled) return -1;
         int rt = 1, wm = 2, d = 4;                    // 64 x 128
         if (wide) {
@@ -775,7 +784,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
         const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
-        const bool ring_conv = !one_tap && ri >= 0 && p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0;   // see choose_cfg_ring
+        const bool ring_conv = !one_tap && ri >= 0 && ((p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0) || (p.ncls == 4 && p.Cout == 64 && M >= 8192));   // see choose_cfg_ring
         if (ring_conv && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
         else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
