@@ -585,7 +585,9 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
         const double wgs = (double)((nimg + g - 1) / g) * tn * p.ncls;
         const double fill = wgs >= 512.0 ? 1.0 : 512.0 / wgs;
         const double cost = pad * height * fill;
-        if (cost < best_cost) { best_cost = cost; best_fit = pad * height; best = i; }
+        // what decides whether the family is used at all: idle rows / columns and an unsuitable height -- for the 32-channel
+        // layers the padding alone (their preferred height depends on the batch through `fill`)
+        if (cost < best_cost) { best_cost = cost; best_fit = p.Cout <= 32 ? pad : pad * height; best = i; }
     }
     // 32-channel layers (the 4x4 conv net) fill only half of the narrowest tile's 64 columns and still run 30 % faster here than
     // on the register-staged kernel (tuner, batch 4096: 29.6 / 21.7 / 11.0 us for its three layers against a 120 vs 91 us pass)
@@ -644,7 +646,8 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
         const double slow = t.kc == 1 ? 1.35 : (resident == 2 ? 1.25 : (t.d >= 4 ? 1.17 : 1.6));
         const double wg = 5000.0 + 1400.0 * t.rt * t.nt + stages * mfma * slow;
         const double rounds = std::ceil(nwg / (256.0 * resident));
-        const double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);   // two co-resident workgroups share the CU's MFMA pipes
+        double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);         // two co-resident workgroups share the CU's MFMA pipes
+        cost *= 1.0 + 0.05 * (1.0 - nwg / (256.0 * resident * rounds));   // ties: the tile that leaves fewer CUs idle (M = 1024: 64 x 128 over 128 x 64, as the tuner)
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     return best;
