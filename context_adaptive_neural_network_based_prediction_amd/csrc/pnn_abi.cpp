@@ -597,6 +597,11 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 // Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
 // kernels.  Calibrated with tools/ring_prof.hip: a workgroup costs ~(prologue + epilogue) + stages x 1.45 x its MFMA
 // cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
+static bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total)
+{
+    return p.ncls == 1 && p.Cout == 64 && k_total >= 512.0 && M / ((long)p.SH * p.SW) < 128 && (M + 63) / 64 >= 128;
+}
+
 static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
 {
     if (!fused && !one_tap) {
@@ -617,7 +622,11 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
                 if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 4 && t.d == 4) return i;
             }
         }
-        if (!wide && !underfilled) return -1;
+        // 64-channel 3x3 layers of a FEW images (under 128: the image kernel gets one workgroup per image or less and leaves most
+        // of the chip idle) but enough rows for >= 128 tiles of 64 rows: the 64 x 128 ring tile, half its columns empty, is what
+        // the tuner takes (16x16 net, 64 blocks: 17.9 us against 28)
+        const bool few_images = pnn_ring_few_images(p, M, k_total);
+        if (!wide && !underfilled && !few_images) return -1;
         int rt = 1, wm = 2, d = 4;                    // 64 x 128
         if (wide) {
             if ((double)((M + 191) / 192) * col_tiles >= 192.0) { rt = 3; d = 3; }        // 192 x 128
@@ -793,7 +802,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     else if (c->opt_sp_cfg < 0) {
         const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
         const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
-        const bool ring_conv = !one_tap && ri >= 0 && ((p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0) || (p.ncls == 4 && p.Cout == 64 && M >= 8192));   // see choose_cfg_ring
+        const bool ring_conv = !one_tap && ri >= 0 && ((p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0) || (p.ncls == 4 && p.Cout == 64 && M >= 8192) || pnn_ring_few_images(p, M, L.k_total));   // see choose_cfg_ring
         if (ring_conv && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
         else if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
         else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
