@@ -591,7 +591,7 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
     }
     // 32-channel layers (the 4x4 conv net) fill only half of the narrowest tile's 64 columns and still run 30 % faster here than
     // on the register-staged kernel (tuner, batch 4096: 29.6 / 21.7 / 11.0 us for its three layers against a 120 vs 91 us pass)
-    return best_fit <= (p.Cout <= 32 ? 2.3 : 1.6) ? best : -1;
+    return best_fit <= (p.Cout <= 32 ? 3.0 : 1.6) ? best : -1;
 }
 
 // Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
