@@ -638,7 +638,7 @@ static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double 
         }
         return -1;
     }
-    if (!fused && ((double)M * p.Cout < 5.0e5 || p.Cin < 256)) return -1;   // FC layers from ~512 rows on (tuner logs: ring 64x128 / 128x64 tiles win there too)
+    if (!fused && ((double)M * p.Cout < 5.0e5 || p.Cin < 64)) return -1;   // FC layers from ~512 rows on (tuner logs: ring 64x128 / 128x64 tiles win there too)
     int best = -1;
     double best_cost = 1e300;
     for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
