@@ -599,7 +599,7 @@ static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
 // cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
 static bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total)
 {
-    return p.ncls == 1 && p.Cout == 64 && k_total >= 512.0 && M / ((long)p.SH * p.SW) < 128 && (M + 63) / 64 >= 128;
+    return (p.ncls == 1 || p.ncls == 4) && p.Cout == 64 && k_total / p.ncls >= 512.0 && M / ((long)p.SH * p.SW) < 128 && (M + 63) / 64 * p.ncls >= 128;
 }
 
 static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
