@@ -211,57 +211,164 @@ def params_from_tf_bundle(prefix, width, is_fc):
 
 
 # ---------------------------------------------------------------------------------------------
-# Frozen GraphDef reader: the `graph_output.pbtxt` files written by the
-# reference's freezing_graph_pnn.py:131-143 are BINARY GraphDefs whose weights are Const nodes
-# named like the variables of Appendix B.7.  No TensorFlow needed.
+# GraphDef / MetaGraphDef walker, no TensorFlow needed.  Two kinds of TF-written
+# files carry the PNN graphs: the frozen `graph_output.pbtxt` files of freezing_graph_pnn.py:131-143
+# (BINARY GraphDefs whose weights are Const nodes named like the variables of Appendix B.7) and the
+# `model_*.ckpt.meta` files beside every checkpoint (MetaGraphDef: field 2 = the training GraphDef, whose
+# inference subgraph holds the same ops with VariableV2 nodes where freezing puts Consts).
+# Field numbers: tensorflow/core/framework/{graph,node_def,attr_value,tensor,tensor_shape}.proto (TF 1.x).
 # ---------------------------------------------------------------------------------------------
-def read_frozen_graph_consts(path):
-    """{node_name: float32 ndarray} for every float Const node of a binary GraphDef."""
-    with open(path, "rb") as f:
-        buf = f.read()
-    consts = {}
+_TF_DTYPES = {1: "<f4", 2: "<f8", 3: "<i4", 9: "<i8", 10: "?"}   # DT_FLOAT, DT_DOUBLE, DT_INT32, DT_INT64, DT_BOOL
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _packed_varints(wt, v):
+    if wt == 0:
+        return [_signed64(v)]
+    out, pos = [], 0
+    while pos < len(v):
+        x, pos = _varint(v, pos)
+        out.append(_signed64(x))
+    return out
+
+
+def parse_tensor_shape(buf):
+    """TensorShapeProto -> list of dims (dim = 2 {size = 1}); unknown_rank (3) -> None."""
+    shape = []
+    for f, wt, v in _proto_fields(buf):
+        if f == 2:
+            sz = 0
+            for f2, _, v2 in _proto_fields(v):
+                if f2 == 1: sz = _signed64(v2)
+            shape.append(sz)
+        elif f == 3 and v:
+            return None
+    return shape
+
+
+def parse_tensor_proto(buf):
+    """TensorProto -> ndarray (dtype = 1, tensor_shape = 2, tensor_content = 4, float_val = 5, double_val = 6,
+    int_val = 7, int64_val = 10, bool_val = 11); string tensors -> None.  A tensor whose repeated *_val field
+    holds ONE value is that value broadcast over the shape (how TF stores constant-filled tensors)."""
+    dtype, shape, content, vals = 0, [], None, []
+    for f, wt, v in _proto_fields(buf):
+        if f == 1: dtype = v
+        elif f == 2: shape = parse_tensor_shape(v)
+        elif f == 4: content = v
+        elif f == 5: vals += list(np.frombuffer(v, dtype="<f4"))              # packed or one fixed32
+        elif f == 6: vals += list(np.frombuffer(v, dtype="<f8"))
+        elif f in (7, 10, 11): vals += _packed_varints(wt, v)
+    np_dt = _TF_DTYPES.get(dtype)
+    if np_dt is None or shape is None:
+        return None
+    n = int(np.prod(shape)) if shape else 1
+    if content is not None and len(content) == n * np.dtype(np_dt).itemsize:
+        arr = np.frombuffer(content, dtype=np_dt).copy()
+    elif len(vals) == n:
+        arr = np.array(vals, dtype=np_dt)
+    elif len(vals) == 1:
+        arr = np.full(n, vals[0], dtype=np_dt)
+    elif n == 0:
+        arr = np.zeros(0, dtype=np_dt)
+    else:
+        return None
+    return arr.reshape(shape)
+
+
+def parse_attr_value(buf):
+    """AttrValue -> Python value: s (2) bytes, i (3) int, f (4) float, b (5) bool, type (6) int, shape (7) list,
+    tensor (8) ndarray, list (1) -> list of the same."""
+    for f, wt, v in _proto_fields(buf):
+        if f == 2: return bytes(v)
+        if f == 3: return _signed64(v)
+        if f == 4: return float(np.frombuffer(v, dtype="<f4")[0])
+        if f == 5: return bool(v)
+        if f == 6: return int(v)
+        if f == 7: return parse_tensor_shape(v)
+        if f == 8: return parse_tensor_proto(v)
+        if f == 1:
+            out = []
+            for f2, w2, v2 in _proto_fields(v):
+                if f2 == 2: out.append(bytes(v2))
+                elif f2 in (3, 6): out += _packed_varints(w2, v2)
+                elif f2 == 4: out += [float(x) for x in np.frombuffer(v2, dtype="<f4")]
+                elif f2 == 5: out += [bool(x) for x in _packed_varints(w2, v2)]
+                elif f2 == 7: out.append(parse_tensor_shape(v2))
+                elif f2 == 8: out.append(parse_tensor_proto(v2))
+            return out
+    return None
+
+
+class GraphNode(object):
+    """One NodeDef: name (1), op (2), inputs (3, repeated), attr (5, map<string, AttrValue>) decoded on demand."""
+    __slots__ = ("name", "op", "inputs", "_attrs")
+
+    def __init__(self, name, op, inputs, attrs):
+        self.name, self.op, self.inputs, self._attrs = name, op, inputs, attrs
+
+    def attr(self, key, default=None):
+        raw = self._attrs.get(key)
+        return default if raw is None else parse_attr_value(raw)
+
+    def attr_names(self):
+        return sorted(self._attrs)
+
+
+def parse_graph_def(buf):
+    """Binary GraphDef -> {node name: GraphNode}, in file order."""
+    nodes = {}
     for field, wt, node in _proto_fields(buf):
         if field != 1 or wt != 2:                       # GraphDef.node
             continue
-        name, op, tensor = None, None, None
+        name, op, inputs, attrs = None, None, [], {}
         for f2, w2, v2 in _proto_fields(node):
             if f2 == 1: name = v2.decode()
             elif f2 == 2: op = v2.decode()
-            elif f2 == 5:                               # NodeDef.attr map entry {key = 1, value = 2 (AttrValue)}
-                key, val = None, None
+            elif f2 == 3: inputs.append(v2.decode())
+            elif f2 == 5:                               # map entry {key = 1, value = 2}
+                key, val = None, b""
                 for f3, _, v3 in _proto_fields(v2):
                     if f3 == 1: key = v3.decode()
                     elif f3 == 2: val = v3
-                if key == "value" and val is not None:
-                    for f4, w4, v4 in _proto_fields(val):
-                        if f4 == 8 and w4 == 2: tensor = v4   # AttrValue.tensor (TensorProto)
-        if op != "Const" or tensor is None:
+                attrs[key] = val
+        if name is not None:
+            nodes[name] = GraphNode(name, op, inputs, attrs)
+    return nodes
+
+
+def read_graph_def(path):
+    """{node name: GraphNode} of a binary GraphDef file (a frozen `graph_output.pbtxt`)."""
+    with open(path, "rb") as f:
+        return parse_graph_def(f.read())
+
+
+def meta_graph_def_bytes(path):
+    """The serialized GraphDef (field 2) inside a MetaGraphDef file (`model_*.ckpt.meta`)."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    for field, wt, v in _proto_fields(buf):
+        if field == 2 and wt == 2:
+            return bytes(v)
+    raise ValueError("%s holds no graph_def" % path)
+
+
+def read_meta_graph(path):
+    """{node name: GraphNode} of the graph_def of a MetaGraphDef file."""
+    return parse_graph_def(meta_graph_def_bytes(path))
+
+
+def read_frozen_graph_consts(path):
+    """{node_name: float32 ndarray} for every float Const node of a binary GraphDef."""
+    consts = {}
+    for name, node in read_graph_def(path).items():
+        if node.op != "Const":
             continue
-        dtype, shape, content, float_vals = 0, [], None, []
-        for f5, w5, v5 in _proto_fields(tensor):
-            if f5 == 1: dtype = v5
-            elif f5 == 2:
-                for f6, _, dim in _proto_fields(v5):
-                    if f6 == 2:
-                        sz = 0
-                        for f7, _, v7 in _proto_fields(dim):
-                            if f7 == 1: sz = v7
-                        shape.append(sz)
-            elif f5 == 4: content = v5
-            elif f5 == 5:                               # float_val: packed (wire type 2) or single fixed32 (wire type 5)
-                float_vals += list(np.frombuffer(v5, dtype="<f4")) if w5 in (2, 5) else []
-        if dtype != 1:
-            continue
-        n = int(np.prod(shape)) if shape else 1
-        if content is not None and len(content) == 4 * n:
-            arr = np.frombuffer(content, dtype="<f4").copy()
-        elif len(float_vals) == n:
-            arr = np.array(float_vals, np.float32)
-        elif len(float_vals) == 1:                      # TF stores a constant-filled tensor as one value
-            arr = np.full(n, float_vals[0], np.float32)
-        else:
-            continue
-        consts[name] = arr.reshape(shape)
+        arr = node.attr("value")
+        if isinstance(arr, np.ndarray) and arr.dtype == np.float32:
+            consts[name] = arr
     return consts
 
 

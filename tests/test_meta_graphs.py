@@ -1,0 +1,221 @@
+"""The networks pinned on the reference's OWN serialized graphs (tests/golden/meta_graphs.npz,
+tests/golden/make_meta_goldens.py): the 13 TF-written MetaGraphDefs under /root/reference/pnn, executed by
+oracle/tf_graph_interp.py with every structural parameter taken from the file.
+
+  * CPU: the oracle equals the graphs' outputs (seeded variables for all 13, the trained variables for the two complete
+    checkpoints); the op list / attrs the files state equal what the architecture tables of weights.py imply; the two
+    .meta files the reference's own tests use (committed gzipped) go through the protobuf walker and the interpreter here.
+  * GPU: the HIP path equals the same fixtures (float within FLOAT_ATOL, Pel within one LSB).
+
+Tolerance: fixtures are the graph's value in float64 rounded to float32; the oracle sums in float32 sequentially, so
+|oracle - fixture| <= 5e-4 on outputs spanning +-300 (K up to 12 800 products per output); measured max 2.9e-4 (FC 16x16).
+"""
+import glob
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from context_adaptive_neural_network_based_prediction_amd import weights as wts
+from tests import util
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+G = np.load(os.path.join(GOLD, "meta_graphs.npz"))
+TAGS = [str(t) for t in G["tags"]]
+ORACLE_ATOL = 5e-4
+FLOAT_ATOL = 2e-3
+REF_PNN = "/root/reference/pnn"
+
+
+def _case(tag):
+    """-> (width, is_fc, params flat, above, left, expected [kept][w][w])"""
+    width, is_fc, batch, seed, keep, in_seed = [int(v) for v in G[tag + "_info"]]
+    is_fc = bool(is_fc)
+    if seed < 0:
+        params = wts.load_pnnw(os.path.join(GOLD, "conv%d_single.pnnw" % width))[0]
+    else:
+        params = util.make_params(width, is_fc, seed, out_gain=util.out_gain(width, is_fc))
+    above, left = util.make_contexts(width, batch, in_seed)
+    return width, is_fc, params, above[:keep], left[:keep], G[tag + "_out"]
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_equals_the_serialized_graphs(oracle, tag):
+    width, is_fc, params, above, left, want = _case(tag)
+    got = oracle.fc_forward(params, width, util.flatten_fc(above, left)) if is_fc else oracle.conv_forward(params, width, above, left)
+    assert want.max() - want.min() > 50
+    np.testing.assert_allclose(got, want, rtol=0, atol=ORACLE_ATOL)
+
+
+def _expected_structure(width, is_fc, batch):
+    """What pnn/components.py + pnn/tfutils.py are READ to build, as weights.tensor_specs / STRIDES_BRANCH restate it
+    (the same tables the oracle and the HIP path take their shapes from) -- in the row format of tf_graph_interp.structure."""
+    specs = dict((n, list(s)) for n, s, _ in wts.tensor_specs(width, is_fc))
+    leak = float(np.float32(0.1))
+    rows = []
+    if is_fc:
+        for i in range(4):
+            rows.append(["fully_connected/MatMul" + ("_%d" % i if i else ""), "MatMul", None, None,
+                         specs["fully_connected/weights_%d" % i], [False, False, False, False]])
+            rows.append([None, "BiasAdd", None, None, None, None])
+            if i < 3:
+                rows.append([None, "Mul", None, None, None, leak])
+                rows.append([None, "Maximum", None, None, None, None])
+        rows.append([None, "Reshape", None, None, None, [batch, width, width, 1]])
+        return rows
+    strides = wts.STRIDES_BRANCH[width]
+    for branch in ("branch_above", "branch_left"):
+        for i, s in enumerate(strides):
+            rows.append(["convolutional/%s/convolution_%d/Conv2D" % (branch, i), "Conv2D", [1, s, s, 1], "SAME",
+                         specs["convolutional/%s/convolution_%d/weights" % (branch, i)], None])
+            rows += [[None, "BiasAdd", None, None, None, None], [None, "Mul", None, None, None, leak],
+                     [None, "Maximum", None, None, None, None]]
+    c = specs["convolutional/merger/channelwise_fully_connected_merger/weights"][0]
+    rows += [[None, "Reshape", None, None, None, [batch, 48, c]], [None, "Transpose", None, None, None, [2, 0, 1]],
+             [None, "Reshape", None, None, None, [batch, 32, c]], [None, "Transpose", None, None, None, [2, 0, 1]],
+             [None, "Concat", None, None, None, 2],
+             [None, "BatchMatMul", None, None, [c, 80, 16], [False, False, False, False]],
+             [None, "ExpandDims", None, None, None, [1]], [None, "Tile", None, None, None, [1, batch, 1]],
+             [None, "Add", None, None, None, None], [None, "Transpose", None, None, None, [1, 2, 0]],
+             [None, "Reshape", None, None, None, [batch, 4, 4, c]], [None, "Mul", None, None, None, leak],
+             [None, "Maximum", None, None, None, None]]
+    size = 4
+    rev = strides[::-1]
+    for i, s in enumerate(rev):
+        shape = specs["convolutional/merger/transpose_convolution_%d/weights" % i]
+        size *= s
+        rows.append(["convolutional/merger/transpose_convolution_%d/conv2d_transpose" % i, "Conv2DBackpropInput",
+                     [1, s, s, 1], "SAME", shape, [batch, size, size, shape[2]]])
+        rows.append([None, "BiasAdd", None, None, None, None])
+        if i < len(rev) - 1:
+            rows += [[None, "Mul", None, None, None, leak], [None, "Maximum", None, None, None, None]]
+    assert size == width
+    return rows
+
+
+def _same_structure(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for g, w in zip(got, want):
+        g = list(g)
+        if g[1] == "ConcatV2":
+            g[1] = "Concat"                                     # same op, pre-/post-1.0 spelling; axis already normalised
+        if w[0] is not None:
+            assert g[0] == w[0], (g, w)
+        assert g[1:] == w[1:], (g, w)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_serialized_structure_equals_the_architecture_tables(tag):
+    """Strides, padding, filter shapes, perms, axes, output shapes, operand order, LeakyReLU slope and where it is
+    applied: what the TF-written file states == what weights.tensor_specs / STRIDES_BRANCH (hence oracle and kernels) use."""
+    width, is_fc, batch = [int(v) for v in G[tag + "_info"][:3]]
+    _same_structure(json.loads(str(G[tag + "_structure"])), _expected_structure(width, bool(is_fc), batch))
+
+
+@pytest.mark.parametrize("w,tag", [(4, "pseudo_w4"), (16, "pseudo_w16")])
+def test_walker_and_interpreter_on_committed_tf_written_files(tmp_path, w, tag):
+    """TF-written bytes (the .meta files of the reference's test_pnn.py:465-494) through weights.read_meta_graph and the
+    interpreter, where /root/reference does not exist: the fixture is reproduced from the file to float32 rounding."""
+    from oracle import tf_graph_interp as tfi
+    path = str(tmp_path / "model.ckpt.meta")
+    with gzip.open(os.path.join(GOLD, "ref_meta", "pseudo_w%d.meta.gz" % w), "rb") as f, open(path, "wb") as out:
+        out.write(f.read())
+    nodes = wts.read_meta_graph(path)
+    assert len(nodes) > 500 and all(n.op for n in nodes.values())
+    out_name, ins, _ = tfi.network_io(nodes)
+    assert out_name == wts.output_node_name(w, w == 4)
+    width, is_fc, params, above, left, want = _case(tag)
+    batch, in_seed = int(G[tag + "_info"][2]), int(G[tag + "_info"][5])
+    a, l = util.make_contexts(width, batch, in_seed)
+    feeds = {ins[0]: util.flatten_fc(a, l)} if is_fc else {ins[0]: a[..., None], ins[1]: l[..., None]}
+    variables = wts.split_params(params, width, is_fc)
+    interp = tfi.Interpreter(nodes, variables)
+    y = interp.run(out_name, feeds)[..., 0]
+    np.testing.assert_allclose(y[:want.shape[0]], want, rtol=0, atol=1e-5)
+    used = set(name for op, name in interp.trace if op.startswith("Variable"))
+    assert used == set(variables), "the graph reads exactly the variables of Appendix B.7"
+    _same_structure(json.loads(json.dumps(tfi.structure(nodes), default=lambda b: b.decode())),
+                    _expected_structure(width, is_fc, batch))
+    # f1: the Const reader of the frozen-graph route on a GraphDef TensorFlow wrote (the .meta's graph_def, saved as a file)
+    gd = str(tmp_path / "graph_def.pb")
+    with open(gd, "wb") as f:
+        f.write(wts.meta_graph_def_bytes(path))
+    consts = wts.read_frozen_graph_consts(gd)
+    leaks = [v for k, v in consts.items() if k.endswith("/x") and "/gradients/" not in k and
+             (k.startswith("fully_connected/mul") or k.startswith("convolutional/"))]
+    assert len(leaks) == (3 if is_fc else 12) and all(v.shape == () and v == np.float32(0.1) for v in leaks)
+    assert all(v.dtype == np.float32 for v in consts.values())
+    with pytest.raises(KeyError):
+        wts.params_from_frozen_graph(gd, width, is_fc)     # a training graph: variables, not Const weights
+    bad = dict(variables)
+    k = [n for n in sorted(bad) if bad[n].ndim > 1][0]
+    bad[k] = bad[k].reshape(-1)
+    with pytest.raises(ValueError):
+        tfi.Interpreter(nodes, bad).run(out_name, feeds)
+
+
+def test_fixtures_live_against_the_reference_files():
+    """Build container only: every .meta under /root/reference/pnn still yields the committed structure, and the trained
+    conv 4x4 / 8x8 checkpoints executed from their own .meta + .index + .data files yield the committed outputs."""
+    if not os.path.isdir(REF_PNN):
+        pytest.skip("no /root/reference here")
+    from oracle import tf_graph_interp as tfi
+    paths = sorted(glob.glob(REF_PNN + "/**/*.meta", recursive=True))
+    assert len(paths) == 13
+    by_path = {}
+    for t in TAGS:
+        by_path.setdefault(str(G[t + "_path"]), []).append(t)
+    for p in paths:
+        nodes = wts.read_meta_graph(p)
+        got = json.loads(json.dumps(tfi.structure(nodes), default=lambda b: b.decode()))
+        for t in by_path[os.path.relpath(p, REF_PNN)]:
+            assert got == json.loads(str(G[t + "_structure"])), t
+    for w in (4, 8):
+        tag = "conv_single_w%d_real" % w
+        prefix = os.path.join(REF_PNN, str(G[tag + "_path"]))[:-len(".meta")]
+        nodes = wts.read_meta_graph(prefix + ".meta")
+        variables = wts.read_tf_bundle(prefix)
+        out_name, ins, _ = tfi.network_io(nodes)
+        batch, in_seed = int(G[tag + "_info"][2]), int(G[tag + "_info"][5])
+        a, l = util.make_contexts(w, batch, in_seed)
+        y = tfi.Interpreter(nodes, variables).run(out_name, {ins[0]: a[..., None], ins[1]: l[..., None]})[..., 0]
+        np.testing.assert_allclose(y, G[tag + "_out"], rtol=0, atol=1e-5)
+        # the committed .pnnw holds the same variables, in the canonical order
+        flat = wts.load_pnnw(os.path.join(GOLD, "conv%d_single.pnnw" % w))[0]
+        for name, arr in wts.split_params(flat, w, False).items():
+            assert np.array_equal(arr, variables[name]), name
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the same fixtures, both arithmetics
+# ------------------------------------------------------------------------------------------------------------------
+def _check_pel(got, want):
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert diff.max() <= 1, "max |delta| = %d LSB" % diff.max()
+    assert (diff != 0).mean() <= 2e-4 + 1.0 / diff.size, "%.4f %% of pixels differ" % (100 * (diff != 0).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "split_f16"])
+@pytest.mark.parametrize("tag", [t for t in TAGS if "pair" not in t and not t.startswith("pseudo")])
+def test_hip_equals_the_serialized_graphs(oracle, monkeypatch, precision, tag):
+    """float predictions within FLOAT_ATOL of the graph's value; HM epilogue within one LSB of the epilogue of that value."""
+    import context_adaptive_neural_network_based_prediction_amd as pnn
+    monkeypatch.setenv("PNN_PRECISION", "0" if precision == "f32" else "1")
+    width, is_fc, params, above, left, want = _case(tag)
+    n = want.shape[0]
+    net = pnn.PredictionNeuralNetwork(n, width, is_fc, params=params)
+    if is_fc:
+        ctx = util.flatten_fc(above, left)
+        got, pel = net.predict(ctx), net.predict_pel(ctx)
+    else:
+        got, pel = net.predict(above, left), net.predict_pel(above, left)
+    np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=FLOAT_ATOL)
+    _check_pel(pel, oracle.epilogue(want, util.MEAN))
+    if precision == "split_f16" and n >= 32:
+        net.set_option("split_min_px", 0)                     # pin the split-product kernels whatever the batch rule says
+        got = net.predict(util.flatten_fc(above, left)) if is_fc else net.predict(above, left)
+        np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=FLOAT_ATOL)
+    net.close()
