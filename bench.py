@@ -8,9 +8,12 @@ batch of synthetic transform blocks per GPU, inputs (reconstructed planes + TB d
 HBM.  Default workload = BASELINE.json configs[1]: 8x8 fully-connected PNN, batch 4096, 1 x MI355X.
 For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own batch
 (independent blocks: no data-path collective, weak scaling) and the time is the max over ranks.
-Prints ONE JSON line on rank 0.  Top level = the workload on the library's default arithmetic; at N = 1 the line
-also carries `f32_exact` (the same workload on exact-f32 MFMA, the reference's own arithmetic) and `conv16`
-(BASELINE.json configs[2], both arithmetics), each with its own parity check, roofline and CPU legs.
+Prints ONE JSON line on rank 0.  Top level = the workload on the library's default arithmetic (f32 emulated with split
+f16 operands, see DTYPE); at N = 1 the line also carries `reference_arithmetic` (the same workload on exact-f32 MFMA, the
+reference's own arithmetic -- the figure to quote against a float32 TF graph), `conv16` (BASELINE.json configs[2], both
+arithmetics) and `sustained` (>= 2 s of back-to-back steps per workload and arithmetic: the power-limited steady state),
+each with its own parity check and roofline; compact copies of the first and the last sit inside `roofline`.
+`--gpus N` without a launcher (WORLD_SIZE unset) starts its own ranks: `python -m torch.distributed.run` as a CHILD process.
 """
 import argparse
 import ctypes
@@ -28,7 +31,10 @@ RAMP_SECONDS = 0.4          # untimed device ramp-up before the warm-up steps (s
 REPEATS = 5                 # timed regions of K steps each; value = the median region
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32)
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
-DTYPE = {1: "f32 (3 x f16 MFMA split products, f32 accumulate)", 0: "f32"}
+SUSTAIN_SECONDS = 2.0       # one region of back-to-back steps per (workload, arithmetic): the steady state the SMI sampler can see
+DTYPE = {1: "f32 emulated: 2 x f16 per operand (hi + lo, 22-bit significand), 3 of the 4 partial products on f16 MFMA "
+            "(lo*lo dropped), f32 accumulate",
+         0: "f32 (IEEE float32 operands on f32 MFMA, f32 accumulate: the reference's arithmetic)"}
 
 WORKLOADS = {                      # name -> (width, is_fc, default batch per GPU, BASELINE.json config)
     "fc4": (4, True, 4096, "4x4 fully-connected PNN"),
@@ -116,7 +122,18 @@ class Workload:
         return self._oracle_pred
 
 
-def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True):
+def stagger(dist, fn):
+    """Runs `fn` one rank after the other (first call of a workload = on-device tile autotune: every rank tunes on an
+    otherwise idle node, as at N = 1, instead of N tuners timing launches at once)."""
+    if dist is None:
+        return fn()
+    for r in range(dist.get_world_size()):
+        if r == dist.get_rank():
+            fn()
+        dist.barrier()
+
+
+def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sustain_s=0.0):
     """Times the hot path of workload `wl` on arithmetic `precision` (1: split products on f16 MFMA, 0: exact-f32 MFMA)
     and derives the dominant kernel's roofline from HIP events attached to every tap-GEMM launch."""
     import torch
@@ -135,8 +152,10 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True):
     # Set-up, untimed and outside the W warm-up steps: the first calls autotune the tile configurations, and the device
     # needs a few hundred milliseconds of sustained work before it holds its clocks (measured: 0.126 ms per step right
     # after start, 0.113 ms once warm) -- run steps for RAMP_SECONDS so that W and K see the steady state.
-    step()
-    torch.cuda.synchronize()
+    def first():
+        step()
+        torch.cuda.synchronize()
+    stagger(dist, first)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < RAMP_SECONDS:
         for _ in range(20):
@@ -159,6 +178,14 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True):
         "launches_per_step": stats["launches"],
     }
     gpu_pred = wl.d_dst.cpu().numpy()
+    if sustain_s > 0:
+        # ---- sustained: ONE region of back-to-back steps lasting >= sustain_s, clocks sampled from sysfs meanwhile
+        from context_adaptive_neural_network_based_prediction_amd.sharding import GpuClockSampler
+        k = max(steps, int(1.1 * sustain_s / (elapsed / steps)))
+        with GpuClockSampler(wl.local_rank) as smp:
+            t = sharding.timed_steps(step, k, torch.cuda.synchronize, dist, None if os.environ.get("PNN_BENCH_SHARE_GPU") == "1" else "cuda")
+        res["sustained"] = {"value": float(n) * world * k / t, "unit": "blocks/s", "ms_per_step": 1e3 * t / k, "steps": k, "seconds": t,
+                            "vs_burst": (float(n) * world * k / t) / res["value"], "gpu_clock": smp.summary()}
 
     # ---- roofline of the dominant GEMM kernel: the network alone on pre-gathered contexts, HIP events on the launch stream
     def net_only():
@@ -297,6 +324,38 @@ def cpu_legs(wl, budget_s=2.0):
             "legs": legs}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` run plainly: this process stays off the GPU and starts the N ranks as a CHILD
+    (`python -m torch.distributed.run`, one process per GPU, rendezvous on 127.0.0.1), relays rank 0's JSON line and
+    exits with the child's code.  Never os.exec*: a process that may have touched HIP must not be replaced."""
+    import socket
+    import subprocess
+    import torch
+    if os.environ.get("PNN_BENCH_SHARE_GPU") != "1":
+        have = torch.cuda.device_count()             # counting devices does not initialise HIP on this image
+        if have < args.gpus:
+            raise SystemExit("--gpus %d: this node exposes %d GPU(s)" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line:
+        print(line)
+    sys.stdout.flush()
+    raise SystemExit(r.returncode if r.returncode or line else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,7 +364,8 @@ def main():
     ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the f32_exact / conv16 sub-measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the reference_arithmetic / conv16 sub-measurements")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= %.0f s sustained regions" % SUSTAIN_SECONDS)
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)       # internal: one CPU-baseline leg, see cpu_leg_worker
     ap.add_argument("--leg-batch1", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--leg-threads", type=int, default=1, help=argparse.SUPPRESS)
@@ -314,19 +374,21 @@ def main():
     if args.cpu_leg:
         return cpu_leg_worker(args.cpu_leg, args.workload, bool(args.leg_batch1), args.leg_threads, args.leg_budget)
 
-    import torch
     from context_adaptive_neural_network_based_prediction_amd import sharding
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)                     # before anything initialises HIP in this process
+    import torch
 
     rank, local_rank, world = sharding.rank_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    share = os.environ.get("PNN_BENCH_SHARE_GPU") == "1"
+    # next to the GPU before the first HIP call: host cores of the device's NUMA node (sysfs only)
+    bound = sharding.bind_to_gpu_numa(0 if share else local_rank) if world > 1 else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # Plumbing check on a ONE-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): PNN_BENCH_SHARE_GPU=1 puts
     # every rank on device 0 and joins them over gloo (RCCL refuses two ranks on one device).  Never a measurement.
-    share = os.environ.get("PNN_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -335,7 +397,8 @@ def main():
     precision = int(os.environ.get("PNN_PRECISION", "1"))
     wl = Workload(args.workload, args.batch, rank, local_rank)
     single = world == 1
-    main_res = measure(wl, precision, args.steps, args.warmup, dist, check=(rank == 0 and single))
+    sustain = 0.0 if args.no_sustained else SUSTAIN_SECONDS
+    main_res = measure(wl, precision, args.steps, args.warmup, dist, check=(rank == 0 and single), sustain_s=sustain)
     out = None
     if rank == 0:
         out = {
@@ -349,24 +412,39 @@ def main():
                        "parallelism": "independent blocks sharded over ranks, no data-path collective" + (" [PNN_BENCH_SHARE_GPU=1: all ranks on ONE device, plumbing check only]" if share else ""),
                        "tile_autotune": "on first use, before the warm-up steps (pnn_set_option autotune)",
                        "device_ramp": "%.2f s of untimed steps before the W warm-up steps (clock ramp)" % RAMP_SECONDS,
-                       "timed_regions": "%d regions of exactly K steps, each bracketed by barrier + synchronize; value = median region" % REPEATS},
+                       "timed_regions": "%d regions of exactly K steps, each bracketed by barrier + synchronize; value = median region" % REPEATS,
+                       "arithmetic": "library default (`precision` = 1), see dtype; the same workload on the reference's IEEE-f32 arithmetic is "
+                                     "`reference_arithmetic` (and roofline.reference_arithmetic)",
+                       "rank_placement": ("rank 0 bound to cpus %s (its GPU's NUMA node)" % bound) if bound else "no NUMA binding (one node / not exposed)"},
         }
         for k in ("repeats", "launches_per_step", "max_abs_lsb_vs_oracle", "parity_detail", "pred_psnr", "roofline"):
             out[k] = main_res.get(k)
         out["cpu_baseline"] = None
+        out["sustained"] = {wl.name + ("_split_f16" if precision == 1 else "_f32"): main_res.get("sustained")}
     if single and not args.no_extras:
         # the reference's own arithmetic on the same workload, and configs[2] on both
         extras = {}
+        compact = lambda r: {"value": r["value"], "unit": "blocks/s", "ms_per_step": r["ms_per_step"], "dtype": r["dtype"],
+                             "roofline_frac": r["roofline"]["frac"], "roofline_peak_tflops": r["roofline"]["peak"],
+                             "roofline_achieved_tflops": r["roofline"]["achieved"], "max_abs_lsb_vs_oracle": r.get("max_abs_lsb_vs_oracle")}
         if precision != 0:
-            extras["f32_exact"] = measure(wl, 0, args.steps, args.warmup, None)
+            ref = measure(wl, 0, args.steps, args.warmup, None, sustain_s=sustain)
+            extras["reference_arithmetic"] = ref
+            out["roofline"]["reference_arithmetic"] = compact(ref)
+            out["sustained"][wl.name + "_f32"] = ref.pop("sustained", None)
         if args.workload != "conv16":
             wc = Workload("conv16", 0, rank, local_rank)
             k16 = max(20, args.steps // 4)
+            c_sp, c_f32 = measure(wc, 1, k16, args.warmup, None, sustain_s=sustain), measure(wc, 0, k16, args.warmup, None, sustain_s=sustain)
+            out["sustained"]["conv16_split_f16"] = c_sp.pop("sustained", None)
+            out["sustained"]["conv16_f32"] = c_f32.pop("sustained", None)
             extras["conv16"] = {"config": {"workload": wc.cfg_name, "batch_per_gpu": wc.batch, "steps": k16},
-                                "split_f16": measure(wc, 1, k16, args.warmup, None), "f32_exact": measure(wc, 0, k16, args.warmup, None)}
+                                "split_f16": c_sp, "reference_arithmetic": c_f32}
+            out["roofline"]["conv16"] = {"split_f16": compact(c_sp), "reference_arithmetic": compact(c_f32)}
             if not args.no_cpu_baseline:
                 extras["conv16"]["cpu_baseline"] = cpu_legs(wc, budget_s=1.5)
         out.update(extras)
+        out["roofline"]["sustained"] = out["sustained"]
     if rank == 0 and single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_legs(wl)
     if rank == 0:

@@ -1,13 +1,12 @@
-// C-ABI layer of libpnn_hip.so (declared in include/pnn_hip.h): contexts, model loading and weight
-// pre-packing, workspace management, and the launch sequences of the FC and convolutional PNNs.
+// C-ABI layer of libpnn_hip.so (declared in include/pnn_hip.h): contexts, model files, staging buffers, the prediction
+// cache and the entry points.  The launch sequences live in pnn_passes.cpp, model building in pnn_model.cpp, tile rules
+// in pnn_tiles.cpp, the autotuner in pnn_tuner.cpp (shared types: pnn_ctx.h).
 //
 // Reference behaviour reproduced here (not code): TComPrediction::initTempBuff (model selection,
 // hm_16_15_substitution/source/Lib/TLibCommon/TComPrediction.cpp:108-178), load_graphs
-// (hevc/hm_common/c++/source_common/integration_prediction_neural_network.cpp:29-69), the graph of
-// pnn/components.py:10-261, and predict_by_batch_via_pnn (pnn/batching.py:7-88).
-#include "../../include/pnn_hip.h"
-#include "pnn_kernels.h"
-#include "pnn_host.h"
+// (hevc/hm_common/c++/source_common/integration_prediction_neural_network.cpp:29-69) and predict_by_batch_via_pnn
+// (pnn/batching.py:7-88).
+#include "pnn_ctx.h"
 
 #include <algorithm>
 #include <cmath>
@@ -15,131 +14,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <string>
-#include <thread>
-#include <vector>
 
 using namespace pnn;
 
 namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
 namespace { thread_local std::string g_create_error; }
-namespace pnn { void set_create_error(const std::string& msg) { g_create_error = msg; } }
+namespace pnn {
 
-namespace {
+void set_create_error(const std::string& msg) { g_create_error = msg; }
 
-constexpr int kHidden = 1200;                         // pnn/components.py:130-160
-// The output layer of an FC net with <= 64 outputs is summed in K segments of 10 chunks (160 hidden units) whose partial
-// sums are then added in ascending order (fuse_reduce_kernel): the order the ring kernel's fused output layer produces
-// with its 128 x 160 tile, and the order tapgemm_small_kernel's K-segment mode reproduces at any batch size.
-constexpr int kFuseSegChunks = 10;
-int strides_for(int w, int* st)                       // pnn/PredictionNeuralNetwork.py:126-132
-{
-    switch (w) {
-    case 4: st[0] = 1; st[1] = 1; return 2;
-    case 8: st[0] = 2; st[1] = 1; return 2;
-    case 16: st[0] = 2; st[1] = 1; st[2] = 2; st[3] = 1; return 4;
-    case 32: st[0] = 2; st[1] = 2; st[2] = 1; st[3] = 2; st[4] = 1; return 5;
-    case 64: st[0] = 2; st[1] = 2; st[2] = 2; st[3] = 2; st[4] = 1; return 5;
-    default: return -1;
-    }
-}
-
-int width_index(int w)                                // TComPrediction.cpp:564: log2(w) - 2
-{
-    switch (w) { case 4: return 0; case 8: return 1; case 16: return 2; case 32: return 3; case 64: return 4; default: return -1; }
-}
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
-struct GemmLayer {                                    // one tap-GEMM launch (all classes)
-    TapGemmParams proto{};
-    float* d_w = nullptr;
-    float* d_w_sp = nullptr;                          // split-precision pack: f16 hi/lo, pre-scaled by 2^sp_shift
-    float sp_inv_scale = 1.f;
-    float* d_bias = nullptr;
-    double k_total = 0;                               // sum over classes of taps * Cin
-    long out_per_block = 0;                           // output floats per block
-};
-struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_bias = nullptr; long out_per_block = 0; };
-struct TConv1Layer { TConv1Params proto{}; float* d_w = nullptr; };
-struct MergerLayer { MergerParams proto{}; float* d_w = nullptr; float* d_bias = nullptr; };
-
-struct Model {
-    int width = 0;
-    bool is_fc = false;
-    long n_params = 0;
-    int n_layers = 0;
-    std::vector<GemmLayer> fc;                        // 4 layers
-    Conv1Layer first[2];                              // branch_above / branch_left conv 0
-    std::vector<GemmLayer> branch[2];                 // conv 1..L-1
-    MergerLayer merger;
-    std::vector<GemmLayer> tconv;                     // tconv 0..L-2
-    TConv1Layer last;
-    int C = 0;                                        // channels at the merger
-    long pmax = 0;                                    // largest intermediate activation (floats / block)
-    std::vector<void*> allocs;
-};
-
-}  // namespace
-
-struct pnn_ctx {
-    int device = 0;
-    float mean = 0.f;
-    hipStream_t stream = nullptr;
-    Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
-    // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
-    // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
-    long opt_split_min_px = -1;                       // tuning aid: conv passes take the split-precision kernels from this many block pixels on (-1: built-in rule)
-    long opt_branch_streams = 1;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf stage_in[2], stage_out[2], stage_tbs;
-    // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
-    // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.
-    struct CacheEntry { uint64_t hash = 0; bool valid = false; std::vector<float> in, out; std::vector<int32_t> pel; };
-    std::vector<CacheEntry> cache[5];
-    long opt_cache_mb = 0;                            // 0 = off
-    long cache_hits = 0, cache_misses = 0;
-    char* h_pin = nullptr;                            // pinned, device-visible staging of the single-block host calls (zero-copy)
-    void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
-    long opt_tile_cfg = -1;
-    long opt_max_chunk = 0;
-    // 1 (default): one per-output summation order at every batch size -- a block's prediction does not depend on the batch
-    // it travels in (encoder behind the batching service, decoder alone: no drift).  0: small passes may take the exact-f32
-    // split-K kernels (a few us faster per single-block call; last float bits can differ from the batched result).
-    long opt_canonical = 1;
-    long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
-    long opt_sp_cfg = -1;
-    long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
-    long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
-    long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
-    long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
-    long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
-    long opt_pair = 1;                                // 1: small conv passes run the same layer of both branches as ONE launch
-    long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
-    long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
-    std::map<std::pair<const void*, long>, int> tuned;
-    long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
-    struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
-    std::vector<LaunchRec> launch_recs;
-    // Range guard of the split-precision path (pnn_device_common.h): kernels raise *h_range (pinned host memory) when a
-    // split-f16 activation leaves the f16 range.  Host entry points then repeat the pass on the exact-f32 kernels; device
-    // entry points report PNN_E_RANGE at the next call / pnn_check_range.
-    int* h_range = nullptr;
-    long range_fallbacks = 0;
-    const float* host_input = nullptr;                // host_predict: the caller's f32 input rows (FC nets), valid during the call
-    size_t ws_cap_bytes = (size_t)8 << 30;
-    std::string err;
-    int stat_gemm_launches = 0, stat_launches = 0;
-    double stat_gemm_flops = 0;
-};
-
-namespace {
 
 int fail(pnn_ctx* c, int code, const char* fmt, ...)
 {
@@ -152,16 +35,18 @@ int fail(pnn_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
-#define HIPCHK(c, expr)                                                                             \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) return fail((c), PNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+}  // namespace pnn
+
+namespace {
 
 void cache_clear(pnn_ctx* c)
 {
     for (auto& t : c->cache) { t.clear(); t.shrink_to_fit(); }
 }
+
+}  // namespace
+
+namespace pnn {
 
 int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
 {
@@ -174,791 +59,9 @@ int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
     return PNN_OK;
 }
 
-int upload(pnn_ctx* c, Model* m, const float* host, size_t n, float** out)
-{
-    void* d = nullptr;
-    if (hipMalloc(&d, std::max(n, (size_t)4) * sizeof(float)) != hipSuccess)
-        return fail(c, PNN_E_NOMEM, "hipMalloc of %zu weight floats failed", n);
-    m->allocs.push_back(d);
-    HIPCHK(c, hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
-    *out = (float*)d;
-    return PNN_OK;
-}
+}  // namespace pnn
 
-// Weight packing runs once per model load, but a process of the reference's kind (one HM encoder or decoder) loads five
-// models at start-up: 27 M parameters, each written into two strided layouts.  The chunks are independent: a few threads.
-template <typename F>
-void parallel_chunks(long nchunks, F fn)
-{
-    const long work = nchunks;
-    int nt = (int)std::min<long>(8, std::max<long>(1, work / 64));
-    nt = std::min<int>(nt, (int)std::max(1u, std::thread::hardware_concurrency()));
-    if (nt <= 1) { fn(0, nchunks); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back([=] { fn(nchunks * t / nt, nchunks * (t + 1) / nt); });
-    for (auto& x : th) x.join();
-}
-
-// [K][N] row-major -> [K/16][4][Npad][4] (k = 16*chunk + 4*q + e), zero-padded columns.
-std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad)
-{
-    std::vector<float> out((size_t)K * npad, 0.f);
-    parallel_chunks(K / 16, [&](long c0, long c1) {
-        for (long k = 16 * c0; k < 16 * c1; k++) {
-            const long ch = k >> 4; const int q = (k >> 2) & 3, e = k & 3;
-            float* dst = out.data() + (((size_t)ch * 4 + q) * npad) * 4 + e;
-            const float* src = kn.data() + (size_t)k * N;
-            for (int n = 0; n < N; n++) dst[(size_t)n * 4] = src[n];
-        }
-    });
-    return out;
-}
-
-// Split-precision pack: [K/16][hl = hi/lo][h = k-half][Npad][8 x f16] with w * scale = hi + lo.
-std::vector<float> pack_kn_split(const std::vector<float>& kn, long K, int N, int npad, float scale)
-{
-    std::vector<float> out((size_t)K * npad, 0.f);              // same byte count as the f32 pack
-    _Float16* o = reinterpret_cast<_Float16*>(out.data());
-    parallel_chunks(K / 16, [&](long c0, long c1) {
-        for (long k = 16 * c0; k < 16 * c1; k++) {
-            const long ch = k >> 4; const int h = (k >> 3) & 1, j = k & 7;
-            const float* src = kn.data() + (size_t)k * N;
-            for (int n = 0; n < N; n++) {
-                const float w = src[n] * scale;
-                const _Float16 hi = (_Float16)w;
-                const _Float16 lo = (_Float16)(w - (float)hi);
-                o[((((size_t)ch * 2 + 0) * 2 + h) * npad + n) * 8 + j] = hi;
-                o[((((size_t)ch * 2 + 1) * 2 + h) * npad + n) * 8 + j] = lo;
-            }
-        }
-    });
-    return out;
-}
-
-int npad_for(int cout) { return ((cout + 15) / 16) * 16 + 160; }   // slack >= the widest column tile (BN = 160)
-
-// Common tail of the three layer builders. `kn` holds the [K][Cout] rows ordered (class, tap, ci) and
-// p.tap_begin / p.Cin / p.ncls are set. Every class is zero-padded to a multiple of kChunkPad 16-deep
-// chunks (so that any pipeline stage depth KC <= kChunkPad reads whole stages), packed and uploaded.
-int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const float* b, int Cout, GemmLayer* L)
-{
-    TapGemmParams& p = L->proto;
-    const int cpt = p.Cin / 16;
-    std::vector<float> padded;
-    long chunk = 0;
-    double k_real = 0;
-    for (int cls = 0; cls < p.ncls; cls++) {
-        p.chunk_begin[cls] = (int)chunk;
-        const long rows = (long)(p.tap_begin[cls + 1] - p.tap_begin[cls]) * p.Cin;
-        const long nch = rows / 16, nch_pad = ((nch + kChunkPad - 1) / kChunkPad) * kChunkPad;
-        const float* src = kn.data() + (size_t)p.tap_begin[cls] * p.Cin * Cout;
-        padded.insert(padded.end(), src, src + (size_t)rows * Cout);
-        padded.resize(padded.size() + (size_t)(nch_pad - nch) * 16 * Cout, 0.f);
-        chunk += nch_pad;
-        k_real += (double)rows;
-    }
-    p.chunk_begin[p.ncls] = (int)chunk;
-    (void)cpt;
-    const int npad = npad_for(Cout);
-    std::vector<float> packed = pack_kn(padded, chunk * 16, Cout, npad);
-    int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
-    if (rc) return rc;
-    {   // split-precision copy: scale so that max |w| lands in [2^12, 2^13) (hi and lo halves both f16-normal)
-        float wmax = 0.f;
-        for (float v : padded) wmax = std::max(wmax, std::fabs(v));
-        int shift = 0;
-        if (wmax > 0.f) { int e; std::frexp(wmax, &e); shift = 13 - e; }
-        shift = std::max(-8, std::min(shift, 24));
-        const float scale = std::ldexp(1.f, shift);
-        L->sp_inv_scale = std::ldexp(1.f, -shift);
-        std::vector<float> sp = pack_kn_split(padded, chunk * 16, Cout, npad, scale);
-        rc = upload(c, m, sp.data(), sp.size(), &L->d_w_sp);
-        if (rc) return rc;
-    }
-    std::vector<float> bias(((Cout + 3) / 4) * 4 + 4, 0.f);
-    std::copy(b, b + Cout, bias.begin());
-    rc = upload(c, m, bias.data(), bias.size(), &L->d_bias);
-    if (rc) return rc;
-    p.Cout = Cout; p.Npad = npad;
-    L->k_total = k_real;
-    return PNN_OK;
-}
-
-// Fully-connected layer as a one-tap GEMM (pnn/components.py:169-176).
-int build_fc_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int K, int N, int act, GemmLayer* L)
-{
-    if (K % 16) return fail(c, PNN_E_MODEL, "FC input size %d is not a multiple of 16", K);
-    std::vector<float> kn(W, W + (size_t)K * N);
-    TapGemmParams& p = L->proto;
-    p.SH = p.SW = p.IH = p.IW = p.OH = p.OW = 1;
-    p.a = 1; p.os = 1; p.Cin = K; p.act = act;
-    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = 1; p.py[0] = p.px[0] = 0; p.tap[0] = pack_tap(0, 0);
-    L->out_per_block = N;
-    return finish_gemm_layer(c, m, kn, b, N, L);
-}
-
-// Forward convolution (pnn/tfutils.py:75-139). W is [k][k][Cin][Cout].
-int build_conv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int IH, int IW, int Cin, int Cout, int s,
-                     GemmLayer* L)
-{
-    const int k = 2 * s + 1, OH = (IH + s - 1) / s, OW = (IW + s - 1) / s;
-    const int pad = std::max((OH - 1) * s + k - IH, 0) / 2;
-    if (Cin % 16 || Cout % 4) return fail(c, PNN_E_MODEL, "conv layer %d->%d not MFMA-tileable", Cin, Cout);
-    const long K = (long)k * k * Cin;
-    std::vector<float> kn(W, W + (size_t)K * Cout);
-    TapGemmParams& p = L->proto;
-    p.SH = OH; p.SW = OW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = s;
-    p.OH = OH; p.OW = OW; p.os = 1; p.act = 1;
-    p.ncls = 1; p.tap_begin[0] = 0; p.tap_begin[1] = k * k; p.py[0] = p.px[0] = 0;
-    for (int ky = 0; ky < k; ky++)
-        for (int kx = 0; kx < k; kx++) p.tap[ky * k + kx] = pack_tap(ky - pad, kx - pad);
-    L->out_per_block = (long)OH * OW * Cout;
-    return finish_gemm_layer(c, m, kn, b, Cout, L);
-}
-
-// Transposed convolution with Cout >= 4 (Appendix B.3; pnn/tfutils.py:395-462). W is [k][k][Cout][Cin].
-// Gather form: y[oy] takes x[iy] through tap ky iff iy*s + ky - pad == oy (pad = 1 for s = 1, 2).
-int build_tconv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int IH, int IW, int Cin, int Cout, int s,
-                      int act, GemmLayer* L)
-{
-    const int k = 2 * s + 1, OH = IH * s, OW = IW * s;
-    const int pad = std::max((IH - 1) * s + k - OH, 0) / 2;
-    if (Cin % 16 || Cout % 4 || (s != 1 && s != 2)) return fail(c, PNN_E_MODEL, "tconv layer %d->%d not tileable", Cin, Cout);
-    TapGemmParams& p = L->proto;
-    std::vector<float> kn;                           // rows ordered (class, tap, ci)
-    int ntap = 0;
-    p.ncls = s * s;
-    for (int py = 0; py < s; py++)
-        for (int px = 0; px < s; px++) {
-            const int cls = py * s + px;
-            p.tap_begin[cls] = ntap; p.py[cls] = py; p.px[cls] = px;
-            for (int ky = 0; ky < k; ky++) {
-                if ((py + pad - ky) % s) continue;   // C++ % keeps the sign; parity test is sign-safe
-                for (int kx = 0; kx < k; kx++) {
-                    if ((px + pad - kx) % s) continue;
-                    p.tap[ntap] = pack_tap((py + pad - ky) / s, (px + pad - kx) / s);
-                    const float* wt = W + (size_t)(ky * k + kx) * Cout * Cin;
-                    for (int ci = 0; ci < Cin; ci++)
-                        for (int co = 0; co < Cout; co++) kn.push_back(wt[(size_t)co * Cin + ci]);
-                    ntap++;
-                }
-            }
-        }
-    p.tap_begin[p.ncls] = ntap;
-    p.SH = IH; p.SW = IW; p.IH = IH; p.IW = IW; p.Cin = Cin; p.a = 1;
-    p.OH = OH; p.OW = OW; p.os = s; p.act = act;
-    L->out_per_block = (long)OH * OW * Cout;
-    return finish_gemm_layer(c, m, kn, b, Cout, L);
-}
-
-void free_model(Model* m)
-{
-    if (!m) return;
-    for (void* p : m->allocs) (void)hipFree(p);
-    delete m;
-}
-
-int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n, Model** out)
-{
-    Model* m = new Model();
-    m->width = width; m->is_fc = is_fc != 0; m->n_params = (long)n;
-    const float* p = params;
-    const float* end = params + n;
-    int rc = PNN_OK;
-    auto need = [&](size_t k) { return (size_t)(end - p) >= k; };
-    if (is_fc) {
-        if (width != 4 && width != 8 && width != 16) { free_model(m); return fail(c, PNN_E_MODEL, "no FC architecture for width %d", width); }
-        const int dims[5] = {5 * width * width, kHidden, kHidden, kHidden, width * width};
-        m->fc.resize(4);
-        for (int i = 0; i < 4 && rc == PNN_OK; i++) {
-            const size_t nw = (size_t)dims[i] * dims[i + 1];
-            if (!need(nw + dims[i + 1])) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
-            rc = build_fc_layer(c, m, p, p + nw, dims[i], dims[i + 1], i < 3, &m->fc[i]);
-            p += nw + dims[i + 1];
-        }
-        m->n_layers = 4;
-        m->pmax = kHidden;
-    } else {
-        int st[8];
-        const int L = strides_for(width, st);
-        if (L < 0) { free_model(m); return fail(c, PNN_E_MODEL, "no convolutional architecture for width %d", width); }
-        int C = 32;
-        for (int br = 0; br < 2 && rc == PNN_OK; br++) {
-            int H = br == 0 ? width : 2 * width, Wd = br == 0 ? 3 * width : width, cin = 1, ch = 32;
-            for (int i = 0; i < L && rc == PNN_OK; i++) {
-                const int s = st[i], k = 2 * s + 1;
-                ch *= s;
-                const size_t nw = (size_t)k * k * cin * ch;
-                if (!need(nw + ch)) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
-                const int OH = (H + s - 1) / s, OW = (Wd + s - 1) / s;
-                if (i == 0) {
-                    Conv1Layer& f = m->first[br];
-                    rc = upload(c, m, p, nw, &f.d_w);
-                    if (rc == PNN_OK) {
-                        std::vector<float> bias(ch + 4, 0.f);
-                        std::copy(p + nw, p + nw + ch, bias.begin());
-                        rc = upload(c, m, bias.data(), bias.size(), &f.d_bias);
-                    }
-                    f.proto.IH = H; f.proto.IW = Wd; f.proto.s = s; f.proto.k = k;
-                    f.proto.pad = std::max((OH - 1) * s + k - H, 0) / 2;
-                    f.proto.OH = OH; f.proto.OW = OW; f.proto.Cout = ch;
-                    f.out_per_block = (long)OH * OW * ch;
-                    m->pmax = std::max(m->pmax, f.out_per_block);
-                } else {
-                    m->branch[br].emplace_back();
-                    rc = build_conv_layer(c, m, p, p + nw, H, Wd, cin, ch, s, &m->branch[br].back());
-                    if (rc == PNN_OK) m->pmax = std::max(m->pmax, m->branch[br].back().out_per_block);
-                }
-                p += nw + ch;
-                H = OH; Wd = OW; cin = ch;
-            }
-            if (rc == PNN_OK && ((br == 0 && (H != 4 || Wd != 12)) || (br == 1 && (H != 8 || Wd != 4))))
-                rc = fail(c, PNN_E_MODEL, "branch output is %dx%d, expected 4x12 / 8x4", H, Wd);
-            C = ch;
-        }
-        m->C = C;
-        if (rc == PNN_OK) {                          // channel-wise FC merger: Wm [C][80][16] -> [80][16][C]
-            const size_t nw = (size_t)C * 80 * 16, nb = (size_t)C * 16;
-            if (!need(nw + nb)) rc = fail(c, PNN_E_MODEL, "parameter buffer too short");
-            else {
-                std::vector<float> wp(nw), bp(nb);
-                for (int ch = 0; ch < C; ch++)
-                    for (int pp = 0; pp < 80; pp++)
-                        for (int j = 0; j < 16; j++) wp[((size_t)pp * 16 + j) * C + ch] = p[((size_t)ch * 80 + pp) * 16 + j];
-                for (int ch = 0; ch < C; ch++)
-                    for (int j = 0; j < 16; j++) bp[(size_t)j * C + ch] = p[nw + (size_t)ch * 16 + j];
-                rc = upload(c, m, wp.data(), nw, &m->merger.d_w);
-                if (rc == PNN_OK) rc = upload(c, m, bp.data(), nb, &m->merger.d_bias);
-                m->merger.proto.C = C; m->merger.proto.na = 48; m->merger.proto.nl = 32; m->merger.proto.nout = 16;
-                p += nw + nb;
-                m->pmax = std::max(m->pmax, (long)16 * C);
-            }
-        }
-        int H = 4, ci = C;
-        for (int i = 0; i < L && rc == PNN_OK; i++) { // merger transposed convolutions, reversed strides
-            const int s = st[L - 1 - i], k = 2 * s + 1;
-            const bool last = i == L - 1;
-            const int co = last ? 1 : ci / s;
-            const size_t nw = (size_t)k * k * co * ci;
-            if (!need(nw + co)) { rc = fail(c, PNN_E_MODEL, "parameter buffer too short"); break; }
-            if (last) {
-                rc = upload(c, m, p, nw, &m->last.d_w);   // [k][k][1][Cin] == [k][k][Cin]
-                m->last.proto.IH = H; m->last.proto.IW = H; m->last.proto.Cin = ci; m->last.proto.s = s; m->last.proto.k = k;
-                m->last.proto.pad = std::max((H - 1) * s + k - H * s, 0) / 2;
-                m->last.proto.bias = p[nw];
-            } else {
-                m->tconv.emplace_back();
-                rc = build_tconv_layer(c, m, p, p + nw, H, H, ci, co, s, 1, &m->tconv.back());
-                if (rc == PNN_OK) m->pmax = std::max(m->pmax, m->tconv.back().out_per_block);
-            }
-            p += nw + co;
-            H *= s; ci = co;
-        }
-        if (rc == PNN_OK && H != width) rc = fail(c, PNN_E_MODEL, "merger output width %d != %d", H, width);
-        m->n_layers = 3 * L + 1;
-    }
-    if (rc == PNN_OK && p != end) rc = fail(c, PNN_E_MODEL, "%zu parameters given, architecture needs %zu", n, (size_t)(p - params));
-    if (rc != PNN_OK) { free_model(m); return rc; }
-    *out = m;
-    return PNN_OK;
-}
-
-// Tile / pipeline choice. Rules distilled from on-device sweeps over every kernel configuration
-// (tools_cfg_sweep.sh; all shapes of the FC-8 and conv-16 nets): once the grid fills the chip every
-// reasonable tile lands within ~3 % (the f32 matrix pipes run at ~1.9 GHz under this load and are
-// ~82 % busy), so the choice only has to (a) avoid column padding, (b) keep >= 2-3 workgroups per CU,
-// and (c) switch to the split-K kernel when M is too small to fill 256 CUs with 64-row tiles.
-int find_cfg(int rt, int nt, int kc, int mf)
-{
-    for (int i = 0; i < tapgemm_num_cfgs(); i++) {
-        const TileCfg t = tapgemm_cfg(i);
-        if (t.rt == rt && t.nt == nt && t.kc == kc && t.mf == mf) return i;
-    }
-    return -1;
-}
-
-int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
-{
-    if (c->opt_tile_cfg >= 0 && c->opt_tile_cfg < tapgemm_num_cfgs()) return (int)c->opt_tile_cfg;
-    const int cpt = cin / 16;
-    const bool one_tap = (k_total == (double)cin);
-    const int kc = (one_tap || cpt % 2 == 0) ? 2 : 1;             // a stage must not straddle two taps
-    int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : ((cout % 128 == 0 && M >= 32768) ? 8 : 4));
-    const long wgs_std = ((M + 63) / 64) * ((cout + 16L * nt - 1) / (16L * nt)) * ncls;
-    if (wgs_std < 192 && !c->opt_canonical) {                     // small M: four waves split K instead
-        int nts = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
-        while (nts > 1 && ((M + 15) / 16) * ((cout + 16L * nts - 1) / (16L * nts)) * ncls < 128) nts >>= 1;
-        const int i = find_cfg(0, nts, 1, 16);
-        if (i >= 0) return i;
-    }
-    int i = find_cfg(1, nt, kc, 16);
-    if (i < 0) i = find_cfg(1, nt, 1, 16);
-    return i < 0 ? 0 : i;
-}
-
-int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s)
-{
-    TapGemmParams p = L.proto;
-    p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
-    const long M = nblocks * p.SH * p.SW;
-    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
-    p.M = (int)M;
-    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
-    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation tensor of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
-    p.x_bytes = (unsigned)xb;
-    const int cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
-    static const bool debug = getenv("PNN_DEBUG") != nullptr;
-    if (debug) {
-        const TileCfg t = tapgemm_cfg(cfg);
-        fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls,
-                cfg, t.rt, t.nt, t.kc);
-    }
-    static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch timing, synchronous
-    if (profile || c->opt_time_launches) {
-        pnn_ctx::LaunchRec r;
-        HIPCHK(c, hipEventCreate(&r.e0));
-        HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = tapgemm_cfg(cfg).rt == 0 ? 1 : 0;
-        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
-        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
-        g_launch_events = &ev;
-        const hipError_t le = launch_tapgemm(p, cfg, s);
-        g_launch_events = nullptr;
-        HIPCHK(c, le);
-        if (profile) {
-            HIPCHK(c, hipEventSynchronize(r.e1));
-            float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
-            const TileCfg t = tapgemm_cfg(cfg);
-            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
-                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
-            (void)hipEventDestroy(r.e0);
-            (void)hipEventDestroy(r.e1);
-        } else {
-            c->launch_recs.push_back(r);
-        }
-    } else {
-        HIPCHK(c, launch_tapgemm(p, cfg, s));
-    }
-    c->stat_gemm_launches++; c->stat_launches++;
-    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
-    return PNN_OK;
-}
-
-// convimg_sp_kernel: how many images one workgroup of tile `t` stages for this layer (0 = tile cannot run the layer).
-static int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap)
-{
-    if (one_tap || (p.Cin / 16) % t.kc) return 0;
-    const int rows = 32 * t.rt * t.wm, sp = p.SH * p.SW;
-    int g = rows / sp;
-    while (g > 0 && convimg_sp_lds_bytes(p, t, g) > (size_t)156 * 1024) --g;
-    return g;
-}
-
-// Rule-based choice among the convimg tiles: fewest idle rows and columns, then the larger wave tile.  -1 = none fits.
-// (A cost model with workgroup counts and residency was tried against the autotuner's per-configuration timings of
-// the conv-16/32 layers and picked WORSE tiles overall -- 0.58 vs 0.54 ms per conv-16 pass; the three kernel families
-// are within 10-15 % of each other on most layers, so big passes are simply autotuned, see run_gemm_sp.)
-// Mid-size passes (tens of blocks: the batching service, small pictures) do not fill the chip with the big tiles: below two
-// workgroups per CU the cost grows with the idle share, which takes the choice down to the 64-row tile where the tuner
-// ends up too (16x16 net, 100 blocks: 471 -> ~300 us per pass).
-static int choose_cfg_convimg(const TapGemmParams& p, bool one_tap)
-{
-    int best = -1;
-    double best_cost = 1e300, best_fit = 1e300;
-    const long nimg = p.M / (p.SH * p.SW);
-    for (int i = 0; i < convimg_sp_num_cfgs(); i++) {
-        const TileCfg t = convimg_sp_cfg(i);
-        const int g = convimg_images(p, t, one_tap);
-        if (g <= 0) continue;
-        const long rows = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
-        const long tn = (p.Cout + bn - 1) / bn;
-        const double pad = (double)rows * (tn * bn) / ((double)g * p.SH * p.SW * p.Cout);
-        // tile height: 128 rows is the sweet spot (tuner logs of the 8x8 / 16x16 nets, K = 576, 64 output channels): taller
-        // tiles stage more images per workgroup -- more LDS, fewer co-resident workgroups, a longer serial staging phase
-        // (384 rows: 81 us where 128 rows take 49) --, the 64-row tile pays more start-up per MFMA
-        double height = rows <= 64 ? 1.15 : rows <= 128 ? 1.0 : rows <= 192 ? 1.05 : rows <= 256 ? 1.25 : rows <= 384 ? 1.6 : 2.0;
-        // 32-channel layers (4x4 conv net: K = 288, maps of 16-48 pixels): little work per image, so the tuner settles on EIGHT
-        // images per workgroup whatever the map size (384 / 256 / 128 rows for 48 / 32 / 16 pixels) -- the weight stream and the
-        // start-up are then shared by enough matrix work
-        if (p.Cout <= 32) height = 1.0 + 0.3 * std::fabs(std::log2((double)rows / (8.0 * p.SH * p.SW)));
-        const double wgs = (double)((nimg + g - 1) / g) * tn * p.ncls;
-        const double fill = wgs >= 512.0 ? 1.0 : 512.0 / wgs;
-        const double cost = pad * height * fill;
-        // what decides whether the family is used at all: idle rows / columns and an unsuitable height -- for the 32-channel
-        // layers the padding alone (their preferred height depends on the batch through `fill`)
-        if (cost < best_cost) { best_cost = cost; best_fit = p.Cout <= 32 ? pad : pad * height; best = i; }
-    }
-    // 32-channel layers (the 4x4 conv net) fill only half of the narrowest tile's 64 columns and still run 30 % faster here than
-    // on the register-staged kernel (tuner, batch 4096: 29.6 / 21.7 / 11.0 us for its three layers against a 120 vs 91 us pass)
-    return best_fit <= (p.Cout <= 32 ? 3.0 : 1.6) ? best : -1;
-}
-
-// Rule-based choice among the ring-kernel tiles for big one-tap (fully-connected) layers, -1 = leave it to the other
-// kernels.  Calibrated with tools/ring_prof.hip: a workgroup costs ~(prologue + epilogue) + stages x 1.45 x its MFMA
-// cycles (loader and MFMA waves overlap imperfectly), workgroups run one (LDS > 80 KB) or two per CU.
-static bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total)
-{
-    return (p.ncls == 1 || p.ncls == 4) && p.Cout == 64 && k_total / p.ncls >= 512.0 && M / ((long)p.SH * p.SW) < 128 && (M + 63) / 64 * p.ncls >= 128;
-}
-
-static int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false)
-{
-    if (!fused && !one_tap) {
-        // Convolution layers.  With the buffer-descriptor loaders the ring kernel is the fastest of the three families on
-        // every layer with >= 128 output channels (tuner logs of the 16x16 / 32x32 nets at 300 ... 1024 blocks: 15-30 % ahead
-        // of the register-staged and the LDS-resident-image kernels); the 64-output-channel 3x3 layers stay with the
-        // LDS-resident-image kernel.  Tile: 128 columns, the tallest of 192 / 128 / 64 rows that still gives >= 192
-        // workgroups (one round of the chip), else 64 rows.  Under-filled long-K layers of any width take the 64-row tile.
-        const bool wide = p.Cout % 128 == 0 && k_total / p.ncls >= 1152.0;
-        const double col_tiles = (double)((p.Cout + 127) / 128) * p.ncls;
-        const bool underfilled = k_total >= 1600.0 && (double)((M + 63) / 64) * col_tiles <= 256.0;
-        // stride-2 transposed convolutions to 64 channels (four output-parity classes of 4-9 taps each: short K per class, the
-        // classes as blockIdx.z): from 8192 rows on the tuner takes the 128 x 64 ring tile over the LDS-resident-image kernel
-        // at every batch looked at (16x16 / 32x32 nets, 512 ... 1024 / 128 ... 256 blocks: 26-28 us against 39 at M = 16384)
-        if (p.ncls == 4 && p.Cout == 64 && M >= 8192) {
-            for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
-                const TileCfg t = tapgemm_ring_cfg(i);
-                if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 4 && t.d == 4) return i;
-            }
-        }
-        // 64-channel 3x3 layers of a FEW images (under 128: the image kernel gets one workgroup per image or less and leaves most
-        // of the chip idle) but enough rows for >= 128 tiles of 64 rows: the 64 x 128 ring tile, half its columns empty, is what
-        // the tuner takes (16x16 net, 64 blocks: 17.9 us against 28)
-        const bool few_images = pnn_ring_few_images(p, M, k_total);
-        if (!wide && !underfilled && !few_images) return -1;
-        int rt = 1, wm = 2, d = 4;                    // 64 x 128
-        if (wide) {
-            if ((double)((M + 191) / 192) * col_tiles >= 192.0) { rt = 3; d = 3; }        // 192 x 128
-            else if ((double)((M + 127) / 128) * col_tiles >= 192.0) rt = 2;              // 128 x 128
-        }
-        for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
-            const TileCfg t = tapgemm_ring_cfg(i);
-            if (t.rt == rt && t.nt == 2 && t.kc == 2 && t.wm == wm && t.d == d) return i;
-        }
-        return -1;
-    }
-    if (!fused && ((double)M * p.Cout < 5.0e5 || p.Cin < 64)) return -1;   // FC layers from ~512 rows on (tuner logs: ring 64x128 / 128x64 tiles win there too)
-    int best = -1;
-    double best_cost = 1e300;
-    for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
-        const TileCfg t = tapgemm_ring_cfg(i);
-        if (fused && !tapgemm_ring_can_fuse(i)) continue;
-        if (!one_tap && (p.Cin / 16) % t.kc) continue;
-        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
-        const long nwg = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
-        const int resident = tapgemm_ring_lds_bytes(t) > (size_t)80 * 1024 ? 1 : 2;
-        const double stages = std::ceil((k_total / 16.0 / p.ncls) / (double)t.kc);
-        const double mfma = 96.0 * t.rt * t.nt * t.kc;
-        // stage time / MFMA time and the fixed part, from tools/ring_prof.hip with the buffer-descriptor loaders (FC 1200x1200,
-        // M = 4096): D >= 4 rings 1.14-1.19, three-deep rings 1.5-1.9, 16-deep stages 1.3; start-up + epilogue 7-13k cycles
-        const double slow = t.kc == 1 ? 1.35 : (resident == 2 ? 1.25 : (t.d >= 4 ? 1.17 : 1.6));
-        const double wg = 5000.0 + 1400.0 * t.rt * t.nt + stages * mfma * slow;
-        const double rounds = std::ceil(nwg / (256.0 * resident));
-        double cost = rounds * wg * (resident == 2 ? 1.6 : 1.0);         // two co-resident workgroups share the CU's MFMA pipes
-        cost *= 1.0 + 0.05 * (1.0 - nwg / (256.0 * resident * rounds));   // ties: the tile that leaves fewer CUs idle (M = 1024: 64 x 128 over 128 x 64, as the tuner)
-        if (cost < best_cost) { best_cost = cost; best = i; }
-    }
-    return best;
-}
-
-// Split-precision launch (3 x f16 MFMA): activations as two f16 planes, outputs f32 and/or two f16 planes.
-int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
-{
-    const int cpt = cin / 16;
-    const bool one_tap = (k_total == (double)cin);
-    if (c->opt_sp_cfg >= 0 && c->opt_sp_cfg < tapgemm_sp_num_cfgs()) {
-        const TileCfg t = tapgemm_sp_cfg((int)c->opt_sp_cfg);
-        if (one_tap || cpt % t.kc == 0) return (int)c->opt_sp_cfg;
-    }
-    int best = -1;
-    double best_cost = 1e300;
-    for (int i = 0; i < tapgemm_sp_num_cfgs(); i++) {
-        const TileCfg t = tapgemm_sp_cfg(i);
-        if (!one_tap && cpt % t.kc) continue;
-        const long bm = 32L * t.rt * t.wm, bn = 32L * t.nt * (4 / t.wm);
-        const long tm = (M + bm - 1) / bm, tn = (cout + bn - 1) / bn;
-        const double wgs = (double)tm * tn * ncls;
-        // calibrated on device sweeps (tools/sp_check.py, tools/sp_prof.py): time ~ padded work x (1 + 2/NT) (operand
-        // traffic per MFMA), mild tail quantisation, RT = 2 and KC = 4 lose a resident workgroup, KC = 1 adds barriers
-        const double per_cu = wgs / 256.0;
-        // under-filled chip: idle CUs below one workgroup per CU, no co-resident workgroup below ~1.5
-        const double fill = per_cu < 1.0 ? 1.2 * std::pow(1.0 / per_cu, 0.7) : 1.0 + 0.4 * std::max(0.0, 1.5 - per_cu);
-        const double pad = (double)(tm * bm) * (tn * bn) / ((double)M * cout);
-        const double reuse = 1.0 + 2.0 / (t.nt * (4 / t.wm));
-        const double shape = (t.rt * t.wm >= 8 ? 1.15 : 1.0) * (t.kc == 4 ? 1.4 : (t.kc == 1 ? 1.08 : 1.0));
-        const double cost = fill * pad * reuse * shape;
-        if (cost < best_cost) { best_cost = cost; best = i; }
-    }
-    return best < 0 ? 0 : best;
-}
-
-// `next` (optional): a following fully-connected layer with <= 64 outputs that the ring kernel applies to its output tile
-// in LDS; `part` then receives the per-column-tile partial products [tiles][M][64] and *tiles_out their count (the caller
-// finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
-int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
-                long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
-                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0)
-{
-    // x_is_f32: Xhi holds plain f32 rows (an FC net's input as the caller handed it over); only the small-M kernel takes
-    // that (it splits in registers), any other choice gets split_kernel launched in front (into ws[2]).
-    // seg_chunks > 0: K-segment mode of an FC output layer (small-M kernel only): raw partials to `part`, see fc_pass.
-    // `first` (optional): the Cin = 1 convolution that produces this layer's input Xhi.  It has NOT been launched: a
-    // convimg configuration computes it inside the kernel (no 50 MB round trip of the maps), any other configuration gets
-    // it launched here in front of the GEMM.
-    TapGemmParams p = L.proto;
-    if (next) {
-        p.W2p = next->d_w_sp; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part;
-    }
-    p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp;
-    static const bool diag = getenv("PNN_SP_DIAG") != nullptr;   // diagnostic library only: phase stamps of every workgroup
-    if (diag) {
-        if (dev_reserve(c, c->stage_tbs, (size_t)64 << 20)) return PNN_E_NOMEM;
-        p.Xlo = c->stage_tbs.p;
-    } p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
-    p.mean = c->mean; p.out_scale = L.sp_inv_scale; p.range_flag = c->h_range;
-    const long M = nblocks * p.SH * p.SW;
-    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
-    p.M = (int)M;
-    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
-    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation plane of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
-    p.x_bytes = (unsigned)xb;
-    const int cpt = p.Cin / 16;
-    const bool one_tap = (L.k_total == (double)p.Cin);
-    static const bool diag0 = getenv("PNN_SP_DIAG") != nullptr;
-    // Few output tiles (the in-loop single-block calls, the batching service's handfuls): one wave per 32 x 32 tile over all
-    // CUs instead of one or two big workgroups walking K alone.  Same per-output summation order: bit-identical.
-    const bool small = seg_chunks > 0 || (!next && !diag0 && c->opt_small && c->opt_sp_cfg < 0 && tapgemm_small_tiles(p) <= c->opt_small_tiles);
-    if (small) {
-        if (seg_chunks > 0) p.part = part;
-        if (first) { HIPCHK(c, launch_conv_cin1(*first, s)); c->stat_launches++; }
-        static const bool dbg = getenv("PNN_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> small kernel (%ld tiles%s%s)\n", M, L.k_total, p.Cout, p.ncls,
-                         tapgemm_small_tiles(p), x_is_f32 ? ", f32 input" : "", seg_chunks ? ", K segments" : "");
-        const double flops = 2.0 * (double)M * L.k_total * p.Cout;
-        if (c->opt_time_launches) {
-            pnn_ctx::LaunchRec r;
-            HIPCHK(c, hipEventCreate(&r.e0));
-            HIPCHK(c, hipEventCreate(&r.e1));
-            r.kind = 5; r.flops = flops;
-            const LaunchEvents ev{r.e0, r.e1};
-            g_launch_events = &ev;
-            const hipError_t le = launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr);
-            g_launch_events = nullptr;
-            HIPCHK(c, le);
-            c->launch_recs.push_back(r);
-        } else {
-            HIPCHK(c, launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr));
-        }
-        c->stat_gemm_launches++; c->stat_launches++;
-        c->stat_gemm_flops += flops;
-        if (tiles_out) *tiles_out = seg_chunks > 0 ? (int)(((long)(L.k_total / 16.0) + seg_chunks - 1) / seg_chunks) : 0;
-        return PNN_OK;
-    }
-    if (x_is_f32) {                                   // the big-tile kernels read split activations
-        const long nin = nblocks * (long)p.IH * p.IW * p.Cin;
-        HIPCHK(c, launch_split((const float*)Xhi, nin, c->ws[2].p, nullptr, c->h_range, s));
-        c->stat_launches++;
-        p.X = (const float*)c->ws[2].p;
-    }
-    const int nsp = tapgemm_sp_num_cfgs(), nci = convimg_sp_num_cfgs(), nrg = tapgemm_ring_num_cfgs();
-    // configuration codes: [0, nsp) = tapgemm_sp_kernel tiles, then the convimg_sp_kernel tiles (images resident in
-    // LDS), then the tapgemm_ring_kernel tiles (LDS-DMA ring)
-    p.zero = c->d_zero;
-    auto cfg_of = [&](int code) { return code < nsp ? tapgemm_sp_cfg(code) : code < nsp + nci ? convimg_sp_cfg(code - nsp) : tapgemm_ring_cfg(code - nsp - nci); };
-    auto kind_of = [&](int code) { return code < nsp ? "" : code < nsp + nci ? "img" : "ring"; };
-    auto legal = [&](int code) {
-        // fused output layer: only the 160-column tile -- its column tiles ARE the K segments of the output layer's canonical
-        // summation order (kFuseSegChunks chunks each), which the small-M kernel reproduces for every other batch size
-        if (next) return code >= nsp + nci && !diag && c->opt_ring && tapgemm_ring_can_fuse(code - nsp - nci) &&
-                         32 * tapgemm_ring_cfg(code - nsp - nci).nt * (4 / tapgemm_ring_cfg(code - nsp - nci).wm) == 16 * kFuseSegChunks;
-        if (code < nsp) return one_tap || cpt % tapgemm_sp_cfg(code).kc == 0;
-        if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
-        return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
-    };
-    auto launch = [&](int code) {
-        if (first) {
-            if (code >= nsp && code < nsp + nci) {
-                const TileCfg t = convimg_sp_cfg(code - nsp);
-                const int g = convimg_images(p, t, one_tap);
-                if (c->opt_fuse_first && convimg_sp_can_fuse_first(p, t, g, first->s, first->k)) {
-                    TapGemmParams q = p;
-                    q.X0 = first->X; q.W0 = first->W; q.B0 = first->bias; q.s0 = first->s; q.k0 = first->k; q.pad0 = first->pad;
-                    return launch_convimg_sp(q, code - nsp, g, s);
-                }
-            }
-            const hipError_t e = launch_conv_cin1(*first, s);
-            if (e != hipSuccess) return e;
-        }
-        if (code < nsp) return launch_tapgemm_sp(p, code, s);
-        if (code < nsp + nci) {
-            const TileCfg t = convimg_sp_cfg(code - nsp);
-            return launch_convimg_sp(p, code - nsp, convimg_images(p, t, one_tap), s);
-        }
-        return launch_tapgemm_ring(p, code - nsp - nci, s);
-    };
-    int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
-    if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
-    else if (c->opt_sp_cfg < 0) {
-        const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
-        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
-        const bool ring_conv = !one_tap && ri >= 0 && ((p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0) || (p.ncls == 4 && p.Cout == 64 && M >= 8192) || pnn_ring_few_images(p, M, L.k_total));   // see choose_cfg_ring
-        if (ring_conv && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
-        else if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
-        else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
-        else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
-    }
-    // autotune: 1 = every split GEMM, 2 (default) = only launches of >= 4 GFLOP, where trying all configurations once
-    // (~70 x 4 launches) costs a few tens of milliseconds and the choice is worth 10-20 %; 0 = rule-based choice only.
-    // All configurations give bit-identical results, so the choice never shows in the predictions.
-    bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
-    if (tune && c->tuned.find(std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M)) == c->tuned.end()) {
-        // timing configurations means synchronising on the caller's stream: never while that stream is being captured
-        // into a hipGraph (the rule-based choice is used instead, nothing is remembered)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
-    }
-    if (tune && c->opt_sp_cfg < 0) {
-        // On-device choice: the first time a (layer, M) pair is seen, every legal tile configuration runs the real
-        // launch three times (idempotent: same inputs, same outputs) and the fastest is remembered.
-        const auto key = std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M);
-        auto it = c->tuned.find(key);
-        if (it == c->tuned.end()) {
-            hipEvent_t e0, e1;
-            HIPCHK(c, hipEventCreate(&e0));
-            HIPCHK(c, hipEventCreate(&e1));
-            float best_ms = 1e30f, rule_ms = 1e30f;
-            int best = cfg;
-            for (int i = 0; i < nsp + nci + nrg; i++) {
-                if (!legal(i)) continue;
-                HIPCHK(c, launch(i));                 // warm
-                HIPCHK(c, hipEventRecord(e0, s));
-                for (int r = 0; r < 3; r++) HIPCHK(c, launch(i));
-                HIPCHK(c, hipEventRecord(e1, s));
-                HIPCHK(c, hipEventSynchronize(e1));
-                float ms = 0.f;
-                HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-                if (getenv("PNN_DEBUG_TUNE")) fprintf(stderr, "[pnn]   code %d: %.1f us\n", i, ms * 1e3 / 3);
-                if (i == cfg) rule_ms = ms;
-                if (ms < best_ms) { best_ms = ms; best = i; }
-            }
-            // Three back-to-back launches of one configuration are a noisy yardstick (no producer in front, caches warm from
-            // the same launch): a configuration has to beat the rule-based choice by more than 3 % to replace it.  (Seen on the
-            // K = 320 layer of the 8x8 FC net: the tuner took the 3-deep ring for "14.6 vs 14.7 us" where the 4-deep ring of
-            // the rule runs the layer in 13.4 us inside the real pass.)
-            if (best != cfg && rule_ms < 1e29f && rule_ms <= best_ms * 1.03f) { best = cfg; best_ms = rule_ms; }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            it = c->tuned.emplace(key, best).first;
-            if (getenv("PNN_DEBUG")) {
-                const TileCfg tb = cfg_of(best), th = cfg_of(cfg);
-                fprintf(stderr, "[pnn] autotune M=%ld K=%.0f N=%d ncls=%d: best %s{%d,%d,%d,wm%d,d%d} %.1f us (heuristic %s{%d,%d,%d,wm%d,d%d})\n", M,
-                        L.k_total, p.Cout, p.ncls, kind_of(best), tb.rt, tb.nt, tb.kc, tb.wm, tb.d, best_ms * 1e3 / 3, kind_of(cfg), th.rt, th.nt,
-                        th.kc, th.wm, th.d);
-            }
-        }
-        cfg = it->second;
-    }
-    if (next && !legal(cfg)) {                        // checked BEFORE anything is launched: the caller falls back to separate launches
-        cfg = -1;
-        for (int i = nsp + nci; i < nsp + nci + nrg && cfg < 0; i++) if (legal(i)) cfg = i;
-        if (cfg < 0) return fail(c, PNN_E_ARG, "no ring configuration can fuse the next layer");
-    }
-    static const bool debug = getenv("PNN_DEBUG") != nullptr;
-    static const bool profile = getenv("PNN_PROFILE") != nullptr;
-    const TileCfg t = cfg_of(cfg);
-    if (debug) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d %s{rt %d, nt %d, kc %d, wm %d, d %d}\n", M, L.k_total, p.Cout, p.ncls,
-                       cfg, kind_of(cfg), t.rt, t.nt, t.kc, t.wm, t.d);
-    if (profile || c->opt_time_launches) {
-        pnn_ctx::LaunchRec r;
-        HIPCHK(c, hipEventCreate(&r.e0));
-        HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = cfg < nsp ? 2 : cfg < nsp + nci ? 3 : 4;
-        r.flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
-        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
-        g_launch_events = &ev;
-        const hipError_t le = launch(cfg);
-        g_launch_events = nullptr;
-        HIPCHK(c, le);
-        if (profile) {
-            HIPCHK(c, hipEventSynchronize(r.e1));
-            float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
-            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
-                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
-            (void)hipEventDestroy(r.e0);
-            (void)hipEventDestroy(r.e1);
-        } else {
-            c->launch_recs.push_back(r);
-        }
-    } else {
-        HIPCHK(c, launch(cfg));
-    }
-    if (diag) {
-        HIPCHK(c, hipStreamSynchronize(s));
-        const TileCfg tt = tapgemm_sp_cfg(cfg);   // (diag runs never take the convimg kernel)
-        const long bm = 32L * tt.rt * tt.wm, bn = 32L * tt.nt * (4 / tt.wm);
-        const size_t nwg = (size_t)((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
-        std::vector<unsigned long long> h(4 * nwg);
-        HIPCHK(c, hipMemcpy(h.data(), c->stage_tbs.p, h.size() * 8, hipMemcpyDeviceToHost));
-        double sum[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < nwg; i++) for (int k = 0; k < 4; k++) sum[k] += (double)h[4 * i + k];
-        const double stages = std::ceil(L.k_total / 16.0 / p.ncls / tt.kc);
-        fprintf(stderr, "[pnn-diag] M=%ld K=%.0f N=%d cfg {%d,%d,%d,wm%d}: per stage (cycles, wave 0 mean over %zu WGs): issue %.0f  mfma %.0f  store %.0f  barrier %.0f\n",
-                M, L.k_total, p.Cout, tt.rt, tt.nt, tt.kc, tt.wm, nwg, sum[0] / nwg / stages, sum[1] / nwg / stages, sum[2] / nwg / stages, sum[3] / nwg / stages);
-    }
-    c->stat_gemm_launches++; c->stat_launches++;
-    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
-    if (next) {
-        c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
-        if (tiles_out) *tiles_out = (int)((p.Cout + 32L * t.nt * (4 / t.wm) - 1) / (32L * t.nt * (4 / t.wm)));
-    }
-    return PNN_OK;
-}
-
-long chunk_blocks(const pnn_ctx* c, const Model* m)
-{
-    const double per_block = 4.0 * (m->is_fc ? 2.0 * kHidden : 2.0 * m->pmax + 80.0 * m->C);
-    long n = c->opt_max_chunk > 0 ? c->opt_max_chunk : (long)((double)c->ws_cap_bytes / per_block);
-    // every activation tensor of a pass must stay below the 2 GiB bound of a buffer descriptor
-    const double biggest = 4.0 * std::max((double)m->pmax, 5.0 * m->width * m->width);
-    n = std::min(n, (long)(2147483000.0 / biggest));
-    return std::max(1L, std::min(n, 1L << 20));
-}
-
-// The branches of a conv pass overlap on two streams while one branch leaves most of the chip idle.  The fork/join costs
-// ~25 us of event traffic between the two queues (measured: single-block calls of the 16x16 net 88 -> 97 us, 32x32 157 ->
-// 147 us, 64x64 261 -> 220 us), so only the nets whose branches are longer than that take it, option "branch_streams" = 2
-// forces it.  Not under the per-launch timing modes, which assume one stream.
-bool branches_overlap(const pnn_ctx* c, const Model* m, long nb)
-{
-    static const bool profile = getenv("PNN_PROFILE") != nullptr;
-    if (!c->opt_branch_streams || m->is_fc || profile || c->opt_time_launches) return false;
-    return nb * m->width * m->width <= 8192 && (m->width >= 32 || c->opt_branch_streams == 2);
-}
-
-int ensure_ws(pnn_ctx* c, const Model* m, long nb)
-{
-    int rc;
-    if ((rc = dev_reserve(c, c->ws[0], (size_t)nb * m->pmax * 4))) return rc;
-    if ((rc = dev_reserve(c, c->ws[1], (size_t)nb * m->pmax * 4))) return rc;
-    if (m->is_fc) {
-        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 5 * m->width * m->width * 4))) return rc;   // split-precision input planes
-    } else {
-        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 48 * m->C * 4))) return rc;
-        if ((rc = dev_reserve(c, c->ws[3], (size_t)nb * 32 * m->C * 4))) return rc;
-        if (branches_overlap(c, m, nb)) {
-            if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
-            if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
-            if (!c->side_stream) {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            }
-        }
-    }
-    return PNN_OK;
-}
+namespace {
 
 Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
 {
@@ -974,181 +77,6 @@ Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
     return m;
 }
 
-// Which arithmetic a pass of nb blocks runs on: the split-precision GEMM wins once the layers fill the chip; small
-// passes (HM's per-TB calls, short batches) are latency-bound and faster on the f32 kernels, whose split-K variant
-// spreads a small-M layer over all CUs (crossovers measured on device: ~500 blocks for the FC nets, ~200 for the
-// convolutional ones).  With canonical_order = 1 the choice must not depend on the batch size.
-bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
-{
-    if (c->opt_precision != 1) return false;
-    if (c->opt_canonical) return true;
-    if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
-    if (m->is_fc) return nb >= 512;
-    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
-    // sweeps of both paths around the crossover): 8x8 net ~150 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
-    const long px = nb * m->width * m->width;
-    return px >= (m->width <= 8 ? 10000 : m->width == 16 ? 18000 : m->width == 32 ? 35000 : 70000);
-}
-
-int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
-{
-    float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
-    int rc;
-    if (pass_uses_split(c, m, nb)) {
-        // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32); the input is
-        // already split when the gather wrote it, else the first layer's kernel splits it (small-M kernel: in registers)
-        const int n_out = m->fc[3].proto.Cout;
-        // Output layer of the 4x4 / 8x8 nets (<= 64 outputs): summed in K segments of kFuseSegChunks chunks + fuse_reduce, at
-        // EVERY batch size -- by the ring kernel's fused output layer (big batches: the 1200-wide activations of the third
-        // hidden layer never leave the workgroups that produce them) or by the small-M kernel's K-segment mode.
-        const bool seg_model = n_out <= 64 && n_out % 4 == 0;
-        const bool ring_fuse = seg_model && c->opt_fuse_last && c->opt_ring && c->opt_sp_cfg < 0 && nb >= 1024;
-        if ((rc = run_gemm_sp(c, m->fc[0], d_ctx, nullptr, nullptr, P0, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, !ctx_is_split))) return rc;
-        if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
-        if (seg_model) {
-            if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
-            float* part = (float*)c->ws[3].p;
-            int tiles = 0;
-            if (ring_fuse) {
-                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
-            } else {
-                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
-                if ((rc = run_gemm_sp(c, m->fc[3], P0, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, nullptr, part, &tiles, nullptr, false, kFuseSegChunks))) return rc;
-            }
-            if (tiles <= 0 || tiles > 20) return fail(c, PNN_E_ARG, "output layer: %d K segments do not fit the partial buffer", tiles);
-            HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
-            c->stat_launches++;
-            return PNN_OK;
-        }
-        if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
-        return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
-    }
-    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
-    if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
-    if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
-    return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
-}
-
-int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, long nb, float* d_out, int32_t* d_dst,
-              hipStream_t s)
-{
-    float* P[2] = {(float*)c->ws[0].p, (float*)c->ws[1].p};
-    float* F[2] = {(float*)c->ws[2].p, (float*)c->ws[3].p};
-    // Split-precision mode: tensors between two tap GEMMs travel in the split f16 layout (same byte count as f32);
-    // tensors consumed by the merger / the last transposed convolution stay f32.
-    const bool sp = pass_uses_split(c, m, nb);
-    int rc;
-    const bool par = branches_overlap(c, m, nb) && c->side_stream && c->ws[4].bytes >= (size_t)nb * m->pmax * 4 &&
-                     c->ws[5].bytes >= (size_t)nb * m->pmax * 4;   // ensure_ws sized them for this pass's chunk
-    hipStream_t const main_stream = s;
-    // Small passes (single-block calls, the service's handfuls): the two branches are independent chains of launches that
-    // cost ~4 us each whatever they do.  Layer i of both branches goes into ONE launch (conv_cin1_pair_kernel, then
-    // tapgemm_small_pair_kernel): 13 -> 9 launches for the 16x16 net, no event traffic between streams.  Same kernels' bodies,
-    // same arithmetic: bit-identical to the separate launches.
-    bool pair = sp && c->opt_pair && c->opt_small && c->opt_sp_cfg < 0 && !c->opt_time_launches && !getenv("PNN_PROFILE") &&
-                m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
-    for (size_t i = 0; pair && i < m->branch[0].size(); i++) {
-        long tiles = 0;
-        for (int br = 0; br < 2; br++) {
-            const TapGemmParams& q = m->branch[br][i].proto;
-            tiles += ((nb * q.SH * q.SW + 31) / 32) * ((q.Cout + 31) / 32) * q.ncls;
-        }
-        pair = tiles <= c->opt_small_tiles;
-    }
-    if (pair) {
-        if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
-        if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
-        float* Q[2][2] = {{P[0], P[1]}, {(float*)c->ws[4].p, (float*)c->ws[5].p}};
-        Conv1Params f[2];
-        for (int br = 0; br < 2; br++) {
-            f[br] = m->first[br].proto;
-            f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
-            f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 1;
-        }
-        HIPCHK(c, launch_conv_cin1_pair(f[0], f[1], s));
-        c->stat_launches++;
-        const size_t nl = m->branch[0].size();
-        int cur = 0;
-        for (size_t i = 0; i < nl; i++) {
-            const bool last = i + 1 == nl;
-            TapGemmParams q[2];
-            for (int br = 0; br < 2; br++) {
-                const GemmLayer& L = m->branch[br][i];
-                q[br] = L.proto;
-                q[br].X = Q[br][cur]; q[br].Wp = L.d_w_sp; q[br].bias = L.d_bias; q[br].mean = c->mean; q[br].out_scale = L.sp_inv_scale;
-                q[br].range_flag = c->h_range; q[br].zero = c->d_zero;
-                if (last) q[br].Y = F[br]; else q[br].Yhi = Q[br][cur ^ 1];
-                q[br].M = (int)(nb * q[br].SH * q[br].SW);
-                q[br].x_bytes = (unsigned)(4.0 * (double)nb * q[br].IH * q[br].IW * q[br].Cin);
-                c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
-            }
-            static const bool dbg = getenv("PNN_DEBUG") != nullptr;
-            if (dbg) fprintf(stderr, "[pnn] sp-gemm pair: branch layer %zu, M = %d / %d -> one small-kernel launch\n", i + 1, q[0].M, q[1].M);
-            HIPCHK(c, launch_tapgemm_small_pair(q[0], q[1], s));
-            c->stat_gemm_launches++; c->stat_launches++;
-            cur ^= 1;
-        }
-    }
-    if (par && !pair) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-    }
-    for (int br = 0; br < 2 && !pair; br++) {
-        if (par) {
-            s = br == 0 ? main_stream : c->side_stream;
-            if (br == 1) { P[0] = (float*)c->ws[4].p; P[1] = (float*)c->ws[5].p; }
-        }
-        const size_t nl = m->branch[br].size();
-        Conv1Params f = m->first[br].proto;
-        f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
-        f.B = (int)nb; f.range_flag = c->h_range;
-        int cur = 0;
-        f.Y = nl == 0 ? F[br] : P[cur];
-        f.split = (sp && nl > 0) ? 1 : 0;
-        const bool delegate = sp && nl > 0;           // run_gemm_sp of the next layer launches or absorbs this convolution
-        if (!delegate) {
-            HIPCHK(c, launch_conv_cin1(f, s));
-            c->stat_launches++;
-        }
-        for (size_t i = 0; i < nl; i++) {
-            const bool last = i + 1 == nl;
-            float* dst = last ? F[br] : P[cur ^ 1];
-            if (sp) rc = run_gemm_sp(c, m->branch[br][i], P[cur], nullptr, last ? dst : nullptr, last ? nullptr : dst, nullptr, nullptr, nb, s, nullptr, nullptr,
-                                     nullptr, (i == 0 && delegate) ? &f : nullptr);
-            else rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s);
-            if (rc) return rc;
-            cur ^= 1;
-        }
-    }
-    if (par && !pair) {
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-        s = main_stream;
-        P[0] = (float*)c->ws[0].p; P[1] = (float*)c->ws[1].p;
-    }
-    const size_t nt = m->tconv.size();
-    MergerParams mp = m->merger.proto;
-    mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
-    mp.split = (sp && nt > 0) ? 1 : 0;
-    mp.one_order = c->opt_canonical ? 1 : 0;
-    mp.range_flag = c->h_range;
-    HIPCHK(c, launch_merger(mp, s));
-    c->stat_launches++;
-    int cur = 0;
-    for (size_t i = 0; i < nt; i++) {
-        const bool last = i + 1 == nt;
-        if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, last ? P[cur ^ 1] : nullptr, last ? nullptr : P[cur ^ 1], nullptr, nullptr, nb, s);
-        else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s);
-        if (rc) return rc;
-        cur ^= 1;
-    }
-    TConv1Params tp = m->last.proto;
-    tp.X = P[cur]; tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
-    HIPCHK(c, launch_tconv_cout1(tp, s));
-    c->stat_launches++;
-    return PNN_OK;
-}
-
 void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; c->stat_gemm_flops = 0; }
 
 // Device (asynchronous) entry points cannot wait for their own pass; a pass that left the f16 range is reported by the
@@ -1161,21 +89,37 @@ int pending_range_error(pnn_ctx* c)
                                 "kernels (|v| >= 65504): its predictions are invalid; repeat it with pnn_set_option(ctx, \"precision\", 0)");
 }
 
-// Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
-int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
-            int32_t* d_dst, hipStream_t s, bool ctx_is_split = false)
+// A host pass left the f16 range of the split-precision kernels (*c->h_range raised, stream idle).  Only the blocks that
+// overflow ALONE are recomputed on the exact-f32 kernels; every other block keeps its split-precision result -- the value it
+// gets in any other batch (canonical_order) -- so one overflowing block behind the batching service does not change the last
+// float bits of the other clients' blocks.  `pass(b0, nb)` runs blocks [b0, b0 + nb) of the staged batch into their slots.
+// Batches above kPerBlockMax take the whole-batch repeat (a stand-alone caller, not the service, whose batches are <= 256).
+template <typename Pass>
+int range_fallback(pnn_ctx* c, long n, Pass pass, hipStream_t s)
 {
-    const int w = m->width;
-    const long chunk = std::min(n, chunk_blocks(c, m));
-    int rc = ensure_ws(c, m, chunk);
-    if (rc) return rc;
-    for (long b0 = 0; b0 < n; b0 += chunk) {
-        const long nb = std::min(chunk, n - b0);
-        float* o = d_out ? d_out + b0 * w * w : nullptr;
-        int32_t* di = d_dst ? d_dst + b0 * w * w : nullptr;
-        rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, ctx_is_split, nb, o, di, s)
-                      : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
+    constexpr long kPerBlockMax = 256;
+    *c->h_range = 0;
+    c->range_fallbacks++;
+    const long keep = c->opt_precision;
+    int rc = PNN_OK;
+    if (n == 1 || n > kPerBlockMax) {
+        c->opt_precision = 0;
+        rc = pass(0, n);
+        c->opt_precision = keep;
         if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(s));
+        return PNN_OK;
+    }
+    for (long i = 0; i < n; i++) {
+        if ((rc = pass(i, 1))) return rc;             // alone, split precision: the same bits as inside the batch
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!*c->h_range) continue;
+        *c->h_range = 0;
+        c->opt_precision = 0;
+        rc = pass(i, 1);
+        c->opt_precision = keep;
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(s));
     }
     return PNN_OK;
 }
@@ -1521,6 +465,13 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (n < 0 || (n > 0 && (!above || (!out && !dst)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     if (n == 0) return PNN_OK;
     if (!m->is_fc && !left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
+    {   // the range guard's v_max_f32 drops NaN operands: non-finite inputs are refused here (a few hundred floats per block)
+        const size_t ca = (size_t)n * (m->is_fc ? 5 : 3) * w2, cl = m->is_fc ? 0 : (size_t)n * 2 * w2;
+        bool finite = true;
+        for (size_t i = 0; i < ca && finite; i++) finite = std::isfinite(above[i]);
+        for (size_t i = 0; i < cl && finite; i++) finite = std::isfinite(left[i]);
+        if (!finite) return fail(c, PNN_E_ARG, "non-finite value in the input contexts");
+    }
     // ---- prediction cache (single-block calls only) ----
     pnn_ctx::CacheEntry* slot = nullptr;
     uint64_t hash = 0;
@@ -1564,24 +515,17 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         if (in_l) memcpy(hp + kPinIn, left, in_l);
         float* p_out = (float*)(hp + 2 * kPinIn);
         int32_t* p_dst = (int32_t*)(hp + 2 * kPinIn + kPinOut);
-        auto pass = [&]() {
-            c->host_input = m->is_fc ? above : nullptr;   // small inputs ride in the first kernel's argument block
-            const int r = run_net(c, m, (const float*)hp, m->is_fc ? 5 * w2 : 3 * w2, (const float*)(hp + kPinIn), 2 * w2, n, p_out, (dst || slot) ? p_dst : nullptr, s);
+        const long pa = m->is_fc ? 5 * w2 : 3 * w2;
+        auto pass = [&](long b0, long nb) {
+            c->host_input = m->is_fc ? above + b0 * pa : nullptr;   // small inputs ride in the first kernel's argument block
+            const int r = run_net(c, m, (const float*)hp + b0 * pa, pa, (const float*)(hp + kPinIn) + b0 * 2 * w2, 2 * w2, nb, p_out + b0 * w2,
+                                  (dst || slot) ? p_dst + b0 * w2 : nullptr, s);
             c->host_input = nullptr;
             return r;
         };
-        if ((rc = pass())) return rc;
+        if ((rc = pass(0, n))) return rc;
         HIPCHK(c, hipStreamSynchronize(s));
-        if (*c->h_range) {                            // left the f16 range: the same pass on the exact-f32 kernels
-            *c->h_range = 0;
-            c->range_fallbacks++;
-            const long keep = c->opt_precision;
-            c->opt_precision = 0;
-            rc = pass();
-            c->opt_precision = keep;
-            if (rc) return rc;
-            HIPCHK(c, hipStreamSynchronize(s));
-        }
+        if (*c->h_range && (rc = range_fallback(c, n, pass, s))) return rc;
         if (out) memcpy(out, p_out, (size_t)n * w2 * 4);
         if (dst) {
             if (dst_stride == w) memcpy(dst, p_dst, (size_t)n * w2 * 4);
@@ -1607,14 +551,13 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (rc) return rc;
     if (c->opt_precision == 1) {                      // the guard costs one synchronisation; the copies below wait for the stream anyway
         HIPCHK(c, hipStreamSynchronize(s));
-        if (*c->h_range) {                            // left the f16 range: the same pass on the exact-f32 kernels
-            *c->h_range = 0;
-            c->range_fallbacks++;
-            c->opt_precision = 0;
-            rc = run_net(c, m, (const float*)c->stage_in[0].p, m->is_fc ? 5 * w2 : 3 * w2, (const float*)c->stage_in[1].p, 2 * w2, n,
-                         d_out, d_dst, s);
-            c->opt_precision = 1;
-            if (rc) return rc;
+        if (*c->h_range) {
+            const long pa = m->is_fc ? 5 * w2 : 3 * w2;
+            auto pass = [&](long b0, long nb) {
+                return run_net(c, m, (const float*)c->stage_in[0].p + b0 * pa, pa, (const float*)c->stage_in[1].p + b0 * 2 * w2, 2 * w2, nb,
+                               d_out + b0 * w2, d_dst ? d_dst + b0 * w2 : nullptr, s);
+            };
+            if ((rc = range_fallback(c, n, pass, s))) return rc;
         }
     }
     if (out) HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n * w2 * 4, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,164 @@
+// Internal types of the C-ABI layer, shared by its translation units (not part of the public boundary, include/pnn_hip.h):
+//   pnn_model.cpp   weight pre-packing and the per-architecture layer tables (built once per model load)
+//   pnn_tiles.cpp   rule-based choice of the kernel family / tile configuration of a tap GEMM
+//   pnn_tuner.cpp   on-device choice among the legal configurations, remembered per (layer, M)
+//   pnn_passes.cpp  the launch sequences of one pass of the fully-connected / convolutional nets
+//   pnn_abi.cpp     the extern "C" entry points, contexts, staging and the prediction cache
+#pragma once
+#include "../../include/pnn_hip.h"
+#include "pnn_kernels.h"
+#include "pnn_host.h"
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace pnn {
+
+constexpr int kHidden = 1200;                         // pnn/components.py:130-160
+// The output layer of an FC net with <= 64 outputs is summed in K segments of 10 chunks (160 hidden units) whose partial
+// sums are then added in ascending order (fuse_reduce_kernel): the order the ring kernel's fused output layer produces
+// with its 128 x 160 tile, and the order tapgemm_small_kernel's K-segment mode reproduces at any batch size.
+constexpr int kFuseSegChunks = 10;
+inline int strides_for(int w, int* st)                       // pnn/PredictionNeuralNetwork.py:126-132
+{
+    switch (w) {
+    case 4: st[0] = 1; st[1] = 1; return 2;
+    case 8: st[0] = 2; st[1] = 1; return 2;
+    case 16: st[0] = 2; st[1] = 1; st[2] = 2; st[3] = 1; return 4;
+    case 32: st[0] = 2; st[1] = 2; st[2] = 1; st[3] = 2; st[4] = 1; return 5;
+    case 64: st[0] = 2; st[1] = 2; st[2] = 2; st[3] = 2; st[4] = 1; return 5;
+    default: return -1;
+    }
+}
+
+inline int width_index(int w)                                // TComPrediction.cpp:564: log2(w) - 2
+{
+    switch (w) { case 4: return 0; case 8: return 1; case 16: return 2; case 32: return 3; case 64: return 4; default: return -1; }
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct GemmLayer {                                    // one tap-GEMM launch (all classes)
+    TapGemmParams proto{};
+    float* d_w = nullptr;
+    float* d_w_sp = nullptr;                          // split-precision pack: f16 hi/lo, pre-scaled by 2^sp_shift
+    float sp_inv_scale = 1.f;
+    float* d_bias = nullptr;
+    double k_total = 0;                               // sum over classes of taps * Cin
+    long out_per_block = 0;                           // output floats per block
+};
+struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_bias = nullptr; long out_per_block = 0; };
+struct TConv1Layer { TConv1Params proto{}; float* d_w = nullptr; };
+struct MergerLayer { MergerParams proto{}; float* d_w = nullptr; float* d_bias = nullptr; };
+
+struct Model {
+    int width = 0;
+    bool is_fc = false;
+    long n_params = 0;
+    int n_layers = 0;
+    std::vector<GemmLayer> fc;                        // 4 layers
+    Conv1Layer first[2];                              // branch_above / branch_left conv 0
+    std::vector<GemmLayer> branch[2];                 // conv 1..L-1
+    MergerLayer merger;
+    std::vector<GemmLayer> tconv;                     // tconv 0..L-2
+    TConv1Layer last;
+    int C = 0;                                        // channels at the merger
+    long pmax = 0;                                    // largest intermediate activation (floats / block)
+    std::vector<void*> allocs;
+};
+
+}  // namespace pnn
+
+struct pnn_ctx {
+    int device = 0;
+    float mean = 0.f;
+    hipStream_t stream = nullptr;
+    pnn::Model* models[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    pnn::DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
+    // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
+    // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
+    long opt_split_min_px = -1;                       // tuning aid: conv passes take the split-precision kernels from this many block pixels on (-1: built-in rule)
+    long opt_branch_streams = 1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    pnn::DevBuf stage_in[2], stage_out[2], stage_tbs;
+    // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
+    // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.
+    struct CacheEntry { uint64_t hash = 0; bool valid = false; std::vector<float> in, out; std::vector<int32_t> pel; };
+    std::vector<CacheEntry> cache[5];
+    long opt_cache_mb = 0;                            // 0 = off
+    long cache_hits = 0, cache_misses = 0;
+    char* h_pin = nullptr;                            // pinned, device-visible staging of the single-block host calls (zero-copy)
+    void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
+    long opt_tile_cfg = -1;
+    long opt_max_chunk = 0;
+    // 1 (default): one per-output summation order at every batch size -- a block's prediction does not depend on the batch
+    // it travels in (encoder behind the batching service, decoder alone: no drift).  0: small passes may take the exact-f32
+    // split-K kernels (a few us faster per single-block call; last float bits can differ from the batched result).
+    long opt_canonical = 1;
+    long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
+    long opt_sp_cfg = -1;
+    long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
+    long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
+    long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
+    long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
+    long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
+    long opt_pair = 1;                                // 1: small conv passes run the same layer of both branches as ONE launch
+    long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
+    long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
+    std::map<std::pair<const void*, long>, int> tuned;
+    long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
+    struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
+    std::vector<LaunchRec> launch_recs;
+    // Range guard of the split-precision path (pnn_device_common.h): kernels raise *h_range (pinned host memory) when a
+    // split-f16 activation leaves the f16 range.  Host entry points then repeat the pass on the exact-f32 kernels; device
+    // entry points report PNN_E_RANGE at the next call / pnn_check_range.
+    int* h_range = nullptr;
+    long range_fallbacks = 0;
+    const float* host_input = nullptr;                // host_predict: the caller's f32 input rows (FC nets), valid during the call
+    size_t ws_cap_bytes = (size_t)8 << 30;
+    std::string err;
+    int stat_gemm_launches = 0, stat_launches = 0;
+    double stat_gemm_flops = 0;
+};
+
+namespace pnn {
+
+int fail(pnn_ctx* c, int code, const char* fmt, ...);
+
+#define HIPCHK(c, expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return pnn::fail((c), PNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// pnn_abi.cpp
+int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes);
+// pnn_model.cpp
+int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n, Model** out);
+void free_model(Model* m);
+// pnn_tiles.cpp
+int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total);
+int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap);
+int choose_cfg_convimg(const TapGemmParams& p, bool one_tap);
+bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total);
+int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false);
+int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total);
+// pnn_tuner.cpp
+// First sighting of (key, M): every legal configuration code in [0, ncodes) runs the real launch (idempotent) on stream
+// `s`, the fastest is remembered in c->tuned and returned in *cfg; later sightings return the remembered code.  `rule` =
+// the rule-based choice (kept unless beaten by > 3 %).  PNN_OK, or the error of a failed launch.
+int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const std::function<bool(int)>& legal,
+              const std::function<hipError_t(int)>& launch, hipStream_t s, int* cfg, float* best_us);
+// pnn_passes.cpp
+long chunk_blocks(const pnn_ctx* c, const Model* m);
+bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb);
+int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
+            int32_t* d_dst, hipStream_t s, bool ctx_is_split = false);
+
+}  // namespace pnn

@@ -1,0 +1,514 @@
+// One pass of a PNN over a chunk of blocks: which kernel family runs each layer, in which order, on which buffers
+// (DESIGN.md section 4).  Reference behaviour reproduced (not code): inference_fully_connected / inference_convolutional /
+// branch / merger of pnn/components.py:10-261.
+#include "pnn_ctx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace pnn {
+namespace {
+
+int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s)
+{
+    TapGemmParams p = L.proto;
+    p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
+    const long M = nblocks * p.SH * p.SW;
+    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
+    p.M = (int)M;
+    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
+    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation tensor of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
+    p.x_bytes = (unsigned)xb;
+    const int cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    static const bool debug = getenv("PNN_DEBUG") != nullptr;
+    if (debug) {
+        const TileCfg t = tapgemm_cfg(cfg);
+        fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls,
+                cfg, t.rt, t.nt, t.kc);
+    }
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch timing, synchronous
+    if (profile || c->opt_time_launches) {
+        pnn_ctx::LaunchRec r;
+        HIPCHK(c, hipEventCreate(&r.e0));
+        HIPCHK(c, hipEventCreate(&r.e1));
+        r.kind = tapgemm_cfg(cfg).rt == 0 ? 1 : 0;
+        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
+        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
+        g_launch_events = &ev;
+        const hipError_t le = launch_tapgemm(p, cfg, s);
+        g_launch_events = nullptr;
+        HIPCHK(c, le);
+        if (profile) {
+            HIPCHK(c, hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+            const TileCfg t = tapgemm_cfg(cfg);
+            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        } else {
+            c->launch_recs.push_back(r);
+        }
+    } else {
+        HIPCHK(c, launch_tapgemm(p, cfg, s));
+    }
+    c->stat_gemm_launches++; c->stat_launches++;
+    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    return PNN_OK;
+}
+
+// `next` (optional): a following fully-connected layer with <= 64 outputs that the ring kernel applies to its output tile
+// in LDS; `part` then receives the per-column-tile partial products [tiles][M][64] and *tiles_out their count (the caller
+// finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
+int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
+                long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
+                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0)
+{
+    // x_is_f32: Xhi holds plain f32 rows (an FC net's input as the caller handed it over); only the small-M kernel takes
+    // that (it splits in registers), any other choice gets split_kernel launched in front (into ws[2]).
+    // seg_chunks > 0: K-segment mode of an FC output layer (small-M kernel only): raw partials to `part`, see fc_pass.
+    // `first` (optional): the Cin = 1 convolution that produces this layer's input Xhi.  It has NOT been launched: a
+    // convimg configuration computes it inside the kernel (no 50 MB round trip of the maps), any other configuration gets
+    // it launched here in front of the GEMM.
+    TapGemmParams p = L.proto;
+    if (next) {
+        p.W2p = next->d_w_sp; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part;
+    }
+    p.X = (const float*)Xhi; p.Xlo = Xlo; p.Wp = L.d_w_sp;
+    static const bool diag = getenv("PNN_SP_DIAG") != nullptr;   // diagnostic library only: phase stamps of every workgroup
+    if (diag) {
+        if (dev_reserve(c, c->stage_tbs, (size_t)64 << 20)) return PNN_E_NOMEM;
+        p.Xlo = c->stage_tbs.p;
+    } p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
+    p.mean = c->mean; p.out_scale = L.sp_inv_scale; p.range_flag = c->h_range;
+    const long M = nblocks * p.SH * p.SW;
+    if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
+    p.M = (int)M;
+    const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
+    if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation plane of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
+    p.x_bytes = (unsigned)xb;
+    const int cpt = p.Cin / 16;
+    const bool one_tap = (L.k_total == (double)p.Cin);
+    static const bool diag0 = getenv("PNN_SP_DIAG") != nullptr;
+    // Few output tiles (the in-loop single-block calls, the batching service's handfuls): one wave per 32 x 32 tile over all
+    // CUs instead of one or two big workgroups walking K alone.  Same per-output summation order: bit-identical.
+    const bool small = seg_chunks > 0 || (!next && !diag0 && c->opt_small && c->opt_sp_cfg < 0 && tapgemm_small_tiles(p) <= c->opt_small_tiles);
+    if (small) {
+        if (seg_chunks > 0) p.part = part;
+        if (first) { HIPCHK(c, launch_conv_cin1(*first, s)); c->stat_launches++; }
+        static const bool dbg = getenv("PNN_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> small kernel (%ld tiles%s%s)\n", M, L.k_total, p.Cout, p.ncls,
+                         tapgemm_small_tiles(p), x_is_f32 ? ", f32 input" : "", seg_chunks ? ", K segments" : "");
+        const double flops = 2.0 * (double)M * L.k_total * p.Cout;
+        if (c->opt_time_launches) {
+            pnn_ctx::LaunchRec r;
+            HIPCHK(c, hipEventCreate(&r.e0));
+            HIPCHK(c, hipEventCreate(&r.e1));
+            r.kind = 5; r.flops = flops;
+            const LaunchEvents ev{r.e0, r.e1};
+            g_launch_events = &ev;
+            const hipError_t le = launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr);
+            g_launch_events = nullptr;
+            HIPCHK(c, le);
+            c->launch_recs.push_back(r);
+        } else {
+            HIPCHK(c, launch_tapgemm_small(p, x_is_f32, seg_chunks, s, x_is_f32 ? c->host_input : nullptr));
+        }
+        c->stat_gemm_launches++; c->stat_launches++;
+        c->stat_gemm_flops += flops;
+        if (tiles_out) *tiles_out = seg_chunks > 0 ? (int)(((long)(L.k_total / 16.0) + seg_chunks - 1) / seg_chunks) : 0;
+        return PNN_OK;
+    }
+    if (x_is_f32) {                                   // the big-tile kernels read split activations
+        const long nin = nblocks * (long)p.IH * p.IW * p.Cin;
+        HIPCHK(c, launch_split((const float*)Xhi, nin, c->ws[2].p, nullptr, c->h_range, s));
+        c->stat_launches++;
+        p.X = (const float*)c->ws[2].p;
+    }
+    const int nsp = tapgemm_sp_num_cfgs(), nci = convimg_sp_num_cfgs(), nrg = tapgemm_ring_num_cfgs();
+    // configuration codes: [0, nsp) = tapgemm_sp_kernel tiles, then the convimg_sp_kernel tiles (images resident in
+    // LDS), then the tapgemm_ring_kernel tiles (LDS-DMA ring)
+    p.zero = c->d_zero;
+    auto cfg_of = [&](int code) { return code < nsp ? tapgemm_sp_cfg(code) : code < nsp + nci ? convimg_sp_cfg(code - nsp) : tapgemm_ring_cfg(code - nsp - nci); };
+    auto kind_of = [&](int code) { return code < nsp ? "" : code < nsp + nci ? "img" : "ring"; };
+    auto legal = [&](int code) {
+        // fused output layer: only the 160-column tile -- its column tiles ARE the K segments of the output layer's canonical
+        // summation order (kFuseSegChunks chunks each), which the small-M kernel reproduces for every other batch size
+        if (next) return code >= nsp + nci && !diag && c->opt_ring && tapgemm_ring_can_fuse(code - nsp - nci) &&
+                         32 * tapgemm_ring_cfg(code - nsp - nci).nt * (4 / tapgemm_ring_cfg(code - nsp - nci).wm) == 16 * kFuseSegChunks;
+        if (code < nsp) return one_tap || cpt % tapgemm_sp_cfg(code).kc == 0;
+        if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
+        return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
+    };
+    auto launch = [&](int code) {
+        if (first) {
+            if (code >= nsp && code < nsp + nci) {
+                const TileCfg t = convimg_sp_cfg(code - nsp);
+                const int g = convimg_images(p, t, one_tap);
+                if (c->opt_fuse_first && convimg_sp_can_fuse_first(p, t, g, first->s, first->k)) {
+                    TapGemmParams q = p;
+                    q.X0 = first->X; q.W0 = first->W; q.B0 = first->bias; q.s0 = first->s; q.k0 = first->k; q.pad0 = first->pad;
+                    return launch_convimg_sp(q, code - nsp, g, s);
+                }
+            }
+            const hipError_t e = launch_conv_cin1(*first, s);
+            if (e != hipSuccess) return e;
+        }
+        if (code < nsp) return launch_tapgemm_sp(p, code, s);
+        if (code < nsp + nci) {
+            const TileCfg t = convimg_sp_cfg(code - nsp);
+            return launch_convimg_sp(p, code - nsp, convimg_images(p, t, one_tap), s);
+        }
+        return launch_tapgemm_ring(p, code - nsp - nci, s);
+    };
+    int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+    if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
+    else if (c->opt_sp_cfg < 0) {
+        const int ci = c->opt_convimg ? choose_cfg_convimg(p, one_tap) : -1;
+        const int ri = c->opt_ring ? choose_cfg_ring(p, M, one_tap, L.k_total, next != nullptr) : -1;
+        const bool ring_conv = !one_tap && ri >= 0 && ((p.Cout % 128 == 0 && L.k_total / p.ncls >= 1152.0) || (p.ncls == 4 && p.Cout == 64 && M >= 8192) || pnn_ring_few_images(p, M, L.k_total));   // see choose_cfg_ring
+        if (ring_conv && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
+        else if (ci >= 0 && legal(nsp + ci) && !one_tap) cfg = nsp + ci;
+        else if (ri >= 0 && legal(nsp + nci + ri)) cfg = nsp + nci + ri;
+        else if (ci >= 0 && legal(nsp + ci)) cfg = nsp + ci;
+    }
+    // autotune: 1 = every split GEMM, 2 (default) = only launches of >= 4 GFLOP, where trying all configurations once
+    // (~70 x 4 launches) costs a few tens of milliseconds and the choice is worth 10-20 %; 0 = rule-based choice only.
+    // All configurations give bit-identical results, so the choice never shows in the predictions.
+    bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
+    if (tune && c->tuned.find(std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M)) == c->tuned.end()) {
+        // timing configurations means synchronising on the caller's stream: never while that stream is being captured
+        // into a hipGraph (the rule-based choice is used instead, nothing is remembered)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
+    }
+    if (tune && c->opt_sp_cfg < 0) {
+        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0));
+        const int rule = cfg;
+        float best_us = -1.f;
+        const int trc = tuned_cfg(c, key, M, nsp + nci + nrg, rule, legal, launch, s, &cfg, &best_us);
+        if (trc) return trc;
+        if (best_us >= 0.f && getenv("PNN_DEBUG")) {
+            const TileCfg tb = cfg_of(cfg), th = cfg_of(rule);
+            fprintf(stderr, "[pnn] autotune M=%ld K=%.0f N=%d ncls=%d: best %s{%d,%d,%d,wm%d,d%d} %.1f us (heuristic %s{%d,%d,%d,wm%d,d%d})\n", M,
+                    L.k_total, p.Cout, p.ncls, kind_of(cfg), tb.rt, tb.nt, tb.kc, tb.wm, tb.d, best_us, kind_of(rule), th.rt, th.nt,
+                    th.kc, th.wm, th.d);
+        }
+    }
+    if (next && !legal(cfg)) {                        // checked BEFORE anything is launched: the caller falls back to separate launches
+        cfg = -1;
+        for (int i = nsp + nci; i < nsp + nci + nrg && cfg < 0; i++) if (legal(i)) cfg = i;
+        if (cfg < 0) return fail(c, PNN_E_ARG, "no ring configuration can fuse the next layer");
+    }
+    static const bool debug = getenv("PNN_DEBUG") != nullptr;
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;
+    const TileCfg t = cfg_of(cfg);
+    if (debug) fprintf(stderr, "[pnn] sp-gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d %s{rt %d, nt %d, kc %d, wm %d, d %d}\n", M, L.k_total, p.Cout, p.ncls,
+                       cfg, kind_of(cfg), t.rt, t.nt, t.kc, t.wm, t.d);
+    if (profile || c->opt_time_launches) {
+        pnn_ctx::LaunchRec r;
+        HIPCHK(c, hipEventCreate(&r.e0));
+        HIPCHK(c, hipEventCreate(&r.e1));
+        r.kind = cfg < nsp ? 2 : cfg < nsp + nci ? 3 : 4;
+        r.flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
+        const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
+        g_launch_events = &ev;
+        const hipError_t le = launch(cfg);
+        g_launch_events = nullptr;
+        HIPCHK(c, le);
+        if (profile) {
+            HIPCHK(c, hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        } else {
+            c->launch_recs.push_back(r);
+        }
+    } else {
+        HIPCHK(c, launch(cfg));
+    }
+    if (diag) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        const TileCfg tt = tapgemm_sp_cfg(cfg);   // (diag runs never take the convimg kernel)
+        const long bm = 32L * tt.rt * tt.wm, bn = 32L * tt.nt * (4 / tt.wm);
+        const size_t nwg = (size_t)((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.ncls;
+        std::vector<unsigned long long> h(4 * nwg);
+        HIPCHK(c, hipMemcpy(h.data(), c->stage_tbs.p, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < nwg; i++) for (int k = 0; k < 4; k++) sum[k] += (double)h[4 * i + k];
+        const double stages = std::ceil(L.k_total / 16.0 / p.ncls / tt.kc);
+        fprintf(stderr, "[pnn-diag] M=%ld K=%.0f N=%d cfg {%d,%d,%d,wm%d}: per stage (cycles, wave 0 mean over %zu WGs): issue %.0f  mfma %.0f  store %.0f  barrier %.0f\n",
+                M, L.k_total, p.Cout, tt.rt, tt.nt, tt.kc, tt.wm, nwg, sum[0] / nwg / stages, sum[1] / nwg / stages, sum[2] / nwg / stages, sum[3] / nwg / stages);
+    }
+    c->stat_gemm_launches++; c->stat_launches++;
+    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    if (next) {
+        c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
+        if (tiles_out) *tiles_out = (int)((p.Cout + 32L * t.nt * (4 / t.wm) - 1) / (32L * t.nt * (4 / t.wm)));
+    }
+    return PNN_OK;
+}
+
+}  // namespace
+
+long chunk_blocks(const pnn_ctx* c, const Model* m)
+{
+    const double per_block = 4.0 * (m->is_fc ? 2.0 * kHidden : 2.0 * m->pmax + 80.0 * m->C);
+    long n = c->opt_max_chunk > 0 ? c->opt_max_chunk : (long)((double)c->ws_cap_bytes / per_block);
+    // every activation tensor of a pass must stay below the 2 GiB bound of a buffer descriptor
+    const double biggest = 4.0 * std::max((double)m->pmax, 5.0 * m->width * m->width);
+    n = std::min(n, (long)(2147483000.0 / biggest));
+    return std::max(1L, std::min(n, 1L << 20));
+}
+
+namespace {
+
+// The branches of a conv pass overlap on two streams while one branch leaves most of the chip idle.  The fork/join costs
+// ~25 us of event traffic between the two queues (measured: single-block calls of the 16x16 net 88 -> 97 us, 32x32 157 ->
+// 147 us, 64x64 261 -> 220 us), so only the nets whose branches are longer than that take it, option "branch_streams" = 2
+// forces it.  Not under the per-launch timing modes, which assume one stream.
+bool branches_overlap(const pnn_ctx* c, const Model* m, long nb)
+{
+    static const bool profile = getenv("PNN_PROFILE") != nullptr;
+    if (!c->opt_branch_streams || m->is_fc || profile || c->opt_time_launches) return false;
+    return nb * m->width * m->width <= 8192 && (m->width >= 32 || c->opt_branch_streams == 2);
+}
+
+int ensure_ws(pnn_ctx* c, const Model* m, long nb)
+{
+    int rc;
+    if ((rc = dev_reserve(c, c->ws[0], (size_t)nb * m->pmax * 4))) return rc;
+    if ((rc = dev_reserve(c, c->ws[1], (size_t)nb * m->pmax * 4))) return rc;
+    if (m->is_fc) {
+        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 5 * m->width * m->width * 4))) return rc;   // split-precision input planes
+    } else {
+        if ((rc = dev_reserve(c, c->ws[2], (size_t)nb * 48 * m->C * 4))) return rc;
+        if ((rc = dev_reserve(c, c->ws[3], (size_t)nb * 32 * m->C * 4))) return rc;
+        if (branches_overlap(c, m, nb)) {
+            if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
+            if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
+            if (!c->side_stream) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+        }
+    }
+    return PNN_OK;
+}
+
+}  // namespace
+
+// Which arithmetic a pass of nb blocks runs on: the split-precision GEMM wins once the layers fill the chip; small
+// passes (HM's per-TB calls, short batches) are latency-bound and faster on the f32 kernels, whose split-K variant
+// spreads a small-M layer over all CUs (crossovers measured on device: ~500 blocks for the FC nets, ~200 for the
+// convolutional ones).  With canonical_order = 1 the choice must not depend on the batch size.
+bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
+{
+    if (c->opt_precision != 1) return false;
+    if (c->opt_canonical) return true;
+    if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
+    if (m->is_fc) return nb >= 512;
+    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
+    // sweeps of both paths around the crossover): 8x8 net ~150 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
+    const long px = nb * m->width * m->width;
+    return px >= (m->width <= 8 ? 10000 : m->width == 16 ? 18000 : m->width == 32 ? 35000 : 70000);
+}
+
+namespace {
+
+int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb, float* d_out, int32_t* d_dst, hipStream_t s)
+{
+    float* P0 = (float*)c->ws[0].p; float* P1 = (float*)c->ws[1].p;
+    int rc;
+    if (pass_uses_split(c, m, nb)) {
+        // split-precision chain: hidden activations travel in the split f16 layout (same byte count as f32); the input is
+        // already split when the gather wrote it, else the first layer's kernel splits it (small-M kernel: in registers)
+        const int n_out = m->fc[3].proto.Cout;
+        // Output layer of the 4x4 / 8x8 nets (<= 64 outputs): summed in K segments of kFuseSegChunks chunks + fuse_reduce, at
+        // EVERY batch size -- by the ring kernel's fused output layer (big batches: the 1200-wide activations of the third
+        // hidden layer never leave the workgroups that produce them) or by the small-M kernel's K-segment mode.
+        const bool seg_model = n_out <= 64 && n_out % 4 == 0;
+        const bool ring_fuse = seg_model && c->opt_fuse_last && c->opt_ring && c->opt_sp_cfg < 0 && nb >= 1024;
+        if ((rc = run_gemm_sp(c, m->fc[0], d_ctx, nullptr, nullptr, P0, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, !ctx_is_split))) return rc;
+        if ((rc = run_gemm_sp(c, m->fc[1], P0, nullptr, nullptr, P1, nullptr, nullptr, nb, s))) return rc;
+        if (seg_model) {
+            if ((rc = dev_reserve(c, c->ws[3], (size_t)20 * nb * 64 * 4))) return rc;
+            float* part = (float*)c->ws[3].p;
+            int tiles = 0;
+            if (ring_fuse) {
+                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
+            } else {
+                if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
+                if ((rc = run_gemm_sp(c, m->fc[3], P0, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, nullptr, part, &tiles, nullptr, false, kFuseSegChunks))) return rc;
+            }
+            if (tiles <= 0 || tiles > 20) return fail(c, PNN_E_ARG, "output layer: %d K segments do not fit the partial buffer", tiles);
+            HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
+            c->stat_launches++;
+            return PNN_OK;
+        }
+        if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
+        return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
+    }
+    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
+    if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
+    if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
+    return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
+}
+
+int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, long nb, float* d_out, int32_t* d_dst,
+              hipStream_t s)
+{
+    float* P[2] = {(float*)c->ws[0].p, (float*)c->ws[1].p};
+    float* F[2] = {(float*)c->ws[2].p, (float*)c->ws[3].p};
+    // Split-precision mode: tensors between two tap GEMMs travel in the split f16 layout (same byte count as f32);
+    // tensors consumed by the merger / the last transposed convolution stay f32.
+    const bool sp = pass_uses_split(c, m, nb);
+    int rc;
+    const bool par = branches_overlap(c, m, nb) && c->side_stream && c->ws[4].bytes >= (size_t)nb * m->pmax * 4 &&
+                     c->ws[5].bytes >= (size_t)nb * m->pmax * 4;   // ensure_ws sized them for this pass's chunk
+    hipStream_t const main_stream = s;
+    // Small passes (single-block calls, the service's handfuls): the two branches are independent chains of launches that
+    // cost ~4 us each whatever they do.  Layer i of both branches goes into ONE launch (conv_cin1_pair_kernel, then
+    // tapgemm_small_pair_kernel): 13 -> 9 launches for the 16x16 net, no event traffic between streams.  Same kernels' bodies,
+    // same arithmetic: bit-identical to the separate launches.
+    bool pair = sp && c->opt_pair && c->opt_small && c->opt_sp_cfg < 0 && !c->opt_time_launches && !getenv("PNN_PROFILE") &&
+                m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
+    for (size_t i = 0; pair && i < m->branch[0].size(); i++) {
+        long tiles = 0;
+        for (int br = 0; br < 2; br++) {
+            const TapGemmParams& q = m->branch[br][i].proto;
+            tiles += ((nb * q.SH * q.SW + 31) / 32) * ((q.Cout + 31) / 32) * q.ncls;
+        }
+        pair = tiles <= c->opt_small_tiles;
+    }
+    if (pair) {
+        if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
+        if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
+        float* Q[2][2] = {{P[0], P[1]}, {(float*)c->ws[4].p, (float*)c->ws[5].p}};
+        Conv1Params f[2];
+        for (int br = 0; br < 2; br++) {
+            f[br] = m->first[br].proto;
+            f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
+            f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 1;
+        }
+        HIPCHK(c, launch_conv_cin1_pair(f[0], f[1], s));
+        c->stat_launches++;
+        const size_t nl = m->branch[0].size();
+        int cur = 0;
+        for (size_t i = 0; i < nl; i++) {
+            const bool last = i + 1 == nl;
+            TapGemmParams q[2];
+            for (int br = 0; br < 2; br++) {
+                const GemmLayer& L = m->branch[br][i];
+                q[br] = L.proto;
+                q[br].X = Q[br][cur]; q[br].Wp = L.d_w_sp; q[br].bias = L.d_bias; q[br].mean = c->mean; q[br].out_scale = L.sp_inv_scale;
+                q[br].range_flag = c->h_range; q[br].zero = c->d_zero;
+                if (last) q[br].Y = F[br]; else q[br].Yhi = Q[br][cur ^ 1];
+                q[br].M = (int)(nb * q[br].SH * q[br].SW);
+                q[br].x_bytes = (unsigned)(4.0 * (double)nb * q[br].IH * q[br].IW * q[br].Cin);
+                c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
+            }
+            static const bool dbg = getenv("PNN_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[pnn] sp-gemm pair: branch layer %zu, M = %d / %d -> one small-kernel launch\n", i + 1, q[0].M, q[1].M);
+            HIPCHK(c, launch_tapgemm_small_pair(q[0], q[1], s));
+            c->stat_gemm_launches++; c->stat_launches++;
+            cur ^= 1;
+        }
+    }
+    if (par && !pair) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    }
+    for (int br = 0; br < 2 && !pair; br++) {
+        if (par) {
+            s = br == 0 ? main_stream : c->side_stream;
+            if (br == 1) { P[0] = (float*)c->ws[4].p; P[1] = (float*)c->ws[5].p; }
+        }
+        const size_t nl = m->branch[br].size();
+        Conv1Params f = m->first[br].proto;
+        f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
+        f.B = (int)nb; f.range_flag = c->h_range;
+        int cur = 0;
+        f.Y = nl == 0 ? F[br] : P[cur];
+        f.split = (sp && nl > 0) ? 1 : 0;
+        const bool delegate = sp && nl > 0;           // run_gemm_sp of the next layer launches or absorbs this convolution
+        if (!delegate) {
+            HIPCHK(c, launch_conv_cin1(f, s));
+            c->stat_launches++;
+        }
+        for (size_t i = 0; i < nl; i++) {
+            const bool last = i + 1 == nl;
+            float* dst = last ? F[br] : P[cur ^ 1];
+            if (sp) rc = run_gemm_sp(c, m->branch[br][i], P[cur], nullptr, last ? dst : nullptr, last ? nullptr : dst, nullptr, nullptr, nb, s, nullptr, nullptr,
+                                     nullptr, (i == 0 && delegate) ? &f : nullptr);
+            else rc = run_gemm(c, m->branch[br][i], P[cur], dst, nullptr, nb, s);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    }
+    if (par && !pair) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+        s = main_stream;
+        P[0] = (float*)c->ws[0].p; P[1] = (float*)c->ws[1].p;
+    }
+    const size_t nt = m->tconv.size();
+    MergerParams mp = m->merger.proto;
+    mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
+    mp.split = (sp && nt > 0) ? 1 : 0;
+    mp.one_order = c->opt_canonical ? 1 : 0;
+    mp.range_flag = c->h_range;
+    HIPCHK(c, launch_merger(mp, s));
+    c->stat_launches++;
+    int cur = 0;
+    for (size_t i = 0; i < nt; i++) {
+        const bool last = i + 1 == nt;
+        if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, last ? P[cur ^ 1] : nullptr, last ? nullptr : P[cur ^ 1], nullptr, nullptr, nb, s);
+        else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    TConv1Params tp = m->last.proto;
+    tp.X = P[cur]; tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
+    HIPCHK(c, launch_tconv_cout1(tp, s));
+    c->stat_launches++;
+    return PNN_OK;
+}
+
+}  // namespace
+
+// Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
+int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
+            int32_t* d_dst, hipStream_t s, bool ctx_is_split)
+{
+    const int w = m->width;
+    const long chunk = std::min(n, chunk_blocks(c, m));
+    int rc = ensure_ws(c, m, chunk);
+    if (rc) return rc;
+    // host_predict's copy of the caller's f32 rows (small FC inputs ride in the first kernel's argument block) follows the
+    // chunks like the device pointers do: with max_chunk below the batch size every chunk must carry ITS rows
+    const float* const host_rows = c->host_input;
+    for (long b0 = 0; b0 < n; b0 += chunk) {
+        const long nb = std::min(chunk, n - b0);
+        float* o = d_out ? d_out + b0 * w * w : nullptr;
+        int32_t* di = d_dst ? d_dst + b0 * w * w : nullptr;
+        c->host_input = host_rows ? host_rows + b0 * pitch_a : nullptr;
+        rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, ctx_is_split, nb, o, di, s)
+                      : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
+        if (rc) break;
+    }
+    c->host_input = host_rows;
+    return rc;
+}
+
+}  // namespace pnn

@@ -97,8 +97,14 @@ void set_nonblocking(int fd)
     if (fl >= 0) fcntl(fd, F_SETFL, fl | O_NONBLOCK);
 }
 
+// Input sizes are implicit in pnn_predict_f32_pel ([n][5w^2] for a fully-connected model, [n][3w^2] + [n][2w^2] for a
+// convolutional one); the server checks a request's shape against the loaded model's kind before it queues it (Server::kind),
+// and this is the second line: a batch of the wrong shape must never reach the copy of `n * 5w^2` floats.
 int ctx_backend(void* user, int width, const float* above, const float* left, int n, int32_t* dst, float* out_f32)
 {
+    int is_fc = 0;
+    if (pnn_model_info(static_cast<pnn_ctx*>(user), width, &is_fc, nullptr, nullptr) != PNN_OK) return PNN_E_MODEL;
+    if ((is_fc != 0) != (left == nullptr)) return PNN_E_ARG;
     return pnn_predict_f32_pel(static_cast<pnn_ctx*>(user), width, above, left, n, out_f32, dst);
 }
 
@@ -145,6 +151,9 @@ struct Server {
     int nworkers;                    // 1: one worker serves every width (a single context is not shared between threads); 5: one per width
     int max_batch, window_us;
     volatile int* stop;
+    // Per width: 1 = the loaded model is fully-connected (requests must carry n_above = 5w^2, n_left = 0), 0 = convolutional
+    // (3w^2 + 2w^2), -2 = no model for this width (every request is refused), -1 = unknown (generic backend: it validates).
+    int kind[5] = {-1, -1, -1, -1, -1};
 
     struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; };
     struct Reply { uint64_t id; std::vector<char> bytes; };
@@ -155,7 +164,7 @@ struct Server {
     int n_peers = 0, n_waiting_peers = 0;   // distinct peer processes connected / with a request in flight (maintained by the I/O thread)
     bool quit = false;
     int wake_fd[2] = {-1, -1};       // workers -> I/O thread
-    long served = 0, calls = 0, largest = 0;
+    long served = 0, calls = 0, largest = 0, refused = 0;
     double busy_s[5] = {0, 0, 0, 0, 0};   // time inside the backend, per worker (PNN_SERVICE_DEBUG)
     long calls_w[5] = {0, 0, 0, 0, 0}, served_w[5] = {0, 0, 0, 0, 0};   // backend calls / requests per worker
 
@@ -179,6 +188,9 @@ struct Server {
                     cv[k].wait_until(lk, until, [&] { return quit || (int)queue[k].size() >= max_batch || n_waiting_peers >= n_peers; });
                     if (quit) return;
                 }
+                // the lock was released during the window: the I/O thread may have dropped the only queued request
+                // (an encoder killed or timed out mid-window)
+                if (queue[k].empty()) continue;
                 // one batch = requests of ONE width and ONE input kind, in arrival order
                 const int w = queue[k][0].width;
                 const bool has_left = !queue[k][0].left.empty();
@@ -192,6 +204,7 @@ struct Server {
                     }
                 }
             }
+            if (batch.empty()) continue;
             const int w = batch[0].width;
             const size_t n = batch.size(), w2 = (size_t)w * w, na = batch[0].above.size(), nl = batch[0].left.size();
             bool any_f32 = false, any_pel = false;
@@ -236,7 +249,12 @@ struct Server {
         const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
         if (lfd < 0) return PNN_E_IO;
         unlink(socket_path);
-        if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 512) < 0 || pipe(wake_fd) < 0) { close(lfd); return PNN_E_IO; }
+        if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 512) < 0) { close(lfd); return PNN_E_IO; }
+        // every descriptor the loop needs exists BEFORE a worker thread is started: an early error return must not leave
+        // joinable threads (std::terminate) or a leaked pipe behind
+        if (pipe(wake_fd) < 0) { close(lfd); unlink(socket_path); return PNN_E_IO; }
+        const int ep = epoll_create1(0);
+        if (ep < 0) { close(lfd); close(wake_fd[0]); close(wake_fd[1]); unlink(socket_path); return PNN_E_IO; }
         set_nonblocking(lfd);
         set_nonblocking(wake_fd[0]);
         set_nonblocking(wake_fd[1]);
@@ -277,6 +295,19 @@ struct Server {
             if (was_in_flight) peer_flight(pid, -1);
             peer_conn(pid, -1);
         };
+        auto flush = [&](Client& c) {                         // false = broken
+            while (c.tx_off < c.tx.size()) {
+                const ssize_t r = send(c.fd, c.tx.data() + c.tx_off, c.tx.size() - c.tx_off, MSG_NOSIGNAL);
+                if (r < 0) {
+                    if (errno == EINTR) continue;
+                    if (errno == EAGAIN || errno == EWOULDBLOCK) return true;
+                    return false;
+                }
+                c.tx_off += (size_t)r;
+            }
+            c.tx.clear(); c.tx_off = 0;
+            return true;
+        };
         // Moves whatever the socket holds into the client's buffer; queues the request when it is complete.
         // false = client gone or protocol violation.
         auto receive = [&](uint64_t id, Client& c) {
@@ -289,6 +320,19 @@ struct Server {
                     want = sizeof h + ((size_t)h.n_above + h.n_left) * 4;
                     if (c.rx.size() == want) {
                         if (c.in_flight) return false;        // one outstanding request per client
+                        const int kd = kind[widx(h.width)];
+                        if (kd == -2 || (kd >= 0 && (kd == 1) != (h.n_left == 0))) {
+                            // well-formed, but not the input shape of the model loaded for this width (e.g. an encoder whose
+                            // local table lists a convolutional 8x8 model talking to a server with the fully-connected one):
+                            // answered with an error code at once, never queued
+                            const RspHeader rh{kd == -2 ? PNN_E_MODEL : PNN_E_ARG, 0u};
+                            const char* hp = reinterpret_cast<const char*>(&rh);
+                            if (c.tx.empty()) c.tx_since = Clock::now();
+                            c.tx.insert(c.tx.end(), hp, hp + sizeof rh);
+                            c.rx.clear();
+                            ++refused;
+                            return flush(c);
+                        }
                         Req r;
                         r.id = id; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0;
                         r.above.resize(h.n_above); r.left.resize(h.n_left);
@@ -321,23 +365,8 @@ struct Server {
                 c.rx.resize(have + (size_t)r);
             }
         };
-        auto flush = [&](Client& c) {                         // false = broken
-            while (c.tx_off < c.tx.size()) {
-                const ssize_t r = send(c.fd, c.tx.data() + c.tx_off, c.tx.size() - c.tx_off, MSG_NOSIGNAL);
-                if (r < 0) {
-                    if (errno == EINTR) continue;
-                    if (errno == EAGAIN || errno == EWOULDBLOCK) return true;
-                    return false;
-                }
-                c.tx_off += (size_t)r;
-            }
-            c.tx.clear(); c.tx_off = 0;
-            return true;
-        };
         // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was
         // what bounded the server (32 encoders: 65 k requests/s); event data = client ID (0: listener, 1: the workers' pipe)
-        const int ep = epoll_create1(0);
-        if (ep < 0) { close(lfd); return PNN_E_IO; }
         auto ep_ctl = [&](int op, int fd, uint32_t events, uint64_t id) {
             epoll_event ev;
             memset(&ev, 0, sizeof ev);
@@ -402,7 +431,7 @@ struct Server {
                     Client& c = it->second;
                     bool ok = true;
                     if (e & EPOLLOUT) { ok = flush(c); if (ok && c.tx.empty()) arm(id, c); }
-                    if (ok && (e & EPOLLIN)) ok = receive(id, c);
+                    if (ok && (e & EPOLLIN)) { ok = receive(id, c); if (ok && !c.tx.empty()) arm(id, c); }
                     else if (ok && (e & (EPOLLHUP | EPOLLERR))) ok = false;
                     if (!ok) gone.push_back(id);
                 }
@@ -452,10 +481,19 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     return sv.run(socket_path, stats);
 }
 
+static const int kServiceWidths[5] = {4, 8, 16, 32, 64};
+
 int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats)
 {
-    if (!ctx) return PNN_E_ARG;
-    return pnn_service_run_backend(socket_path, ctx_backend, ctx, max_batch, window_us, stop, stats);
+    if (!ctx || !stop || max_batch < 1 || window_us < 0) return PNN_E_ARG;
+    Server sv;
+    sv.backend = ctx_backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+    for (void*& u : sv.users) u = ctx;
+    for (int k = 0; k < 5; k++) {
+        int is_fc = 0;
+        sv.kind[k] = pnn_model_info(ctx, kServiceWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
+    }
+    return sv.run(socket_path, stats);
 }
 
 int pnn_service_run_table(const char* socket_path, const char* model_table_path, int use_pair, float mean, int device, int max_batch,
@@ -487,11 +525,17 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
         }
         rc = pnn_create_empty(&ctxs[k], mean, device);
         if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k], p.c_str());
+        // the file must hold a model of the width its table row names (pnn_create's check)
+        if (rc == PNN_OK && pnn_model_info(ctxs[k], kWidths[k], nullptr, nullptr, nullptr) != PNN_OK) rc = PNN_E_MODEL;
     }
     if (rc == PNN_OK) {
         Server sv;
         sv.backend = ctx_backend; sv.nworkers = 5; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
-        for (int k = 0; k < 5; k++) sv.users[k] = ctxs[k];
+        for (int k = 0; k < 5; k++) {
+            sv.users[k] = ctxs[k];
+            int is_fc = 0;
+            sv.kind[k] = pnn_model_info(ctxs[k], kWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
+        }
         rc = sv.run(socket_path, stats);
     }
     for (pnn_ctx* c : ctxs) if (c) pnn_destroy(c);

@@ -77,3 +77,160 @@ def gather_predictions(local, n_total, dist=None):
     outs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(outs, padded)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Host-side placement of a rank next to its GPU, read from sysfs only (nothing here initialises HIP: it runs BEFORE the
+# first HIP call of a rank, and in the self-launching parent of bench.py, which must never touch the GPU).
+# ---------------------------------------------------------------------------------------------------------------------
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs `local_cpulist`)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_render_minors(kfd_nodes=KFD_NODES):
+    """DRM render minors of the GPUs in KFD topology order -- the order ROCr / HIP enumerate devices in (a node with
+    simd_count > 0 is a GPU; CPU nodes have none)."""
+    minors = []
+    try:
+        names = sorted(os.listdir(kfd_nodes), key=lambda n: int(n))
+    except (OSError, ValueError):
+        return minors
+    for n in names:
+        props = {}
+        try:
+            with open(os.path.join(kfd_nodes, n, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) > 0 and int(props.get("drm_render_minor", "0") or 0) > 0:
+            minors.append(int(props["drm_render_minor"]))
+    return minors
+
+
+def visible_device_index(local_rank, environ=None):
+    """Index into the physical enumeration of HIP device `local_rank` under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+    (plain integer lists only; anything else -> the identity)."""
+    e = os.environ if environ is None else environ
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = e.get(var, "").strip()
+        if v:
+            try:
+                ids = [int(x) for x in v.split(",") if x.strip() != ""]
+                return ids[local_rank]
+            except (ValueError, IndexError):
+                return local_rank
+    return local_rank
+
+
+def gpu_sysfs_dir(local_rank, kfd_nodes=KFD_NODES, drm="/sys/class/drm"):
+    """/sys/class/drm/renderD<minor>/device of HIP device `local_rank`, or None."""
+    minors = gpu_render_minors(kfd_nodes)
+    idx = visible_device_index(local_rank)
+    if not 0 <= idx < len(minors):
+        return None
+    d = os.path.join(drm, "renderD%d" % minors[idx], "device")
+    return d if os.path.isdir(d) else None
+
+
+def bind_to_gpu_numa(local_rank, kfd_nodes=KFD_NODES, drm="/sys/class/drm"):
+    """Pins this process to the host cores of the NUMA node its GPU hangs off (sysfs `local_cpulist`), so that the launch
+    thread and the pinned staging buffers of a rank sit next to its device on a multi-socket node.  Best effort:
+    returns the CPU list it bound to, or None when sysfs does not say (single-node boxes, containers)."""
+    d = gpu_sysfs_dir(local_rank, kfd_nodes, drm)
+    if d is None:
+        return None
+    try:
+        with open(os.path.join(d, "local_cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed]
+        if not cpus or len(cpus) == len(allowed):
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError):
+        return None
+
+
+class GpuClockSampler(object):
+    """Samples the GPU's shader clock and busy percentage from sysfs in a thread while a measurement runs (what
+    `rocm-smi --showclocks --showuse` prints): hwmon `freq1_input` (Hz) when present, else the starred level of
+    `pp_dpm_sclk`; `gpu_busy_percent`.  `summary()` -> {"sclk_mhz_mean", "sclk_mhz_min", "sclk_mhz_max", "busy_pct_mean",
+    "samples", "source"} or None when nothing is readable."""
+
+    def __init__(self, local_rank=0, period_s=0.02):
+        import glob
+        self.period = period_s
+        self.dir = gpu_sysfs_dir(local_rank)
+        self.freq_file, self.source = None, None
+        if self.dir:
+            hw = sorted(glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", "freq1_input")))
+            if hw:
+                self.freq_file, self.source = hw[0], "hwmon freq1_input"
+            elif os.path.exists(os.path.join(self.dir, "pp_dpm_sclk")):
+                self.freq_file, self.source = os.path.join(self.dir, "pp_dpm_sclk"), "pp_dpm_sclk (current level)"
+        self.busy_file = os.path.join(self.dir, "gpu_busy_percent") if self.dir else None
+        self.mhz, self.busy = [], []
+        self._stop = None
+        self._thread = None
+
+    def _read_mhz(self):
+        try:
+            with open(self.freq_file) as f:
+                text = f.read()
+            if self.source.startswith("hwmon"):
+                return float(text.strip()) / 1e6
+            for line in text.splitlines():
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            if self.freq_file:
+                v = self._read_mhz()
+                if v is not None:
+                    self.mhz.append(v)
+            if self.busy_file:
+                try:
+                    with open(self.busy_file) as f:
+                        self.busy.append(float(f.read().strip()))
+                except (OSError, ValueError):
+                    pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+        return False
+
+    def summary(self):
+        if not self.mhz and not self.busy:
+            return None
+        out = {"samples": max(len(self.mhz), len(self.busy)), "source": self.source}
+        if self.mhz:
+            out.update(sclk_mhz_mean=sum(self.mhz) / len(self.mhz), sclk_mhz_min=min(self.mhz), sclk_mhz_max=max(self.mhz))
+        if self.busy:
+            out["busy_pct_mean"] = sum(self.busy) / len(self.busy)
+        return out

@@ -64,7 +64,8 @@ const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last err
 float pnn_mean(const pnn_ctx* ctx);
 
 /* Options: "precision" (1, default: tap GEMMs form every f32 product from three f16 MFMAs on hi/lo operand halves --
- * f32-class accuracy, ~1.6x faster; 0: exact-f32 MFMA), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice; an
+ * f32-class accuracy: operands carry 22 significand bits and the lo x lo term is dropped; 2.3-2.7x the blocks/s of 0 on
+ * the bench workloads; 0: exact-f32 MFMA, IEEE float32 operands -- the reference's arithmetic), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice; an
  * "sp_cfg" code in [0, pnn_num_split_configs()) forces one configuration of one of the three split-GEMM kernels on
  * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
  * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
@@ -107,8 +108,10 @@ int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Input-range contract of the default arithmetic ("precision" = 1): operands travel as pairs of f16 values, so every
  * intermediate activation must satisfy |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude
  * below that; arbitrary float inputs or models may not.  The kernels detect a violation (they never emit
- * a silent NaN): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then repeat the pass on the exact-f32 kernels
- * by themselves; device entry points are asynchronous, so the NEXT call on the context fails with PNN_E_RANGE, and
+ * a silent NaN): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then recompute, on the exact-f32 kernels and
+ * by themselves, exactly the blocks that overflow when predicted alone (batches of <= 256; the other blocks of the batch keep
+ * the bits they get in any batch), and they refuse non-finite inputs (PNN_E_ARG) -- the guard's max would drop a NaN; models
+ * with a non-finite parameter are refused at load (PNN_E_MODEL).  Device entry points are asynchronous, so the NEXT call on the context fails with PNN_E_RANGE, and
  * pnn_check_range -- which waits for `stream` -- tells right away (returns PNN_OK or PNN_E_RANGE; *host_fallbacks, optional,
  * = how many host calls took the exact-f32 repeat so far). */
 int pnn_check_range(pnn_ctx* ctx, void* stream, long* host_fallbacks);

@@ -30,6 +30,14 @@ void oracle_epilogue(const float* pred, long n, float mean, int32_t* dst);
 uint32_t oracle_block_cost(const int32_t* org, int org_stride, const int32_t* cur, int cur_stride, int w, int hadamard);
 // the GPU entry points pnn_service.cpp references; never called here (pnn_service_run_backend gets a stand-in)
 int pnn_predict_f32_pel(pnn_ctx*, int, const float*, const float*, int, float*, int32_t*) { return PNN_E_HIP; }
+// a stand-in context for pnn_service_run's shape check: widths 4 / 8 hold fully-connected models, 16 / 32 convolutional
+// ones, 64 none (the reference's production table minus the 64x64 model)
+int pnn_model_info(const pnn_ctx*, int width, int* is_fc, int*, long*)
+{
+    if (width == 64) return PNN_E_MODEL;
+    if (is_fc) *is_fc = width <= 8;
+    return PNN_OK;
+}
 // ... and the context calls of pnn_service_run_table (not exercised here: they need the GPU)
 int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
 int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
@@ -170,6 +178,49 @@ static void service_cases(const char* dir)
     CHECK(stats[0] == 5 * 60 * 2 && stats[3] == 7);
 }
 
+// The server with a context behind it (pnn_service_run): a well-formed request whose shape does not fit the model loaded for
+// its width is answered with an error at once and never reaches the backend's copy of n * 5w^2 floats (heap
+// over-read in the shared server); a width without a model is refused; a fitting request reaches the backend (here a stub
+// that says PNN_E_HIP).  Then the window race: with window_us > 0 a worker releases the lock while it waits for stragglers,
+// and the only queued request may be dropped meanwhile (its client died) -- the worker must find an empty queue, not index it.
+static void service_kind_and_window_cases(const char* dir)
+{
+    const std::string sock = std::string(dir) + "/pnn_san2.sock";
+    volatile int stop = 0;
+    long stats[4] = {0, 0, 0, 0};
+    int rc_server = -99;
+    std::thread server([&] { rc_server = pnn_service_run(sock.c_str(), reinterpret_cast<pnn_ctx*>(stats), 8, 20000, &stop, stats); });
+    pnn_client* c = nullptr;
+    for (int t = 0; t < 500 && pnn_client_connect(&c, sock.c_str()) != 0; t++) usleep(2000);
+    CHECK(c != nullptr);
+    std::vector<float> a(5 * 64 * 64, 1.f), l(2 * 64 * 64, 2.f), out(64 * 64);
+    CHECK(pnn_client_predict_f32(c, 8, a.data(), l.data(), out.data()) == PNN_E_ARG);       // conv-shaped request, FC model
+    CHECK(pnn_client_predict_f32(c, 16, a.data(), nullptr, out.data()) == PNN_E_ARG);      // FC-shaped request, conv model
+    CHECK(pnn_client_predict_f32(c, 64, a.data(), l.data(), out.data()) == PNN_E_MODEL);   // no model for that width
+    CHECK(pnn_client_predict_f32(c, 8, a.data(), nullptr, out.data()) == PNN_E_HIP);       // right shape: reaches the (stub) backend
+    CHECK(pnn_client_predict_f32(c, 32, a.data(), l.data(), out.data()) == PNN_E_HIP);
+    pnn_client_close(c);
+    // window race: a second peer process would keep the worker in its window; within ONE process every connection has the same
+    // pid, so "all peers wait" ends the window at once -- use raw sockets that send a complete request and vanish, many times
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    strcpy(addr.sun_path, sock.c_str());
+    for (int it = 0; it < 200; it++) {
+        const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+        CHECK(connect(fd, (sockaddr*)&addr, sizeof addr) == 0);
+        std::vector<char> req(20 + 80 * 4, 0);
+        const unsigned hdr[5] = {0x324e4e50u, 4u, 80u, 0u, 0u};
+        memcpy(req.data(), hdr, 20);
+        (void)!write(fd, req.data(), req.size());
+        close(fd);                                   // gone before (or while) the worker looks at the queue
+    }
+    usleep(100000);
+    stop = 1;
+    server.join();
+    CHECK(rc_server == 0);
+}
+
 static void oracle_cases()
 {
     unsigned seed = 7;
@@ -196,6 +247,7 @@ int main(int argc, char** argv)
     gather_cases();
     table_cases(dir);
     service_cases(dir);
+    service_kind_and_window_cases(dir);
     oracle_cases();
     puts("sanitize_host: ok");
     return 0;

@@ -3,7 +3,7 @@
 Tolerances: the nets compute in float32 on both sides but in different summation orders (MFMA k-chunks
 vs the oracle's sequential loops), so raw float predictions are compared with an absolute tolerance of
 2e-3 on values of magnitude up to ~300, and HM-epilogue outputs (uint8 range) within +-1 LSB -- the
-tolerance BASELINE.json states -- with at most 0.1 % of the pixels allowed to differ at all (exact .5
+tolerance BASELINE.json states -- with at most 0.02 % of the pixels allowed to differ at all (exact .5
 ties).  Gather outputs are integer-valued minus a constant: bit-exact.
 """
 import ctypes
@@ -35,7 +35,9 @@ def precision(request, monkeypatch):
 def _check_pel(got, want):
     diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
     assert diff.max() <= 1, "max |delta| = %d LSB" % diff.max()
-    assert (diff != 0).mean() <= 1e-3, "%.4f %% of pixels differ" % (100 * (diff != 0).mean())
+    # exact .5 ties only: the bench's own count is 13 of 262 144 pixels (0.005 %); 0.02 % so that a regression shows
+    # (+ one pixel, for cases of a few hundred pixels)
+    assert (diff != 0).sum() <= 2e-4 * diff.size + 1, "%.4f %% of pixels differ" % (100 * (diff != 0).mean())
 
 
 @pytest.mark.parametrize("w,n", [(4, 1), (4, 257), (8, 1), (8, 64), (8, 1000), (16, 33)])
@@ -690,7 +692,8 @@ def test_conv_branches_on_two_streams(pnn, oracle, w):
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 4096), (16, False, 1024)])
 def test_full_size_properties(pnn, oracle, w, is_fc, n):
     """configs[1] / configs[2] at full size: (1) a prediction does not depend on its batch position or on the batch
-    it travels in (chunked vs whole, permuted), (2) a random 64-block sample equals the oracle, (3) duplicated
+    it travels in (chunked vs whole, permuted), (2) the WHOLE batch equals the oracle (FC; a 256-block sample for the conv net,
+    whose oracle takes 50 ms per block), (3) duplicated
     inputs give identical outputs, (4) the fused gather+net+epilogue entry equals gather -> net -> epilogue."""
     import torch
     from context_adaptive_neural_network_based_prediction_amd import _lib
@@ -712,7 +715,7 @@ def test_full_size_properties(pnn, oracle, w, is_fc, n):
     net.set_option("canonical_order", 1)
     net.set_option("max_chunk", 0)
     assert np.array_equal(full[n // 2], full[3])
-    idx = np.random.RandomState(1).choice(n, 64, replace=False)
+    idx = np.arange(n) if is_fc else np.random.RandomState(1).choice(n, 256, replace=False)
     want = oracle.fc_forward(params, w, util.flatten_fc(above[idx], left[idx])) if is_fc else oracle.conv_forward(params, w, above[idx], left[idx])
     np.testing.assert_allclose(full[idx, ..., 0], want, rtol=0, atol=FLOAT_ATOL)
     plane = util.make_plane(544, 960, seed=5, pad=32)
@@ -726,8 +729,70 @@ def test_full_size_properties(pnn, oracle, w, is_fc, n):
     got = d_dst.cpu().numpy()
     assert got.min() >= 0 and got.max() <= 255 and got.min() == 0 and got.max() == 255
     assert np.array_equal(got, oracle.epilogue(d_f32.cpu().numpy(), util.MEAN))   # epilogue fused == epilogue applied after
-    sample = idx[:32]
+    sample = idx if is_fc else idx[:128]
     _check_pel(got[sample], oracle.predict_tbs(params, w, is_fc, plane, xs[sample], ys[sample], flags[sample], util.MEAN))
+
+
+def test_chunked_host_calls_carry_their_own_rows(pnn, oracle, precision):
+    """with max_chunk below the batch size, every chunk of a host call through an FC net must be predicted
+    from ITS rows -- the inline copy of small inputs (first kernel's argument block) used to stay on the first chunk's."""
+    for w, chunk, n in ((4, 1, 3), (4, 2, 7), (8, 1, 3)):
+        params = util.make_params(w, True, 31, out_gain=util.out_gain(w, True))
+        above, left = util.make_contexts(w, n, 32 + w)
+        ctx = util.flatten_fc(above, left)
+        net = pnn.PredictionNeuralNetwork(n, w, True, params=params)
+        whole = net.predict(ctx)
+        net.set_option("max_chunk", chunk)
+        got = net.predict(ctx)
+        assert np.array_equal(got, whole)
+        np.testing.assert_allclose(got[..., 0], oracle.fc_forward(params, w, ctx), rtol=0, atol=FLOAT_ATOL)
+        assert not np.array_equal(got[0], got[1])
+        net.close()
+
+
+@pytest.mark.parametrize("w,is_fc,n", [(8, True, 6), (16, False, 5), (64, False, 3)])
+def test_range_fallback_touches_only_the_overflowing_block(pnn, oracle, precision, w, is_fc, n):
+    """one block of a host batch leaves the f16 range -- only THAT block is recomputed on the exact-f32
+    kernels; the others keep, bit for bit, what they get alone or in any other batch (the batching service's promise)."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, is_fc, 91, out_gain=util.out_gain(w, is_fc)).copy()
+    specs = wts.tensor_specs(w, is_fc)
+    offs = np.concatenate([[0], np.cumsum([int(np.prod(sh)) for _, sh, _ in specs])])
+    gain = 300.0 if is_fc else 3000.0                              # ordinary contexts stay below 65504 ...
+    params[offs[0]:offs[2]] *= gain
+    params[offs[-3]:offs[-2]] /= gain
+    above, left = util.make_contexts(w, n, 92, masked_fraction=0.0)
+    bad = n // 2
+    above[bad] *= 40.0                                              # ... this one does not
+    left[bad] *= 40.0
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    fb = ctypes.c_long()
+    alone = []
+    for i in range(n):
+        alone.append(run(above[i:i + 1], left[i:i + 1])[0])
+        assert L.pnn_check_range(net.ctx, None, ctypes.byref(fb)) == 0
+        assert fb.value == (1 if i >= bad else 0), "only block %d was meant to leave the f16 range" % bad
+    batch = run(above, left)
+    assert L.pnn_check_range(net.ctx, None, ctypes.byref(fb)) == 0 and fb.value == 2
+    assert np.isfinite(batch).all()
+    for i in range(n):
+        assert np.array_equal(batch[i], alone[i]), "block %d changed because block %d overflowed" % (i, bad)
+    want = oracle.fc_forward(params, w, util.flatten_fc(above, left)) if is_fc else oracle.conv_forward(params, w, above, left)
+    np.testing.assert_allclose(batch[..., 0], want, rtol=0, atol=FLOAT_ATOL * 40)
+    # non-finite inputs are refused, non-finite parameters too (the guard's max would drop a NaN)
+    a2 = above.copy()
+    a2[0, 0, 0] = np.nan
+    with pytest.raises(_lib.PnnError):
+        run(a2, left)
+    p2 = params.copy()
+    p2[5] = np.inf
+    with pytest.raises(_lib.PnnError):
+        pnn.PredictionNeuralNetwork(1, w, is_fc, params=p2)
+    net.close()
 
 
 @pytest.mark.parametrize("w,is_fc,big", [(4, True, 1500), (8, True, 2048), (4, False, 700), (8, False, 600), (16, False, 200), (32, False, 40),
@@ -825,11 +890,13 @@ def test_python_evaluator_real_weights(pnn, oracle):
         evaluation.compute_psnr(img.astype(np.float32), img)
 
 
-def test_bench_two_ranks_on_one_gpu(precision, tmp_path):
-    """bench.py's N > 1 path end to end on the hardware that is there: `python -m torch.distributed.run --nproc-per-node 2
-    bench.py --gpus 2` with PNN_BENCH_SHARE_GPU=1 (both ranks on device 0, joined over gloo -- RCCL refuses two ranks on one
-    device): rank / world plumbing, per-rank workloads, barriers, the max-over-ranks clock, ONE JSON line from rank 0 whose
-    value counts both ranks' blocks.  A plumbing check, not a measurement (the driver measures real multi-GPU scaling)."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_on_one_gpu(precision, tmp_path, launcher):
+    """bench.py's N > 1 path end to end on the hardware that is there, with PNN_BENCH_SHARE_GPU=1 (both ranks on device 0,
+    joined over gloo -- RCCL refuses two ranks on one device): rank / world plumbing, per-rank workloads, barriers, staggered
+    autotune, the max-over-ranks clock, ONE JSON line from rank 0 whose value counts both ranks' blocks.
+    `self`: plain `python bench.py --gpus 2` -- the parent starts its own ranks as a child process (what the driver's SCALE
+    step may run); `torchrun`: the launcher form of the contract.  A plumbing check, not a measurement."""
     import json
     import subprocess
     import sys
@@ -837,10 +904,12 @@ def test_bench_two_ranks_on_one_gpu(precision, tmp_path):
         pytest.skip("once is enough")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PNN_BENCH_SHARE_GPU="1", PNN_AUTOTUNE="0")
-    env.pop("PNN_PRECISION", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "1024"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    for k in ("PNN_PRECISION", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "1024", "--no-sustained"]
+    head = [sys.executable] if launcher == "self" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                         "--master-addr", "127.0.0.1", "--master-port", "29611"]
+    r = subprocess.run(head + tail, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                                  # rank 0 only
@@ -848,7 +917,7 @@ def test_bench_two_ranks_on_one_gpu(precision, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 10
     assert d["config"]["batch_per_gpu"] == 1024
     assert abs(d["value"] - 2 * 1024 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]   # whole-job blocks over the slowest rank's time
-    assert d["cpu_baseline"] is None and "f32_exact" not in d       # the extras are N = 1 only
+    assert d["cpu_baseline"] is None and "reference_arithmetic" not in d       # the extras are N = 1 only
 
 
 @pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (8, False), (16, False), (32, False)])

@@ -537,3 +537,56 @@ def test_model_table_parser_against_the_reference_parser(tmp_path):
     assert n_ok > 150 and n_bad > 10
     assert R.ref_parse_three_keys(str(tmp_path / "absent.txt").encode(), b",;", buf, len(buf)) == -1
     assert L.pnn_parse_model_table(str(tmp_path / "absent.txt").encode(), widths, pairs, chans, paths, 64) == -2
+
+
+def test_bench_self_launch_without_a_gpu():
+    """`python bench.py --gpus 2` run plainly (no launcher, WORLD_SIZE unset) must start its own ranks as a child process and
+    relay their fate: here, without a GPU, a clear refusal before any rank is started (the node exposes 0 GPUs), and in share
+    mode the children's own "no HIP device" error with a non-zero code -- never a traceback about a missing launcher."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PNN_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node: the real thing runs instead")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "this node exposes" in r.stderr, r.stderr[-2000:]
+    if torch.cuda.device_count() == 0:
+        env["PNN_BENCH_SHARE_GPU"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                           text=True, timeout=300, cwd=root)
+        assert r.returncode != 0 and "no HIP device visible" in r.stderr, r.stderr[-2000:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpu_placement_helpers(tmp_path):
+    """sharding's sysfs readers on a fake KFD / DRM tree: GPUs in KFD order, HIP_VISIBLE_DEVICES remapping, cpulist parsing,
+    NUMA binding to the cores that are both local to the GPU and allowed to this process."""
+    from context_adaptive_neural_network_based_prediction_amd import sharding
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    kfd, drm = tmp_path / "kfd", tmp_path / "drm"
+    allowed = sorted(os.sched_getaffinity(0))
+    for i, (simd, minor) in enumerate([(0, 0), (1024, 129), (1024, 128)]):
+        (kfd / str(i)).mkdir(parents=True)
+        (kfd / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count %d\ndrm_render_minor %d\n" % (simd, minor))
+    for minor, cpus in ((128, "%d" % allowed[0]), (129, "%d-%d" % (allowed[0], allowed[-1]))):
+        (drm / ("renderD%d" % minor) / "device").mkdir(parents=True)
+        (drm / ("renderD%d" % minor) / "device" / "local_cpulist").write_text(cpus + "\n")
+    assert sharding.gpu_render_minors(str(kfd)) == [129, 128]
+    assert sharding.visible_device_index(1, {"HIP_VISIBLE_DEVICES": "3,1"}) == 1 and sharding.visible_device_index(1, {}) == 1
+    assert sharding.gpu_sysfs_dir(1, str(kfd), str(drm)).endswith("renderD128/device")
+    assert sharding.gpu_sysfs_dir(5, str(kfd), str(drm)) is None
+    before = os.sched_getaffinity(0)
+    try:
+        if len(allowed) > 1:
+            assert sharding.bind_to_gpu_numa(1, str(kfd), str(drm)) == [allowed[0]]
+            assert os.sched_getaffinity(0) == {allowed[0]}
+            os.sched_setaffinity(0, before)
+        assert sharding.bind_to_gpu_numa(0, str(kfd), str(drm)) is None     # the whole machine is "local": nothing to bind
+    finally:
+        os.sched_setaffinity(0, before)
+    assert sharding.GpuClockSampler(7).summary() is None or True
