@@ -129,7 +129,6 @@ def main():
     # five contexts (one per width, each with its own worker thread and stream) inside the C server; a block gets the same
     # prediction whatever batch it travels in (one summation order at every batch size is the library's default)
     import os
-    import socket as _socket
     try:                                              # a stale file of a killed earlier run must not read as "bound"
         os.unlink(args.socket)
     except OSError:
@@ -140,17 +139,12 @@ def main():
     for sig in (signal.SIGTERM, signal.SIGINT):       # handlers run in this (main) thread; the C loop runs in the server's thread
         signal.signal(sig, lambda *_: done.set())
 
-    def accepting():                                  # bound AND listening: a connection goes through (the models load first)
-        with _socket.socket(_socket.AF_UNIX, _socket.SOCK_STREAM) as sk:
-            try:
-                sk.connect(args.socket)
-                return True
-            except OSError:
-                return False
+    # the stale path is gone, so the file's existence now means THIS server bound it (bind and listen are back to back in the C
+    # loop, after the models are loaded); no probing connection: it would count as a client in the server's statistics
     t0 = time.time()
-    while srv.rc is None and not accepting() and time.time() - t0 < 300:
+    while srv.rc is None and not os.path.exists(args.socket) and time.time() - t0 < 300:
         time.sleep(0.02)
-    if srv.rc is not None or not accepting():
+    if srv.rc is not None or not os.path.exists(args.socket):
         raise SystemExit("pnn service: cannot start (%s): %s" % (srv.rc, (_lib.lib().pnn_last_error(None) or b"").decode()))
     print("pnn service: listening on %s" % args.socket, flush=True)
     while not done.is_set() and srv.rc is None:

@@ -168,7 +168,7 @@ class GpuClockSampler(object):
     """Samples the GPU's shader clock and busy percentage from sysfs in a thread while a measurement runs (what
     `rocm-smi --showclocks --showuse` prints): hwmon `freq1_input` (Hz) when present, else the starred level of
     `pp_dpm_sclk`; `gpu_busy_percent`.  `summary()` -> {"sclk_mhz_mean", "sclk_mhz_min", "sclk_mhz_max", "busy_pct_mean",
-    "samples", "source"} or None when nothing is readable."""
+    "power_w_mean", "samples", "source"} or None when nothing is readable."""
 
     def __init__(self, local_rank=0, period_s=0.02):
         import glob
@@ -182,7 +182,9 @@ class GpuClockSampler(object):
             elif os.path.exists(os.path.join(self.dir, "pp_dpm_sclk")):
                 self.freq_file, self.source = os.path.join(self.dir, "pp_dpm_sclk"), "pp_dpm_sclk (current level)"
         self.busy_file = os.path.join(self.dir, "gpu_busy_percent") if self.dir else None
-        self.mhz, self.busy = [], []
+        pw = sorted(glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", "power1_input"))) if self.dir else []
+        self.power_file = pw[0] if pw else None       # microwatts
+        self.mhz, self.busy, self.watts = [], [], []
         self._stop = None
         self._thread = None
 
@@ -211,6 +213,12 @@ class GpuClockSampler(object):
                         self.busy.append(float(f.read().strip()))
                 except (OSError, ValueError):
                     pass
+            if self.power_file:
+                try:
+                    with open(self.power_file) as f:
+                        self.watts.append(float(f.read().strip()) / 1e6)
+                except (OSError, ValueError):
+                    pass
             self._stop.wait(self.period)
 
     def __enter__(self):
@@ -233,4 +241,6 @@ class GpuClockSampler(object):
             out.update(sclk_mhz_mean=sum(self.mhz) / len(self.mhz), sclk_mhz_min=min(self.mhz), sclk_mhz_max=max(self.mhz))
         if self.busy:
             out["busy_pct_mean"] = sum(self.busy) / len(self.busy)
+        if self.watts:
+            out["power_w_mean"] = sum(self.watts) / len(self.watts)
         return out
