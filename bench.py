@@ -356,12 +356,39 @@ def self_launch(args):
     raise SystemExit(r.returncode if r.returncode or line else 1)
 
 
+def hm_campaigns(which, devices, quick=False):
+    """BASELINE.json configs[3] / configs[4] at their stated picture counts through the reference's own HM binaries
+    (tools/hm/campaign.py; built by __graft_entry__.build() where /root/reference exists, they travel with the tree).
+    Returns {name: record}; a missing binary or a failed run is recorded, never raised -- the kernel line must survive."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools", "hm"))
+    out = {}
+    try:
+        import campaign
+    except Exception as e:                            # noqa: BLE001
+        return {"error": "tools/hm/campaign.py not importable: %r" % (e,)}
+    if not campaign.binaries_present():
+        return {"error": "tools/hm/_build/*/TApp{Encoder,Decoder}Static are missing (built where /root/reference exists: `make -C tools/hm`)"}
+    for name in which:
+        work = tempfile.mkdtemp(prefix="pnn_bench_hm_")
+        try:
+            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None))
+        except Exception as e:                        # noqa: BLE001
+            out[name] = {"error": repr(e)[:2000]}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS) + ["hm_kodak", "hm_bsds"])
+    ap.add_argument("--no-hm", action="store_true", help="skip the configs[3] / configs[4] HM campaigns of the default N = 1 line")
+    ap.add_argument("--hm-quick", action="store_true", help=argparse.SUPPRESS)   # 4 pictures per campaign (plumbing tests)
     ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the reference_arithmetic / conv16 sub-measurements")
@@ -375,6 +402,21 @@ def main():
         return cpu_leg_worker(args.cpu_leg, args.workload, bool(args.leg_batch1), args.leg_threads, args.leg_budget)
 
     from context_adaptive_neural_network_based_prediction_amd import sharding
+    if args.workload.startswith("hm_"):
+        # configs[3] / configs[4]: whole encodes through the reference's HM binaries, one batching service per device; this
+        # process never touches the GPU (the services and the codecs are child processes)
+        name = args.workload[3:]
+        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick)
+        r = rec.get(name, rec)
+        ok = "error" not in r
+        print(json.dumps({
+            "metric": "pnn_intra_pred_blocks_per_s", "value": r["service"]["pnn_blocks_per_s_over_the_wall"] if ok else None, "unit": "blocks/s",
+            "n_gpus": args.gpus, "steps": 1, "warmup": 0, "ms_per_step": 1e3 * r["wall_s_all_encodes_and_decodes"] if ok else None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[1], "data": "synthetic",
+            "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign",
+                       "parallelism": "independent encodes dealt over one batching service per device, no collective"},
+            "hm": r, "roofline": None, "cpu_baseline": r.get("yardstick_hm_16_15_regular")}))
+        raise SystemExit(0 if ok else 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                     # before anything initialises HIP in this process
     import torch
@@ -447,6 +489,14 @@ def main():
         out["roofline"]["sustained"] = out["sustained"]
     if rank == 0 and single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_legs(wl)
+    if rank == 0 and single and not args.no_extras and not args.no_hm:
+        # BASELINE.json configs[3] / configs[4] at their stated counts (24 x 768x512 through hm_16_15_substitution, 100 x 480x320
+        # through hm_16_15_switch), after the kernel measurements: child processes only, ~30 s on the 256-core GPU box
+        out["hm"] = hm_campaigns(["kodak", "bsds"], [local_rank], args.hm_quick)
+        if isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"]["hm_16_15_regular"] = {k: v.get("yardstick_hm_16_15_regular") for k, v in out["hm"].items() if isinstance(v, dict)}
+            out["cpu_baseline"]["hm"] = {k: {kk: v.get(kk) for kk in ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
+                                                                     "every_decode_equals_its_encoder")} for k, v in out["hm"].items() if isinstance(v, dict)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -1,0 +1,185 @@
+"""BASELINE.json configs[3] / configs[4] at their stated picture counts, on the hardware that is there.
+
+    configs[3]  "Kodak 24-image first-frame encode via hm_16_15_substitution, CTU-row batched PNN on 1 GPU"
+                (comparing_rate_distortion.py:477-561, hevc/running.py:94-127): 24 pictures of 768 x 512, luminance only
+    configs[4]  "BSDS100 luminance encode via hm_16_15_switch, all widths 4-64, CTU rows sharded over 8 x MI355X"
+                (hevc/unifiedloading.py:71-76 crops 481 x 321 to 480 x 320): 100 pictures of 480 x 320
+
+The datasets are not in the reference checkout (download scripts, no network) and neither are the trained production models:
+seeded synthetic pictures (run_hm.make_frame) and seeded random-init models in the reference's five architectures stand in.
+Inside one encode the PNN calls are serially dependent, so the data-parallel axis is ACROSS encodes: one
+batching-service process per visible device, encodes dealt round-robin, all of them in flight up to the host-core count --
+replicas, no collective.  `hm_16_15_regular` (the reference's stock HM-16.15, CPU only) encodes the same
+pictures beside it as the yardstick.
+
+    python tools/hm/campaign.py --config kodak [--devices 0,1,...] [--pictures 24] [--in-flight N]
+
+Prints one JSON object: wall clock of all encodes + decodes, HM's own `Total Time` (CPU seconds, summed), PNN calls per width,
+cache rates, the services' request / call / batch statistics, PNN blocks per second through the services, and whether every
+decoded picture equals its encoder's reconstruction.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import run_hm  # noqa: E402
+
+CONFIGS = {
+    "kodak": {"variant": "substitution", "pictures": 24, "width": 768, "height": 512,
+              "baseline": "configs[3]: Kodak 24-image first-frame encode via hm_16_15_substitution"},
+    "bsds": {"variant": "switch", "pictures": 100, "width": 480, "height": 320,
+             "baseline": "configs[4]: BSDS100 luminance encode via hm_16_15_switch, all widths 4-64"},
+}
+
+
+def binaries_present(variants=("substitution", "switch", "regular")):
+    try:
+        for v in variants:
+            run_hm.exe(v, "Encoder"), run_hm.exe(v, "Decoder")
+        return True
+    except FileNotFoundError:
+        return False
+
+
+def _service_stats(stdout_text, stderr_text):
+    out = {}
+    m = re.search(r"(\d+) requests in (\d+) batched calls \(largest batch (\d+)\), (\d+) clients", stdout_text)
+    if m:
+        req, calls, largest, clients = map(int, m.groups())
+        out = {"requests": req, "backend_calls": calls, "largest_batch": largest, "mean_batch": round(req / max(calls, 1), 3), "clients": clients}
+    workers = {}
+    for m in re.finditer(r"worker (\d+): ([0-9.]+) s inside the backend, (\d+) calls \(([0-9.]+) us each\), (\d+) requests", stderr_text):
+        k = int(m.group(1))
+        workers[(4, 8, 16, 32, 64)[k]] = {"backend_busy_s": float(m.group(2)), "calls": int(m.group(3)), "us_per_call": float(m.group(4)),
+                                          "requests": int(m.group(5))}
+    if workers:
+        out["per_width"] = workers
+    return out
+
+
+def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800):
+    cfg = CONFIGS[config]
+    n = int(pictures or cfg["pictures"])
+    h, w, variant = cfg["height"], cfg["width"], cfg["variant"]
+    in_flight = int(in_flight or min(n, max(1, (os.cpu_count() or 8) - 2 * len(devices))))
+    os.makedirs(work, exist_ok=True)
+    table, mean_path = run_hm.make_models(os.path.join(work, "models"))
+    frames = [run_hm.make_frame(h, w, seed + j) for j in range(n)]
+    servers, socks = [], []
+    t_start = time.time()
+    for k, dev in enumerate(devices):
+        sock = os.path.join(work, "pnn%d.sock" % k)
+        env = dict(os.environ, PNN_SERVICE_DEBUG="1")
+        servers.append(subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
+                                         "--table", table, "--device", str(dev), "--max-batch", "256", "--window-us", "0"], cwd=ROOT, env=env,
+                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        socks.append(sock)
+    results, stats = [], []
+    try:
+        for srv in servers:
+            line = srv.stdout.readline()
+            if "listening" not in line:
+                raise RuntimeError("batching service did not start: %s %s" % (line, srv.stderr.read()[-2000:]))
+        t_up = time.time() - t_start
+
+        def job(j):
+            return run_hm.encode_decode(variant, frames[j], qp, table, mean_path, os.path.join(work, "enc"), tag=str(j),
+                                        env={"PNN_SERVICE_SOCKET": socks[j % len(socks)]}, timeout=timeout)
+        t0 = time.time()
+        with ThreadPoolExecutor(in_flight) as ex:
+            results = list(ex.map(job, range(n)))
+        wall = time.time() - t0
+    finally:
+        for srv in servers:
+            srv.terminate()
+        for srv in servers:
+            try:
+                so, se = srv.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                srv.kill()
+                so, se = srv.communicate()
+            stats.append(_service_stats(so or "", se or ""))
+    calls = {}
+    for side in ("enc_pnn", "dec_pnn"):
+        for wd in (4, 8, 16, 32, 64):
+            runs = sum(r[side].get(wd, {}).get("runs", 0) for r in results)
+            hits = sum(r[side].get(wd, {}).get("cache_hits", 0) for r in results)
+            calls.setdefault(side, {})[wd] = {"session_run_calls": runs, "cache_hits": hits, "cache_rate": round(hits / max(runs, 1), 4)}
+    requests = sum(s.get("requests", 0) for s in stats)
+    backend_calls = sum(s.get("backend_calls", 0) for s in stats)
+    busy = {}
+    for s in stats:
+        for wd, v in s.get("per_width", {}).items():
+            b = busy.setdefault(wd, {"backend_busy_s": 0.0, "calls": 0, "requests": 0})
+            b["backend_busy_s"] += v["backend_busy_s"]; b["calls"] += v["calls"]; b["requests"] += v["requests"]
+    for wd, b in busy.items():
+        b["blocks_per_s_inside_backend"] = round(b["requests"] / b["backend_busy_s"], 1) if b["backend_busy_s"] > 0 else None
+        b["mean_batch"] = round(b["requests"] / max(b["calls"], 1), 3)
+        b["backend_busy_s"] = round(b["backend_busy_s"], 3)
+    out = {
+        "config": cfg["baseline"], "variant": "hm_16_15_" + variant, "pictures": n, "picture_size": "%dx%d 4:0:0" % (w, h), "qp": qp,
+        "data": "seeded synthetic pictures + seeded random-init models (Kodak / BSDS and the trained production models are not in the reference checkout)",
+        "devices": list(devices), "services": len(devices), "encodes_in_flight": in_flight, "host_cores": os.cpu_count(),
+        "wall_s_all_encodes_and_decodes": round(wall, 3), "service_start_s": round(t_up, 3),
+        "pictures_per_s": round(n / wall, 3),
+        "hm_total_time_s_sum": {"encoders": round(sum(r["enc_total_time_s"] or 0 for r in results), 2),
+                                "decoders": round(sum(r["dec_total_time_s"] or 0 for r in results), 2),
+                                "note": "HM's clock(): CPU seconds of the process; time blocked on the service socket is not in it"},
+        "enc_wall_s": {"mean": round(sum(r["enc_wall_s"] for r in results) / n, 3), "max": max(r["enc_wall_s"] for r in results)},
+        "dec_wall_s": {"mean": round(sum(r["dec_wall_s"] for r in results) / n, 3), "max": max(r["dec_wall_s"] for r in results)},
+        "bits_total": int(sum(r["bits"] for r in results)), "psnr_rec_db_mean": round(sum(r["psnr_rec_db"] for r in results) / n, 3),
+        "pnn_calls": calls,
+        "service": {"requests": requests, "backend_calls": backend_calls, "mean_batch": round(requests / max(backend_calls, 1), 3),
+                    "largest_batch": max([s.get("largest_batch", 0) for s in stats] or [0]), "per_service": stats, "per_width": busy,
+                    "pnn_blocks_per_s_over_the_wall": round(requests / wall, 1)},
+        "every_decode_equals_its_encoder": bool(all(r["decoder_equals_encoder"] and not r["decoder_hash_error"] for r in results)),
+    }
+    if yardstick and binaries_present(("regular",)):
+        def ref_job(j):
+            return run_hm.encode_decode("regular", frames[j], qp, None, None, os.path.join(work, "reg"), tag=str(j), timeout=timeout)
+        t0 = time.time()
+        with ThreadPoolExecutor(in_flight) as ex:
+            reg = list(ex.map(ref_job, range(n)))
+        rw = time.time() - t0
+        out["yardstick_hm_16_15_regular"] = {
+            "what": "the reference's stock HM-16.15 (no PNN), CPU only, the same pictures, the same number in flight",
+            "wall_s_all_encodes_and_decodes": round(rw, 3), "pictures_per_s": round(n / rw, 3),
+            "hm_total_time_s_sum_encoders": round(sum(r["enc_total_time_s"] or 0 for r in reg), 2),
+            "enc_wall_s_mean": round(sum(r["enc_wall_s"] for r in reg) / n, 3), "bits_total": int(sum(r["bits"] for r in reg)),
+            "every_decode_equals_its_encoder": bool(all(r["decoder_equals_encoder"] for r in reg))}
+        out["wall_vs_regular"] = round(wall / rw, 3)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--config", default="kodak", choices=sorted(CONFIGS))
+    ap.add_argument("--devices", default="0")
+    ap.add_argument("--pictures", type=int, default=0)
+    ap.add_argument("--in-flight", type=int, default=0)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hm_campaign"))
+    args = ap.parse_args()
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp(prefix="hm_campaign_")
+    try:
+        res = run_campaign(args.config, work, [int(d) for d in args.devices.split(",")], args.pictures or None, args.in_flight or None, args.qp)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
