@@ -7,27 +7,32 @@ r=${1:-r01}
 out=gpurun_out/profiles_$r
 mkdir -p $out
 for wl in fc8 conv16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${wl}_trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-sustained > $out/${wl}_trace.log 2>&1
   python3 tools/trace_summary.py $out/${wl}_trace > $out/${wl}_kernel_summary.txt
   cp $out/${wl}_trace/*/*_kernel_stats.csv $out/${wl}_kernel_stats.csv
+  # the same on the exact-f32 kernels (the reference's arithmetic): the rocprof side of bench.py's `reference_arithmetic` roofline
+  PNN_PRECISION=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_f32_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-sustained > $out/${wl}_f32_trace.log 2>&1
+  python3 tools/trace_summary.py $out/${wl}_f32_trace > $out/${wl}_f32_kernel_summary.txt
+  cp $out/${wl}_f32_trace/*/*_kernel_stats.csv $out/${wl}_f32_kernel_stats.csv
+  rm -rf $out/${wl}_f32_trace
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $out/${wl}_pmc_p$i.log 2>&1
+    PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}/p$i -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-sustained > $out/${wl}_pmc_p$i.log 2>&1
   done
   python3 tools/pmc_summary.py $wl > $out/${wl}_pmc_summary.txt
   rm -rf $out/${wl}_trace
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE"; do          # HBM traffic of the exact-f32 kernels, its own passes
     i=$((i+1))
-    PNN_PRECISION=0 PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}_f32/p$((i+2)) -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $out/${wl}_f32_pmc_p$i.log 2>&1
+    PNN_PRECISION=0 PNN_AUTOTUNE=0 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_${wl}_f32/p$((i+2)) -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-sustained > $out/${wl}_f32_pmc_p$i.log 2>&1
   done
 done
 python3 tools/pmc_traffic.py $out/pmc_traffic.json fc8 conv16 fc8_f32 conv16_f32 > /dev/null
 for wl in fc8 conv16; do   # timeline of one steady-state step (rule-based tiles: no tuning launches in the trace)
-  PNN_AUTOTUNE=0 rocprofv3 --kernel-trace --output-format csv -d $out/${wl}_tl -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  PNN_AUTOTUNE=0 rocprofv3 --kernel-trace --output-format csv -d $out/${wl}_tl -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-sustained > /dev/null 2>&1
   python3 tools/trace_gaps.py $out/${wl}_tl > $out/${wl}_step_timeline.txt
   rm -rf $out/${wl}_tl
 done
