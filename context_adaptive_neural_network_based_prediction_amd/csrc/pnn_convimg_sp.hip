@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     if (p.X0) {
         // Fused first convolution of the branch: the maps are COMPUTED here from the raw f32 context (a few KB per image)
         // instead of being written by conv_cin1_kernel and read back (50 MB each way at batch 1024 for the 16x16 net).
-        // Same arithmetic as conv_cin1_kernel (acc = bias; acc += x * w over ky, kx; LeakyReLU; split), so the two paths
-        // agree bit for bit.  Scratch for the raw tiles = the weight staging area, free until the tap loop starts.
+        // Same arithmetic as conv_cin1_kernel's split path (FirstConv: MFMA chain over the taps, scale, bias, LeakyReLU, split),
+        // so the two paths agree bit for bit.  Scratch for the raw tiles = the weight staging area, free until the tap loop starts.
         float* raw = reinterpret_cast<float*>(Bs);
         const int K0 = p.k0, S0 = p.s0, IH0 = p.IH * S0, IW0 = p.IW * S0;
         const int PH = (p.IH - 1) * S0 + K0, PW = (p.IW - 1) * S0 + K0;
@@ -68,37 +68,50 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             raw[idx] = ((unsigned)iy < (unsigned)IH0 && (unsigned)ix < (unsigned)IW0) ? p.X0[((size_t)(img0 + li) * IH0 + iy) * IW0 + ix] : 0.f;
         }
         __syncthreads();
-        const int CG = p.Cin >> 2;
-        const int cg = tid % CG, ppi = 256 / CG;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.B0 + 4 * cg);
+        // The contraction over the taps on the matrix cores (FirstConv, pnn_device_common.h): a wave takes 32 staged pixels at a
+        // time, builds its operand from the raw tile, runs one MFMA chain per 32-channel column tile and writes scale / bias /
+        // LeakyReLU / split straight into the image slots.  (Until round 3: 25 dependent v_fma_f32 per output on the VALU, 12 k
+        // SIMD-cycles per image of the 16x16 net -- as much as this layer's own matrix work.)
         float amax0 = 0.f;                             // range guard (pnn_device_common.h)
-        auto conv0 = [&](auto k_tag) {                 // the k x k weights of this thread's four channels live in registers
+        auto conv0 = [&](auto k_tag) {
             constexpr int K = decltype(k_tag)::value;
-            f32x4 w[K * K];
+            const f32x4* wsp = reinterpret_cast<const f32x4*>(p.W0sp);
+            const int nct = p.Cin >> 5;
+            typename FirstConv<K>::W w0[2];             // first convolutions have 32 (stride 1) or 64 (stride 2) output channels
+            f32x4 bv0[2][4];
 #pragma unroll
-            for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W0 + (size_t)t * p.Cin + 4 * cg);
-            // (image, row, column) of this thread's pixel, advanced by ppi pixels per iteration without divisions: the index
-            // arithmetic was more than half of the ~250 instructions per pixel
-            int li = (tid / CG) / NPIN, oy, ox;
-            { const int q = tid / CG - li * NPIN; oy = q / p.IW; ox = q - oy * p.IW; }
-            for (int pix = tid / CG; pix < nimg * NPIN; pix += ppi) {
-                const float* xr = raw + li * PH * PW + (oy * S0) * PW + ox * S0;
-                f32x4 acc = bv;
+            for (int ct = 0; ct < 2; ct++) {
+                if (ct < nct) w0[ct] = FirstConv<K>::weights(wsp, p.Npad0, ct * 32 + l31, h);
 #pragma unroll
-                for (int ky = 0; ky < K; ky++)
+                for (int g = 0; g < 4; g++) bv0[ct][g] = *reinterpret_cast<const f32x4*>(p.B0 + (ct < nct ? ct * 32 + 8 * g + 4 * h : 0));
+            }
+            const int total = nimg * NPIN;
+            for (int rt0 = wave; rt0 * 32 < total; rt0 += 4) {
+                const int pix = rt0 * 32 + l31;
+                const bool valid = pix < total;
+                const int li = valid ? pix / NPIN : 0, q = valid ? pix - li * NPIN : 0;
+                const int oy = q / p.IW, ox = q - oy * p.IW;
+                FirstConv<K> fc;
+                fc.load(raw + li * PH * PW + (oy * S0) * PW + ox * S0, PW, h, valid);
 #pragma unroll
-                    for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
-                acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-                typedef f16x4 h4;
-                h4 hi, lo;
-                split4(acc, hi, lo);
-                amax0 = amax4(amax0, acc);
-                _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (cg >> 2) * 32 + (cg & 3) * 4;
-                *reinterpret_cast<h4*>(dst) = hi;
-                *reinterpret_cast<h4*>(dst + 16) = lo;
-                ox += ppi;
-                while (ox >= p.IW) { ox -= p.IW; ++oy; }
-                while (oy >= p.IH) { oy -= p.IH; ++li; }
+                for (int ct = 0; ct < 2; ct++) {
+                    if (ct >= nct) break;
+                    const f32x16 a0 = fc.tile(w0[ct]);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v = (f32x4){a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]} * p.scale0 + bv0[ct][g];
+                        v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                        f16x4 hi, lo;
+                        split4(v, hi, lo);
+                        if (valid) {
+                            amax0 = amax4(amax0, v);
+                            const int n = ct * 32 + 8 * g + 4 * h;
+                            _Float16* dst = reinterpret_cast<_Float16*>(Ai + pix * PITCH) + (n >> 4) * 32 + (n & 15);
+                            *reinterpret_cast<f16x4*>(dst) = hi;
+                            *reinterpret_cast<f16x4*>(dst + 16) = lo;
+                        }
+                    }
+                }
             }
         };
         if (K0 == 5) conv0(std::integral_constant<int, 5>{}); else conv0(std::integral_constant<int, 3>{});
@@ -401,7 +414,7 @@ bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, 
     const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
     const size_t scratch_floats = 2 * (size_t)t.kc * 4 * bn * 4;               // the weight staging area
     const size_t ph = (size_t)(p.IH - 1) * s0 + k0, pw = (size_t)(p.IW - 1) * s0 + k0;
-    return (k0 == 3 || k0 == 5) && p.Cin % 16 == 0 && 256 % (p.Cin / 4) == 0 && (size_t)G * ph * pw <= scratch_floats;
+    return (k0 == 3 || k0 == 5) && (p.Cin == 32 || p.Cin == 64) && (size_t)G * ph * pw <= scratch_floats;
 }
 
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)

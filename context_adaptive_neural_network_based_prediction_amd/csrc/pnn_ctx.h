@@ -52,7 +52,7 @@ struct GemmLayer {                                    // one tap-GEMM launch (al
     double k_total = 0;                               // sum over classes of taps * Cin
     long out_per_block = 0;                           // output floats per block
 };
-struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_bias = nullptr; long out_per_block = 0; };
+struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_w_sp = nullptr; float sp_inv_scale = 1.f; int npad = 0; float* d_bias = nullptr; long out_per_block = 0; };
 struct TConv1Layer { TConv1Params proto{}; float* d_w = nullptr; };
 struct MergerLayer { MergerParams proto{}; float* d_w = nullptr; float* d_bias = nullptr; };
 

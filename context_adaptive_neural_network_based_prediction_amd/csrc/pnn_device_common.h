@@ -104,6 +104,75 @@ __device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, i
     *reinterpret_cast<f16x4*>(dst + 16) = lo;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First convolution of a branch (Cin = 1, k x k taps, pnn/tfutils.py:75-139) on the split-precision path: a contraction
+// over the TAPS on the matrix cores.  out[pixel][co] = sum_t x[pixel, tap t] * W[t][co], t = ky * k + kx, K = k * k taps
+// zero-padded to a multiple of 16 (3 x 3: one 16-deep chunk, 5 x 5: two), operands split into f16 hi / lo halves and
+// multiplied as w_hi * x_hi, w_hi * x_lo, w_lo * x_hi per chunk -- the order of every split-precision GEMM kernel, so this IS
+// "the tap GEMM over the im2col rows of the context", computed without materialising them.  Used by conv_cin1_kernel /
+// conv_cin1_pair_kernel (split output) and by convimg_sp_kernel's fused first convolution: one definition, one summation
+// order at every batch size.  (Until round 3 the first convolution was 25 dependent v_fma_f32 per output on the VALU:
+// 12 k SIMD-cycles per 16x16-net image, as much as the matrix work of the layer it feeds.)
+// Weights: the layer's [K][Cout] matrix in the split pack of the GEMM layers, [chunk][hi / lo][k-half][Npad][8 x f16],
+// pre-scaled by a power of two that the caller undoes (out_scale).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int K>
+struct FirstConv {
+    static constexpr int NCH = (K * K + 15) / 16;
+    f16x8 xhi[NCH], xlo[NCH];
+    // This lane's operand: 8 taps (k-half h = lane >> 5) of each chunk for ITS pixel.  xr = the pixel's top-left tap in the
+    // zero-padded f32 plane (LDS or global), PW = the plane's row pitch; !valid (idle row of the tile) -> zeros.
+    __device__ __forceinline__ void load(const float* xr, int PW, int h, bool valid)
+    {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            f32x4 v[2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int t0 = 16 * c + j, t1 = t0 + 8;             // the tap of k-half 0 / 1
+                const int o0 = t0 < K * K ? (t0 / K) * PW + t0 % K : 0, o1 = t1 < K * K ? (t1 / K) * PW + t1 % K : 0;
+                const bool in = valid && (h ? t1 < K * K : t0 < K * K);
+                const float x = xr[h ? o1 : o0];
+                v[j >> 2][j & 3] = in ? x : 0.f;
+            }
+            f16x4 h0, l0, h1, l1;
+            split4(v[0], h0, l0);
+            split4(v[1], h1, l1);
+            xhi[c] = (f16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            xlo[c] = (f16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+    }
+    // Weight fragments of one 32-channel column tile: lane's channel n = tile * 32 + (lane & 31), k-half h.
+    struct W { f32x4 hi[NCH], lo[NCH]; };
+    static __device__ __forceinline__ W weights(const f32x4* __restrict__ wsp, int npad, int n, int h)
+    {
+        W w;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            w.hi[c] = wsp[((c * 2 + 0) * 2 + h) * npad + n];
+            w.lo[c] = wsp[((c * 2 + 1) * 2 + h) * npad + n];
+        }
+        return w;
+    }
+    // 32 pixels x 32 channels: acc[4 g + e] = channel tile * 32 + 8 g + 4 h + e of pixel (lane & 31), before scale / bias.
+    __device__ __forceinline__ f32x16 tile(const W& w) const
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const f16x8 whi = __builtin_bit_cast(f16x8, w.hi[c]), wlo = __builtin_bit_cast(f16x8, w.lo[c]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xhi[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xlo[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xhi[c], acc, 0, 0, 0);
+        }
+        return acc;
+    }
+};
+
 __device__ __forceinline__ void store_split1(void* base, size_t pixel_times_c, int n, float v, float& amax)
 {
     amax = fmaxf(amax, fabsf(v));

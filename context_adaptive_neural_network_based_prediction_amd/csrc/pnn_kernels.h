@@ -41,6 +41,7 @@ struct TapGemmParams {
     // SAME padding with pad0 before, LeakyReLU): X0 != NULL makes the kernel compute its input maps from the raw f32
     // context X0 [images][IH * s0][IW * s0] instead of reading them from X (see pnn_convimg_sp.hip)
     const float* X0; const float* W0; const float* B0; int s0, k0, pad0;
+    const float* W0sp; float scale0; int Npad0;   // the first convolution's taps x channels matrix in the split pack (FirstConv, pnn_device_common.h)
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
@@ -104,6 +105,7 @@ struct Conv1Params {
     int split;   // 1: write Y as split activations [pixel][Cout/16][hi 16 x f16 | lo 16 x f16] for the split-precision GEMM
     int band_rows;   // output rows per workgroup (set by the launcher)
     int* range_flag; // split output only: raised when a value leaves the f16 range
+    const float* Wsp; float out_scale; int npad;   // split output: the taps x channels matrix in the split pack of the GEMM layers, its inverse pre-scale, its Npad
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s);   // both branches in one launch (same batch, same kernel size)

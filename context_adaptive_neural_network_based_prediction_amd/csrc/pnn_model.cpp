@@ -242,6 +242,22 @@ int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n,
                     Conv1Layer& f = m->first[br];
                     rc = upload(c, m, p, nw, &f.d_w);
                     if (rc == PNN_OK) {
+                        // split-precision path: the k*k taps x ch matrix, rows zero-padded to whole 16-deep chunks, in the split
+                        // pack of the GEMM layers (max |w| scaled into [2^12, 2^13) so that hi and lo halves are f16-normal)
+                        const long krows = ((long)k * k + 15) / 16 * 16;
+                        std::vector<float> kn((size_t)krows * ch, 0.f);
+                        std::copy(p, p + nw, kn.begin());
+                        float wmax = 0.f;
+                        for (size_t q = 0; q < nw; q++) wmax = std::max(wmax, std::fabs(p[q]));
+                        int shift = 0;
+                        if (wmax > 0.f) { int e; std::frexp(wmax, &e); shift = 13 - e; }
+                        shift = std::max(-8, std::min(shift, 24));
+                        f.npad = npad_for(ch);
+                        f.sp_inv_scale = std::ldexp(1.f, -shift);
+                        const std::vector<float> sp = pack_kn_split(kn, krows, ch, f.npad, std::ldexp(1.f, shift));
+                        rc = upload(c, m, sp.data(), sp.size(), &f.d_w_sp);
+                    }
+                    if (rc == PNN_OK) {
                         std::vector<float> bias(ch + 4, 0.f);
                         std::copy(p + nw, p + nw + ch, bias.begin());
                         rc = upload(c, m, bias.data(), bias.size(), &f.d_bias);

@@ -154,6 +154,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
                 if (c->opt_fuse_first && convimg_sp_can_fuse_first(p, t, g, first->s, first->k)) {
                     TapGemmParams q = p;
                     q.X0 = first->X; q.W0 = first->W; q.B0 = first->bias; q.s0 = first->s; q.k0 = first->k; q.pad0 = first->pad;
+                    q.W0sp = first->Wsp; q.scale0 = first->out_scale; q.Npad0 = first->npad;
                     return launch_convimg_sp(q, code - nsp, g, s);
                 }
             }
@@ -399,6 +400,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         for (int br = 0; br < 2; br++) {
             f[br] = m->first[br].proto;
             f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
+            f[br].Wsp = m->first[br].d_w_sp; f[br].out_scale = m->first[br].sp_inv_scale; f[br].npad = m->first[br].npad;
             f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 1;
         }
         HIPCHK(c, launch_conv_cin1_pair(f[0], f[1], s));
@@ -437,6 +439,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         const size_t nl = m->branch[br].size();
         Conv1Params f = m->first[br].proto;
         f.X = br == 0 ? d_above : d_left; f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
+        f.Wsp = m->first[br].d_w_sp; f.out_scale = m->first[br].sp_inv_scale; f.npad = m->first[br].npad;
         f.B = (int)nb; f.range_flag = c->h_range;
         int cur = 0;
         f.Y = nl == 0 ? F[br] : P[cur];

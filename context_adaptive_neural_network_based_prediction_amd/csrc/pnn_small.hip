@@ -14,9 +14,10 @@ namespace pnn {
 
 // ------------------------------------------------------------------------------------------------
 // Cin == 1 forward convolution + bias + LeakyReLU (k = 3, stride 1 or k = 5, stride 2).
-// One workgroup per image: the zero-padded input plane sits in LDS (SAME padding becomes plain indexing),
-// each lane keeps its 4 output channels' k*k weights in registers, Cout/4 lanes share a pixel so a wave
-// stores 1 KiB (Cout 64) of contiguous NHWC output per instruction.  HBM-bound on the output write.
+// One workgroup per image (or band of output rows): the zero-padded input plane sits in LDS (SAME padding becomes plain
+// indexing).  f32 output (exact-f32 path): each lane keeps its 4 output channels' k*k weights in registers, Cout/4 lanes
+// share a pixel so a wave stores 1 KiB (Cout 64) of contiguous NHWC output per instruction.  Split output (the default
+// arithmetic): the contraction over the taps runs on the matrix cores, see FirstConv.  HBM-bound on the output write.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) Conv1Params CConv1;   // read in place in the kernel-argument segment: scalar loads
 template <int K>
@@ -35,6 +36,62 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
         const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
         xs[idx] = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
     }
+    const int npix = p.OH * p.OW;
+    if (p.split) {
+        // Split-precision path: the contraction over the taps on the matrix cores (FirstConv, pnn_device_common.h).  A wave
+        // takes 32 consecutive pixels of the band at a time: operand from the staged plane, one MFMA chain per 32-channel
+        // column tile, scale / bias / LeakyReLU / split, then through a wave-private LDS tile so that the 32 pixels leave as
+        // ONE contiguous run of 16-byte pieces (the accumulator layout owns 8-byte fragments of 32 different pixels).
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+        const int cq = p.Cout >> 2, PITCH = cq + 1, nct = p.Cout >> 5;
+        f32x4* stage = reinterpret_cast<f32x4*>(xs + ((PH * PW + 3) & ~3)) + wave * 32 * PITCH;
+        const f32x4* wsp = reinterpret_cast<const f32x4*>(p.Wsp);
+        typename FirstConv<K>::W w[2];
+        f32x4 bv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            if (ct < nct) w[ct] = FirstConv<K>::weights(wsp, p.npad, ct * 32 + l31, h);
+#pragma unroll
+            for (int g = 0; g < 4; g++) bv[ct][g] = *reinterpret_cast<const f32x4*>(p.bias + (ct < nct ? ct * 32 + 8 * g + 4 * h : 0));
+        }
+        const int band_pix = (oy1 - oy0) * p.OW;
+        float amax = 0.f;                            // range guard of the split output (pnn_device_common.h)
+        f32x4* yo = reinterpret_cast<f32x4*>(p.Y) + ((size_t)b * npix + (size_t)oy0 * p.OW) * cq;
+        for (int rt = wave; rt * 32 < band_pix; rt += 4) {
+            const int lp = rt * 32 + l31;
+            const bool valid = lp < band_pix;
+            const int ly = valid ? lp / p.OW : 0, lx = valid ? lp - ly * p.OW : 0;
+            FirstConv<K> fc;
+            fc.load(xs + (ly * p.s) * PW + lx * p.s, PW, h, valid);
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                if (ct >= nct) break;
+                const f32x16 acc = fc.tile(w[ct]);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} * p.out_scale + bv[ct][g];
+                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    if (valid) amax = amax4(amax, v);
+                    f16x4 hi, lo;
+                    split4(v, hi, lo);
+                    const int n = ct * 32 + 8 * g + 4 * h;
+                    _Float16* dst = reinterpret_cast<_Float16*>(stage + l31 * PITCH) + (n >> 4) * 32 + (n & 15);
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    *reinterpret_cast<f16x4*>(dst + 16) = lo;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();         // the tile is this wave's own: LDS keeps a wave's accesses in order
+            const int rows = band_pix - rt * 32 < 32 ? band_pix - rt * 32 : 32;
+            for (int i = lane; i < rows * cq; i += 64) {
+                const int row = i / cq, q = i - row * cq;
+                yo[(size_t)(rt * 32) * cq + i] = stage[row * PITCH + q];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        report_range(p.range_flag, amax);
+        return;
+    }
     const int CG = p.Cout >> 2;                       // lanes per pixel (8 or 16)
     const int cg = threadIdx.x % CG, psub = threadIdx.x / CG, ppi = 256 / CG;
     f32x4 w[K * K];
@@ -42,8 +99,6 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
     for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W + (size_t)t * p.Cout + 4 * cg);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
     __syncthreads();
-    const int npix = p.OH * p.OW;
-    float amax = 0.f;                                // range guard of the split output (pnn_device_common.h)
     float* yb = p.Y + b * npix * p.Cout;
     for (int pix = oy0 * p.OW + psub; pix < oy1 * p.OW; pix += ppi) {
         const int oy = pix / p.OW, ox = pix - oy * p.OW;
@@ -54,10 +109,8 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
 #pragma unroll
             for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
         acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-        if (p.split) store_split4(p.Y, ((size_t)b * npix + pix) * p.Cout, 4 * cg, acc, amax);
-        else *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
+        *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
     }
-    if (p.split) report_range(p.range_flag, amax);
 }
 
 template <int K>
@@ -89,8 +142,14 @@ static bool conv_cin1_bands(const Conv1Params& p, Conv1Params* q, int* bands_out
     while ((long)p.B * bands < 512 && bands * 2 <= p.OH) bands *= 2;
     q->band_rows = (p.OH + bands - 1) / bands;
     *bands_out = (p.OH + q->band_rows - 1) / q->band_rows;
-    *lds_out = (size_t)((q->band_rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) * sizeof(float);
-    return *lds_out <= 64 * 1024 && (p.Cout == 32 || p.Cout == 64) && (p.k == 3 || p.k == 5);
+    // staged plane (+ the split path's four wave-private output tiles of 32 pixels x (Cout / 4 + 1) 16-byte slots)
+    auto lds_of = [&](int rows) {
+        return ((size_t)((rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) + 3) / 4 * 16 + (p.split ? (size_t)4 * 32 * (p.Cout / 4 + 1) * 16 : 0);
+    };
+    while (lds_of(q->band_rows) > 64 * 1024 && q->band_rows > 1) q->band_rows = (q->band_rows + 1) / 2;
+    *bands_out = (p.OH + q->band_rows - 1) / q->band_rows;
+    *lds_out = lds_of(q->band_rows);
+    return *lds_out <= 64 * 1024 && (p.Cout == 32 || p.Cout == 64) && (p.k == 3 || p.k == 5) && (!p.split || p.Wsp);
 }
 
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s)

@@ -184,6 +184,13 @@ class GpuClockSampler(object):
         self.busy_file = os.path.join(self.dir, "gpu_busy_percent") if self.dir else None
         pw = sorted(glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", "power1_input"))) if self.dir else []
         self.power_file = pw[0] if pw else None       # microwatts
+        self.power_cap_w = None
+        if pw:
+            try:
+                with open(os.path.join(os.path.dirname(pw[0]), "power1_cap")) as f:
+                    self.power_cap_w = float(f.read().strip()) / 1e6
+            except (OSError, ValueError):
+                pass
         self.mhz, self.busy, self.watts = [], [], []
         self._stop = None
         self._thread = None
@@ -243,4 +250,5 @@ class GpuClockSampler(object):
             out["busy_pct_mean"] = sum(self.busy) / len(self.busy)
         if self.watts:
             out["power_w_mean"] = sum(self.watts) / len(self.watts)
+            out["power_cap_w"] = self.power_cap_w
         return out
