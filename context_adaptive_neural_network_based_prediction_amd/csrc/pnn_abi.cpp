@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 using namespace pnn;
 
@@ -89,6 +90,20 @@ int pending_range_error(pnn_ctx* c)
                                 "kernels (|v| >= 65504): its predictions are invalid; repeat it with pnn_set_option(ctx, \"precision\", 0)");
 }
 
+// End of a synchronous host call: wait for the context's stream.  hipStreamSynchronize parks the thread on the completion
+// signal (an interrupt and a wake-up: several microseconds on a 45 us call); HM's thread has nothing else to do, so it polls.
+int wait_stream(pnn_ctx* c, hipStream_t s)
+{
+    if (c->opt_spin_wait) {
+        hipError_t e;
+        while ((e = hipStreamQuery(s)) == hipErrorNotReady) {}
+        if (e != hipSuccess) return fail(c, PNN_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        return PNN_OK;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PNN_OK;
+}
+
 // A host pass left the f16 range of the split-precision kernels (*c->h_range raised, stream idle).  Only the blocks that
 // overflow ALONE are recomputed on the exact-f32 kernels; every other block keeps its split-precision result -- the value it
 // gets in any other batch (canonical_order) -- so one overflowing block behind the batching service does not change the last
@@ -156,6 +171,8 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
     if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
+    if (const char* e = getenv("PNN_FC_OUT")) c->opt_fc_out = atol(e);
+    if (const char* e = getenv("PNN_SPIN_WAIT")) c->opt_spin_wait = atol(e);
     if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
@@ -289,6 +306,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "small")) c->opt_small = value;
     else if (!strcmp(name, "small_max_tiles")) c->opt_small_tiles = value;
     else if (!strcmp(name, "pair")) c->opt_pair = value;
+    else if (!strcmp(name, "fc_out")) c->opt_fc_out = value;
+    else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
@@ -523,8 +542,19 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
             c->host_input = nullptr;
             return r;
         };
+        static const bool host_trace = getenv("PNN_HOST_TRACE") != nullptr;   // diagnostic: where a single-block call spends its time
+        timespec ht0, ht1, ht2;
+        if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht0);
         if ((rc = pass(0, n))) return rc;
-        HIPCHK(c, hipStreamSynchronize(s));
+        if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht1);
+        if ((rc = wait_stream(c, s))) return rc;
+        if (host_trace) {
+            clock_gettime(CLOCK_MONOTONIC, &ht2);
+            static double s_launch = 0, s_wait = 0; static long s_n = 0;
+            s_launch += (ht1.tv_sec - ht0.tv_sec) * 1e6 + (ht1.tv_nsec - ht0.tv_nsec) * 1e-3;
+            s_wait += (ht2.tv_sec - ht1.tv_sec) * 1e6 + (ht2.tv_nsec - ht1.tv_nsec) * 1e-3;
+            if (++s_n % 1000 == 0) { fprintf(stderr, "[pnn-host] width %d: %d launches enqueued in %.1f us, then %.1f us until the stream is idle (mean of 1000 calls)\n", w, c->stat_launches, s_launch / 1000, s_wait / 1000); s_launch = s_wait = 0; }
+        }
         if (*c->h_range && (rc = range_fallback(c, n, pass, s))) return rc;
         if (out) memcpy(out, p_out, (size_t)n * w2 * 4);
         if (dst) {

@@ -109,6 +109,11 @@ struct pnn_ctx {
     long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
     long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
     long opt_pair = 1;                                // 1: small conv passes run the same layer of both branches as ONE launch
+    // Two round-3 experiments on the single-block call, both bit-identical, both measured WITHOUT gain and therefore off by default
+    // (tools/batch1_latency.py, profiles/r03_batch1_latency.txt): the call's time is the chain of dependent
+    // launches on the device (~4 us each whatever they do) plus ~10 us of first-launch latency and completion hand-over.
+    long opt_fc_out = 0;                              // 1: small FC passes run the <= 64-output layer (K segments + reduction) as ONE launch (5 -> 4 launches)
+    long opt_spin_wait = 0;                           // 1: host calls poll the stream (hipStreamQuery) instead of blocking in hipStreamSynchronize
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
     std::map<std::pair<const void*, long>, int> tuned;

@@ -277,6 +277,105 @@ __global__ __launch_bounds__(256) void tapgemm_small_pair_kernel(const SmallArgs
     tapgemm_small_body<false, false>(*p, 0, r % gx, r / gx, bz);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Output layer of a fully-connected PNN with <= 64 outputs at small M, in ONE launch: K-segment partial sums AND their
+// reduction (what tapgemm_small_kernel's K-segment mode + fuse_reduce_kernel do in two launches, ~4 us of launch floor each:
+// a single-block FC call was 5 launches, 32.8 us of kernels).  One workgroup of 8 waves per 32-row tile; wave z owns K
+// segment z (SEG chunks, the fused ring layer's column tile) for both 32-column tiles: the same MFMA chain from a zero
+// accumulator -- chunks ascending, w_hi*a_hi, w_hi*a_lo, w_lo*a_hi -- so the partials are the bits of the two-launch path;
+// operands go global -> registers (a segment is 10 chunks: NPF of them in flight, no LDS ring, no barrier in the loop);
+// the partials meet in LDS and are added in segment order, scaled, biased and rounded exactly as fuse_reduce_kernel does.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct FcOutArgs { TapGemmParams p; int seg; };
+template <int SEG>
+__global__ __launch_bounds__(512) void fc_out_small_kernel(const FcOutArgs args)
+{
+    touch_kernargs<sizeof(FcOutArgs)>();
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) FcOutArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    CSmallParams& p = k->p;
+    __shared__ __attribute__((aligned(16))) float part[8][32][64];
+    constexpr int NPF = 5;                           // chunks in flight per wave: 6 x 16 bytes per lane each
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int z = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mblk = blockIdx.x * 32;
+    const int nchunks = p.Cin >> 4;
+    const int nseg = (nchunks + SEG - 1) / SEG;
+    const int nct = (p.Cout + 31) >> 5;
+    if (z < nseg) {
+        const int c0 = z * SEG, c1 = c0 + SEG < nchunks ? c0 + SEG : nchunks;
+        const int m = mblk + l31 < p.M ? mblk + l31 : p.M - 1;        // rows past M: any valid row, never stored
+        const f32x4* __restrict__ xa = reinterpret_cast<const f32x4*>(p.X) + (size_t)m * (p.Cin >> 2) + h;   // piece (chunk, hi, half h); lo: + 2
+        const f32x4* __restrict__ wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)h * p.Npad + l31;      // piece (chunk, hi, half h, column l31)
+        const size_t wchunk = (size_t)4 * p.Npad, wlo = (size_t)2 * p.Npad;
+        f32x4 fa[NPF][2], fw[NPF][2][2];
+        auto load = [&](int slot, int c) {
+            const int cc = c < c1 ? c : c1 - 1;
+            fa[slot][0] = xa[cc * 4];
+            fa[slot][1] = xa[cc * 4 + 2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                const int col = ct < nct ? ct * 32 : 0;
+                fw[slot][ct][0] = wg[cc * wchunk + col];
+                fw[slot][ct][1] = wg[cc * wchunk + wlo + col];
+            }
+        };
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[ct][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPF; i++) load(i, c0 + i);
+#pragma unroll
+        for (int i = 0; i < SEG; i++) {
+            const int slot = i % NPF;
+            if (c0 + i < c1) {
+                const f16x8 ahi = __builtin_bit_cast(f16x8, fa[slot][0]), alo = __builtin_bit_cast(f16x8, fa[slot][1]);
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) {
+                    const f16x8 whi = __builtin_bit_cast(f16x8, fw[slot][ct][0]), wl = __builtin_bit_cast(f16x8, fw[slot][ct][1]);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ahi, acc[ct], 0, 0, 0);
+                }
+            }
+            if (i + NPF < SEG) load(slot, c0 + i + NPF);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<f32x4*>(&part[z][l31][ct * 32 + 8 * g + 4 * h]) = (f32x4){acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+    }
+    __syncthreads();
+    // fuse_reduce_kernel's arithmetic, one thread per 4 consecutive columns of a row
+    const int mr = tid >> 4, n = (tid & 15) << 2;
+    const int mg = mblk + mr;
+    if (mg >= p.M || n >= p.Cout) return;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nseg; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][mr][n]);
+    const f32x4 v = sum * p.out_scale + *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
+    if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+}
+
+// p: the output layer as a one-tap GEMM (X = split activations [M][Cin], Wp = its split pack, bias, out_scale, mean, Y / Yi);
+// seg_chunks must be the K-segment length of the fused ring layer (10).  false: the layer does not fit this kernel.
+bool fc_out_small_fits(const TapGemmParams& p, int seg_chunks)
+{
+    const int nchunks = p.Cin >> 4;
+    return seg_chunks == 10 && p.ncls == 1 && p.SH * p.SW == 1 && p.Cout <= 64 && p.Cout % 4 == 0 && (nchunks + seg_chunks - 1) / seg_chunks <= 8 && p.M > 0;
+}
+
+hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s)
+{
+    if (!fc_out_small_fits(p, seg_chunks)) return hipErrorInvalidValue;
+    const FcOutArgs a{p, seg_chunks};
+    pnn_launch(fc_out_small_kernel<10>, dim3((unsigned)((p.M + 31) / 32)), dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
 size_t tapgemm_small_lds_bytes() { return (size_t)kSmallD * kSmallCS * 4 * 64 * 16; }
 
 // Number of workgroups (one 32 x 32 tile each) the layer needs (what the caller compares with the chip): row tiles x column tiles x classes.

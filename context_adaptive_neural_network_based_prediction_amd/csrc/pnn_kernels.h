@@ -93,6 +93,9 @@ hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_f
 long tapgemm_small_tiles(const TapGemmParams& p);
 // host_input (optional, with a_is_f32): the same rows in HOST memory; when they fit they travel inside the argument block
 hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input = nullptr);
+// Output layer (<= 64 outputs) of an FC net at small M in one launch: K segments + their reduction (pnn_gemm_small.hip)
+bool fc_out_small_fits(const TapGemmParams& p, int seg_chunks);
+hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s);
 hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);

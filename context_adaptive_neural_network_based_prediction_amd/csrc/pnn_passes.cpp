@@ -350,6 +350,31 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
                 if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
             } else {
                 if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, nullptr, P0, nullptr, nullptr, nb, s))) return rc;
+                // small passes: K segments and their reduction in ONE launch (fc_out_small_kernel; the same bits as the small
+                // kernel's K-segment mode + fuse_reduce_kernel, two launch floors of ~4 us less per single-block call)
+                TapGemmParams q = m->fc[3].proto;
+                q.X = P0; q.Wp = m->fc[3].d_w_sp; q.bias = m->fc[3].d_bias; q.out_scale = m->fc[3].sp_inv_scale; q.mean = c->mean;
+                q.Y = d_out; q.Yi = d_dst; q.M = (int)nb;
+                if (c->opt_fc_out && c->opt_small && c->opt_sp_cfg < 0 && nb <= 2048 && fc_out_small_fits(q, kFuseSegChunks)) {
+                    const double flops = 2.0 * (double)nb * m->fc[3].k_total * q.Cout;
+                    if (c->opt_time_launches) {
+                        pnn_ctx::LaunchRec r;
+                        HIPCHK(c, hipEventCreate(&r.e0));
+                        HIPCHK(c, hipEventCreate(&r.e1));
+                        r.kind = 5; r.flops = flops;
+                        const LaunchEvents ev{r.e0, r.e1};
+                        g_launch_events = &ev;
+                        const hipError_t le = launch_fc_out_small(q, kFuseSegChunks, s);
+                        g_launch_events = nullptr;
+                        HIPCHK(c, le);
+                        c->launch_recs.push_back(r);
+                    } else {
+                        HIPCHK(c, launch_fc_out_small(q, kFuseSegChunks, s));
+                    }
+                    c->stat_gemm_launches++; c->stat_launches++;
+                    c->stat_gemm_flops += flops;
+                    return PNN_OK;
+                }
                 if ((rc = run_gemm_sp(c, m->fc[3], P0, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, nullptr, part, &tiles, nullptr, false, kFuseSegChunks))) return rc;
             }
             if (tiles <= 0 || tiles > 20) return fail(c, PNN_E_ARG, "output layer: %d K segments do not fit the partial buffer", tiles);

@@ -120,11 +120,14 @@ int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total
         // stride-2 transposed convolutions to 64 channels (four output-parity classes of 4-9 taps each: short K per class, the
         // classes as blockIdx.z): from 8192 rows on the tuner takes the 128 x 64 ring tile over the LDS-resident-image kernel
         // at every batch looked at (16x16 / 32x32 nets, 512 ... 1024 / 128 ... 256 blocks: 26-28 us against 39 at M = 16384)
+        // (round 3: with the 3-deep ring, 28.0 against 32.1 us at M = 16384 -- K per class is 4-9 taps x 8 chunks, the shorter
+        // ring starts sooner; tools/tile_sweep.py, profiles/r03_tile_sweep.txt)
         if (p.ncls == 4 && p.Cout == 64 && M >= 8192) {
-            for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
-                const TileCfg t = tapgemm_ring_cfg(i);
-                if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 4 && t.d == 4) return i;
-            }
+            for (int d = 3; d <= 4; d++)
+                for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
+                    const TileCfg t = tapgemm_ring_cfg(i);
+                    if (t.rt == 1 && t.nt == 2 && t.kc == 2 && t.wm == 4 && t.d == d) return i;
+                }
         }
         // 64-channel 3x3 layers of a FEW images (under 128: the image kernel gets one workgroup per image or less and leaves most
         // of the chip idle) but enough rows for >= 128 tiles of 64 rows: the 64 x 128 ring tile, half its columns empty, is what

@@ -92,6 +92,10 @@ float pnn_mean(const pnn_ctx* ctx);
  * summation order as the big-tile kernels; 0: big-tile kernels only),
  * "pair" (1, default: such small passes of a convolutional net run layer i of BOTH branches as one launch -- they do not
  * depend on each other and a launch costs ~4 us whatever it does; bit-identical to separate launches; 0: one launch each),
+ * "fc_out" (0, default; 1: small passes through a fully-connected PNN with <= 64 outputs run the output layer's K segments
+ * AND their reduction as one launch, fc_out_small_kernel -- bit-identical, one launch less, measured no faster) and
+ * "spin_wait" (0, default; 1: synchronous host calls poll the stream with hipStreamQuery instead of blocking in
+ * hipStreamSynchronize -- measured no faster): two round-3 experiments on the single-block call kept as switches,
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs
@@ -101,7 +105,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FUSE_FIRST, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */
