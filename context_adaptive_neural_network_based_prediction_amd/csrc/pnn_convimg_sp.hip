@@ -16,6 +16,9 @@
 // to stage its 52 KB image, ~30k in the tap loop (1650 per 32-deep stage for 576 MFMA cycles, two workgroups per CU), ~10k in
 // the epilogue.  Staging by LDS-DMA with an XOR-swizzled layout was tried: same 9.3k cycles -- the 50 MB of activations of
 // all resident workgroups arrive as one burst at ~5.8 TB/s, it is memory bandwidth, not the copy loop.
+// Round 3: the ring kernel's issue order inside a chunk (one MFMA, then two of the next chunk's fragment reads, pinned with
+// sched_group_barrier) was tried here too: conv 16x16 pass 0.3830 -> 0.3849 ms same-box, i.e. nothing -- with two workgroups
+// per CU the other workgroup's wave fills the SIMD while this one issues its read burst.
 #include "pnn_kernels.h"
 #include <type_traits>
 #include "pnn_device_common.h"
