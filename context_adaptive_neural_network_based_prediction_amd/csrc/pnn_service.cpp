@@ -21,6 +21,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -157,14 +158,31 @@ struct Server {
 
     struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; };
     struct Reply { uint64_t id; std::vector<char> bytes; };
-    std::mutex mu;
+    // Locks: one per worker queue (with its condition variable), one per I/O thread's reply / new-connection queues, one for
+    // the peer accounting (only kept when a batching window is set) and the statistics.  (A single server-wide mutex was taken
+    // five times per request by nine threads.)
+    std::mutex qmu[5];
     std::condition_variable cv[5];
-    std::vector<Req> queue[5];       // by worker
-    std::vector<Reply> done;
-    int n_peers = 0, n_waiting_peers = 0;   // distinct peer processes connected / with a request in flight (maintained by the I/O thread)
-    bool quit = false;
-    int wake_fd[2] = {-1, -1};       // workers -> I/O thread
-    long served = 0, calls = 0, largest = 0, refused = 0;
+    std::vector<Req> queue[5];       // by worker, under qmu[k]
+    std::mutex dmu[8];               // done[t], fresh[t]
+    std::mutex mu;                   // peers, statistics
+    // Socket work is spread over `nio` I/O threads (round 3): ONE thread doing every recv / send / epoll_wait topped out at
+    // ~120 k requests/s -- 24 and 100 HM encoders on one server ran at the same 119 k and 123 k requests/s, and two server
+    // PROCESSES on the same GPU finished the 100-picture campaign in 8.9 s instead of 12.9 (profiles/r03_hm_runs.txt).  A
+    // connection belongs to one I/O thread for its life (dealt round-robin at accept; the thread's index sits in the low bits
+    // of the client ID), the per-width workers hand a reply to the owner's queue and wake it through its own pipe.
+    static constexpr int kMaxIo = 8;
+    int nio = 1;
+    std::vector<Reply> done[kMaxIo];
+    std::vector<int> fresh[kMaxIo];  // accepted descriptors dealt to I/O thread t by the listener (thread 0), under `mu`
+    std::atomic<int> n_peers{0}, n_waiting_peers{0};   // distinct peer processes connected / with a request in flight (window_us > 0 only; written under `mu`)
+    std::atomic<bool> quit_flag{false};
+    struct Peer { int conns = 0, in_flight = 0; };
+    std::map<int, Peer> peers;       // under `mu`
+    int wake_fd[kMaxIo][2];          // workers (and the listener) -> I/O thread t
+    std::atomic<uint64_t> next_seq{1};
+    std::atomic<long> accepted{0}, refused{0};
+    long served = 0, calls = 0, largest = 0;
     double busy_s[5] = {0, 0, 0, 0, 0};   // time inside the backend, per worker (PNN_SERVICE_DEBUG)
     long calls_w[5] = {0, 0, 0, 0, 0}, served_w[5] = {0, 0, 0, 0, 0};   // backend calls / requests per worker
 
@@ -178,15 +196,15 @@ struct Server {
         std::vector<int32_t> dst;
         for (;;) {
             {
-                std::unique_lock<std::mutex> lk(mu);
-                cv[k].wait(lk, [&] { return quit || !queue[k].empty(); });
-                if (quit) return;
+                std::unique_lock<std::mutex> lk(qmu[k]);
+                cv[k].wait(lk, [&] { return quit_flag.load() || !queue[k].empty(); });
+                if (quit_flag.load()) return;
                 // an idle worker gives stragglers a moment to join -- unless every peer process already waits for an answer
                 // (an encoder is single-threaded and blocks on its request: nobody else can arrive)
-                if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers < n_peers) {
+                if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers.load() < n_peers.load()) {
                     const auto until = Clock::now() + std::chrono::microseconds(window_us);
-                    cv[k].wait_until(lk, until, [&] { return quit || (int)queue[k].size() >= max_batch || n_waiting_peers >= n_peers; });
-                    if (quit) return;
+                    cv[k].wait_until(lk, until, [&] { return quit_flag.load() || (int)queue[k].size() >= max_batch || n_waiting_peers.load() >= n_peers.load(); });
+                    if (quit_flag.load()) return;
                 }
                 // the lock was released during the window: the I/O thread may have dropped the only queued request
                 // (an encoder killed or timed out mid-window)
@@ -231,57 +249,67 @@ struct Server {
                     replies[i].bytes.insert(replies[i].bytes.end(), pp, pp + w2 * 4);
                 }
             }
+            bool woke[kMaxIo] = {false};
+            for (int t = 0; t < nio; t++) {          // replies to their owners, one lock per I/O thread that has any
+                bool any = false;
+                for (auto& r : replies) any |= (int)(r.id & 15) % nio == t;
+                if (!any) continue;
+                woke[t] = true;
+                std::lock_guard<std::mutex> lk(dmu[t]);
+                for (auto& r : replies) if ((int)(r.id & 15) % nio == t) done[t].push_back(std::move(r));
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                for (auto& r : replies) done.push_back(std::move(r));
                 served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
                 ++calls_w[k]; served_w[k] += (long)n;
             }
             const char one = 1;
-            (void)!write(wake_fd[1], &one, 1);
+            for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t][1], &one, 1);
         }
     }
 
-    int run(const char* socket_path, long* stats)
+    void peer_conn(int pid, int d)                   // a connection of `pid` opened (+1) / closed (-1); under `mu`
     {
-        sockaddr_un addr;
-        if (make_addr(socket_path, &addr)) return PNN_E_ARG;
-        const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
-        if (lfd < 0) return PNN_E_IO;
-        unlink(socket_path);
-        if (bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) < 0 || listen(lfd, 512) < 0) { close(lfd); return PNN_E_IO; }
-        // every descriptor the loop needs exists BEFORE a worker thread is started: an early error return must not leave
-        // joinable threads (std::terminate) or a leaked pipe behind
-        if (pipe(wake_fd) < 0) { close(lfd); unlink(socket_path); return PNN_E_IO; }
-        const int ep = epoll_create1(0);
-        if (ep < 0) { close(lfd); close(wake_fd[0]); close(wake_fd[1]); unlink(socket_path); return PNN_E_IO; }
-        set_nonblocking(lfd);
-        set_nonblocking(wake_fd[0]);
-        set_nonblocking(wake_fd[1]);
-        std::map<uint64_t, Client> clients;          // by client ID
-        uint64_t next_id = 2;                        // 0 and 1 are the listener and the wake pipe in the epoll set
-        long accepted = 0;
-        std::vector<std::thread> threads;
-        for (int k = 0; k < nworkers; k++) threads.emplace_back([this, k] { worker(k); });
+        Peer& pr = peers[pid];
+        pr.conns += d;
+        if (pr.conns <= 0) { if (pr.in_flight > 0) --n_waiting_peers; peers.erase(pid); }
+        n_peers = (int)peers.size();
+    }
+    void peer_flight(int pid, int d)                 // a request of `pid` queued (+1) / answered or dropped (-1); under `mu`
+    {
+        auto it = peers.find(pid);
+        if (it == peers.end()) return;
+        const bool was = it->second.in_flight > 0;
+        it->second.in_flight += d;
+        const bool is = it->second.in_flight > 0;
+        if (is != was) n_waiting_peers += is ? 1 : -1;
+    }
 
-        // distinct peer processes and those with a request in flight, kept incrementally (under the lock).  This used to be a
-        // recount over all connections per message: with 160 connections that sort was most of what the I/O thread did
-        // (16 encoders on one server were slower than 8 + 8 on two).
-        struct Peer { int conns = 0, in_flight = 0; };
-        std::map<int, Peer> peers;
-        auto peer_conn = [&](int pid, int d) {       // a connection of `pid` opened (+1) / closed (-1)
-            Peer& pr = peers[pid];
-            pr.conns += d;
-            if (pr.conns <= 0) { if (pr.in_flight > 0) --n_waiting_peers; peers.erase(pid); }
-            n_peers = (int)peers.size();
+    // One I/O thread: its share of the connections (receive, queue for the workers, reply); thread 0 also owns the listener.
+    // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was what
+    // bounded the server; event data = client ID (0: listener, 1: this thread's wake pipe).
+    void io_loop(const int t, const int lfd, const int ep)
+    {
+        std::map<uint64_t, Client> clients;          // by client ID
+        auto ep_ctl = [&](int op, int fd, uint32_t events, uint64_t id) {
+            epoll_event ev;
+            memset(&ev, 0, sizeof ev);
+            ev.events = events; ev.data.u64 = id;
+            epoll_ctl(ep, op, fd, &ev);
         };
-        auto peer_flight = [&](int pid, int d) {     // a request of `pid` queued (+1) / answered or dropped (-1)
-            auto it = peers.find(pid);
-            if (it == peers.end()) return;
-            const bool was = it->second.in_flight > 0;
-            it->second.in_flight += d;
-            const bool is = it->second.in_flight > 0;
-            if (is != was) n_waiting_peers += is ? 1 : -1;
+        auto arm = [&](uint64_t id, Client& c) { ep_ctl(EPOLL_CTL_MOD, c.fd, EPOLLIN | (c.tx.empty() ? 0u : (uint32_t)EPOLLOUT), id); };
+        auto adopt = [&](int cfd) {                  // a connection dealt to this thread
+            set_nonblocking(cfd);
+            Client c;
+            c.fd = cfd;
+            ucred cred;
+            socklen_t len = sizeof cred;
+            if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
+            const uint64_t nid = (next_seq.fetch_add(1) << 4) | (uint64_t)t;     // never 0 or 1: the sequence starts at 1
+            const int pid = c.pid;
+            clients.emplace(nid, std::move(c));
+            ep_ctl(EPOLL_CTL_ADD, cfd, EPOLLIN, nid);
+            if (window_us > 0) { std::lock_guard<std::mutex> lk(mu); peer_conn(pid, +1); }
         };
         auto drop = [&](uint64_t id) {
             auto it = clients.find(id);
@@ -290,10 +318,16 @@ struct Server {
             const int pid = it->second.pid;
             const bool was_in_flight = it->second.in_flight;
             clients.erase(it);
-            std::lock_guard<std::mutex> lk(mu);
-            for (auto& q : queue) q.erase(std::remove_if(q.begin(), q.end(), [id](const Req& r) { return r.id == id; }), q.end());
-            if (was_in_flight) peer_flight(pid, -1);
-            peer_conn(pid, -1);
+            if (was_in_flight)
+                for (int k = 0; k < nworkers; k++) {
+                    std::lock_guard<std::mutex> lk(qmu[k]);
+                    queue[k].erase(std::remove_if(queue[k].begin(), queue[k].end(), [id](const Req& r) { return r.id == id; }), queue[k].end());
+                }
+            if (window_us > 0) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (was_in_flight) peer_flight(pid, -1);
+                peer_conn(pid, -1);
+            }
         };
         auto flush = [&](Client& c) {                         // false = broken
             while (c.tx_off < c.tx.size()) {
@@ -318,6 +352,7 @@ struct Server {
                     memcpy(&h, c.rx.data(), sizeof h);
                     if (!valid_header(h)) return false;
                     want = sizeof h + ((size_t)h.n_above + h.n_left) * 4;
+                    if (c.rx.size() > want) return false;     // bytes of a second request behind an unanswered one
                     if (c.rx.size() == want) {
                         if (c.in_flight) return false;        // one outstanding request per client
                         const int kd = kind[widx(h.width)];
@@ -341,22 +376,24 @@ struct Server {
                         c.in_flight = true;
                         c.rx.clear();
                         const int k = worker_of(h.width);
-                        bool all_wait;
+                        if (window_us > 0) { std::lock_guard<std::mutex> lk(mu); peer_flight(c.pid, +1); }
                         {
-                            std::lock_guard<std::mutex> lk(mu);
+                            std::lock_guard<std::mutex> lk(qmu[k]);
                             queue[k].push_back(std::move(r));
-                            peer_flight(c.pid, +1);
-                            all_wait = n_waiting_peers >= n_peers;
                         }
                         cv[k].notify_one();
                         // the other workers only care when "every peer waits" has just become true (they may be sitting in their window)
-                        if (nworkers > 1 && all_wait) for (int o = 0; o < nworkers; o++) if (o != k) cv[o].notify_one();
+                        if (nworkers > 1 && window_us > 0 && n_waiting_peers.load() >= n_peers.load())
+                            for (int o = 0; o < nworkers; o++) if (o != k) { std::lock_guard<std::mutex> lk(qmu[o]); cv[o].notify_one(); }
                         return true;
                     }
                 }
+                // one outstanding request per client: everything the socket holds belongs to this request, so a header and its
+                // payload (one send on the client side) come in with ONE recv instead of two
                 const size_t have = c.rx.size();
-                c.rx.resize(want);
-                const ssize_t r = recv(c.fd, c.rx.data() + have, want - have, 0);
+                const size_t room = have < sizeof(ReqHeader) ? sizeof(ReqHeader) + (size_t)5 * 64 * 4 : want;   // header + an 8x8 FC context
+                c.rx.resize(room);
+                const ssize_t r = recv(c.fd, c.rx.data() + have, room - have, 0);
                 if (r <= 0) {
                     c.rx.resize(have);
                     if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) return true;   // rest comes later
@@ -365,52 +402,42 @@ struct Server {
                 c.rx.resize(have + (size_t)r);
             }
         };
-        // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was
-        // what bounded the server (32 encoders: 65 k requests/s); event data = client ID (0: listener, 1: the workers' pipe)
-        auto ep_ctl = [&](int op, int fd, uint32_t events, uint64_t id) {
-            epoll_event ev;
-            memset(&ev, 0, sizeof ev);
-            ev.events = events; ev.data.u64 = id;
-            epoll_ctl(ep, op, fd, &ev);
-        };
-        ep_ctl(EPOLL_CTL_ADD, lfd, EPOLLIN, 0);
-        ep_ctl(EPOLL_CTL_ADD, wake_fd[0], EPOLLIN, 1);
-        auto arm = [&](uint64_t id, Client& c) { ep_ctl(EPOLL_CTL_MOD, c.fd, EPOLLIN | (c.tx.empty() ? 0u : (uint32_t)EPOLLOUT), id); };
         epoll_event evs[256];
         auto last_sweep = Clock::now();
         std::vector<uint64_t> gone;
+        int deal = 0;                                // listener: next I/O thread to get a connection
         while (!*stop) {
             const int r = epoll_wait(ep, evs, 256, 50);
             gone.clear();
             for (int i = 0; i < r; i++) {
                 const uint64_t id = evs[i].data.u64;
                 const uint32_t e = evs[i].events;
-                if (id == 0) {
+                if (id == 0) {                                // the listener (thread 0 only): deal the new connections
+                    bool woke[kMaxIo] = {false};
                     for (;;) {
                         const int cfd = accept(lfd, nullptr, nullptr);
                         if (cfd < 0) break;
-                        set_nonblocking(cfd);
-                        Client c;
-                        c.fd = cfd;
-                        ucred cred;
-                        socklen_t len = sizeof cred;
-                        if (getsockopt(cfd, SOL_SOCKET, SO_PEERCRED, &cred, &len) == 0) c.pid = (int)cred.pid;
-                        const uint64_t nid = next_id++;
-                        const int pid = c.pid;
-                        clients.emplace(nid, std::move(c));
-                        ep_ctl(EPOLL_CTL_ADD, cfd, EPOLLIN, nid);
                         ++accepted;
-                        std::lock_guard<std::mutex> lk(mu);
-                        peer_conn(pid, +1);
+                        const int to = deal;
+                        deal = (deal + 1) % nio;
+                        if (to == t) { adopt(cfd); continue; }
+                        std::lock_guard<std::mutex> lk(dmu[to]);
+                        fresh[to].push_back(cfd);
+                        woke[to] = true;
                     }
-                } else if (id == 1) {                         // replies from the workers
+                    const char one = 1;
+                    for (int o = 0; o < nio; o++) if (woke[o]) (void)!write(wake_fd[o][1], &one, 1);
+                } else if (id == 1) {                         // new connections from the listener, replies from the workers
                     char buf[256];
-                    while (read(wake_fd[0], buf, sizeof buf) > 0) {}
+                    while (read(wake_fd[t][0], buf, sizeof buf) > 0) {}
                     std::vector<Reply> ready;
+                    std::vector<int> mine;
                     {
-                        std::lock_guard<std::mutex> lk(mu);
-                        ready.swap(done);
+                        std::lock_guard<std::mutex> lk(dmu[t]);
+                        ready.swap(done[t]);
+                        mine.swap(fresh[t]);
                     }
+                    for (int cfd : mine) adopt(cfd);
                     for (Reply& rp : ready) {
                         auto it = clients.find(rp.id);
                         if (it == clients.end()) continue;    // dropped meanwhile
@@ -419,8 +446,7 @@ struct Server {
                         c.tx.insert(c.tx.end(), rp.bytes.begin(), rp.bytes.end());
                         if (c.in_flight) {
                             c.in_flight = false;
-                            std::lock_guard<std::mutex> lk(mu);
-                            peer_flight(c.pid, -1);
+                            if (window_us > 0) { std::lock_guard<std::mutex> lk(mu); peer_flight(c.pid, -1); }
                         }
                         if (!flush(c)) gone.push_back(rp.id);
                         else if (!c.tx.empty()) arm(rp.id, c);   // the socket took only part of it: wait for EPOLLOUT
@@ -447,18 +473,65 @@ struct Server {
             gone.erase(std::unique(gone.begin(), gone.end()), gone.end());
             for (uint64_t id : gone) drop(id);
         }
-        close(ep);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-        }
-        for (int k = 0; k < nworkers; k++) cv[k].notify_all();
-        for (auto& t : threads) t.join();
         for (auto& kv : clients) close(kv.second.fd);
-        close(lfd);
-        close(wake_fd[0]); close(wake_fd[1]);
+    }
+
+    int run(const char* socket_path, long* stats)
+    {
+        sockaddr_un addr;
+        if (make_addr(socket_path, &addr)) return PNN_E_ARG;
+        if (const char* e = getenv("PNN_SERVICE_IO_THREADS")) nio = atoi(e);
+        nio = std::max(1, std::min(nio, (int)kMaxIo));
+        const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
+        if (lfd < 0) return PNN_E_IO;
         unlink(socket_path);
-        if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted; }
+        // every descriptor the loops need exists BEFORE a thread is started: an early error return must not leave joinable
+        // threads (std::terminate) or leaked descriptors behind
+        int eps[kMaxIo];
+        int made = 0;
+        bool ok = bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) == 0 && listen(lfd, 512) == 0;
+        for (; ok && made < nio; made++) {
+            wake_fd[made][0] = wake_fd[made][1] = -1;
+            eps[made] = -1;
+            if (pipe(wake_fd[made]) < 0) { ok = false; break; }
+            eps[made] = epoll_create1(0);
+            if (eps[made] < 0) { close(wake_fd[made][0]); close(wake_fd[made][1]); ok = false; break; }
+        }
+        if (!ok) {
+            for (int t = 0; t < made; t++) { close(eps[t]); close(wake_fd[t][0]); close(wake_fd[t][1]); }
+            close(lfd);
+            unlink(socket_path);
+            return PNN_E_IO;
+        }
+        set_nonblocking(lfd);
+        for (int t = 0; t < nio; t++) {
+            set_nonblocking(wake_fd[t][0]);
+            set_nonblocking(wake_fd[t][1]);
+            epoll_event ev;
+            memset(&ev, 0, sizeof ev);
+            ev.events = EPOLLIN; ev.data.u64 = 1;
+            epoll_ctl(eps[t], EPOLL_CTL_ADD, wake_fd[t][0], &ev);
+        }
+        {
+            epoll_event ev;
+            memset(&ev, 0, sizeof ev);
+            ev.events = EPOLLIN; ev.data.u64 = 0;
+            epoll_ctl(eps[0], EPOLL_CTL_ADD, lfd, &ev);
+        }
+        std::vector<std::thread> threads;
+        for (int k = 0; k < nworkers; k++) threads.emplace_back([this, k] { worker(k); });
+        std::vector<std::thread> io;
+        for (int t = 1; t < nio; t++) io.emplace_back([this, t, lfd, &eps] { io_loop(t, lfd, eps[t]); });
+        io_loop(0, lfd, eps[0]);                     // the calling thread: listener + its share of the connections
+        for (auto& th : io) th.join();
+        quit_flag = true;
+        for (int t = 0; t < nio; t++) for (int cfd : fresh[t]) close(cfd);   // dealt but never adopted
+        for (int k = 0; k < nworkers; k++) { std::lock_guard<std::mutex> lk(qmu[k]); cv[k].notify_all(); }
+        for (auto& th : threads) th.join();
+        for (int t = 0; t < nio; t++) { close(eps[t]); close(wake_fd[t][0]); close(wake_fd[t][1]); }
+        close(lfd);
+        unlink(socket_path);
+        if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted.load(); }
         if (getenv("PNN_SERVICE_DEBUG"))
             for (int k = 0; k < nworkers; k++)
                 fprintf(stderr, "[pnn-service] worker %d: %.2f s inside the backend, %ld calls (%.1f us each), %ld requests (%.2f per call)\n", k, busy_s[k],
@@ -478,6 +551,7 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     Server sv;
     sv.backend = backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
     for (void*& u : sv.users) u = user;
+    sv.nio = 2;
     return sv.run(socket_path, stats);
 }
 
@@ -531,6 +605,7 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     if (rc == PNN_OK) {
         Server sv;
         sv.backend = ctx_backend; sv.nworkers = 5; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+        sv.nio = 4;                                  // socket threads (PNN_SERVICE_IO_THREADS overrides)
         for (int k = 0; k < 5; k++) {
             sv.users[k] = ctxs[k];
             int is_fc = 0;
