@@ -287,7 +287,8 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
         a = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - a)
-    print(json.dumps({"blocks_per_s": per_call / float(np.median(ts)), "runs": len(ts), "blocks_per_run": per_call, "threads": threads}))
+    print(json.dumps({"blocks_per_s": per_call / float(np.median(ts)), "runs": len(ts), "blocks_per_run": per_call, "threads": threads,
+                      "blocks_per_s_spread": [per_call / float(np.max(ts)), per_call / float(np.min(ts))]}))   # slowest / fastest run of this leg
 
 
 def cpu_legs(wl, budget_s=2.0):

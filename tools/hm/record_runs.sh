@@ -1,7 +1,7 @@
 #!/bin/bash
 # Records the HM runs quoted in DESIGN.md section 5b into one text file (default profiles/r02_hm_runs.txt).  GPU box.
 #   tools/hm/record_runs.sh [out-file]
-out=${1:-profiles/r02_hm_runs.txt}
+out=${1:-profiles/r03_hm_runs.txt}
 work=${TMPDIR:-/tmp}/hm_runs.$$
 mkdir -p "$work"
 run() {   # title, then run_hm.py arguments; result lines cut after the first fields
