@@ -335,3 +335,25 @@ def test_hm_encodes_dealt_over_one_service_per_device(hm_built, tmp_path):
     clients = [int(m.group(2)) for m in re.finditer(r"(\d+) requests in \d+ batched calls \(largest batch \d+\), (\d+) clients", out.stdout)]
     assert len(served) == 2 and min(served) > 0, out.stdout
     assert clients == [20, 20], clients                              # 2 encoders + 2 decoders per service, 5 sessions each
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["kodak", "bsds"])
+def test_bench_hm_campaign_in_small(hm_built, config):
+    """BASELINE.json configs[3] / configs[4] through bench.py (`--workload hm_kodak` / `hm_bsds`, here with 4 pictures instead of
+    24 / 100): one batching service per device, all encodes in flight, hm_16_15_regular beside it; ONE JSON line whose `hm`
+    record says that every decoded picture equals its encoder's reconstruction.  The default bench line runs the same code at
+    the stated picture counts."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "hm_" + config, "--hm-quick"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    h = d["hm"]
+    assert h["pictures"] == 4 and h["every_decode_equals_its_encoder"] is True
+    assert h["variant"] == ("hm_16_15_substitution" if config == "kodak" else "hm_16_15_switch")
+    assert h["service"]["requests"] > 1000 and h["service"]["backend_calls"] <= h["service"]["requests"]
+    assert d["value"] == h["service"]["pnn_blocks_per_s_over_the_wall"] and d["cpu_baseline"]["every_decode_equals_its_encoder"] is True
+    assert sum(v["session_run_calls"] for v in h["pnn_calls"]["enc_pnn"].values()) > h["service"]["requests"]     # the rest were cache hits

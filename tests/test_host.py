@@ -590,3 +590,38 @@ def test_gpu_placement_helpers(tmp_path):
     finally:
         os.sched_setaffinity(0, before)
     assert sharding.GpuClockSampler(7).summary() is None or True
+
+
+def _stagger_rank(rank, world, port, out):
+    import time
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from context_adaptive_neural_network_based_prediction_amd import sharding
+    d = sharding.init_ranks("gloo")
+    stamps = []
+
+    def fn():
+        stamps.append(time.time())
+        time.sleep(0.2)
+        stamps.append(time.time())
+    bench.stagger(d, fn)
+    out.put((rank, stamps))
+    d.destroy_process_group()
+
+
+def test_staggered_first_calls_two_ranks_gloo():
+    """bench.py's first (autotuning) call of a workload runs one rank after the other (bench.stagger): with two gloo ranks the
+    two 0.2 s sections must not overlap, rank 0 first."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_stagger_rank, args=(r, 2, 29733, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] <= res[1][0] + 1e-3, res
