@@ -168,6 +168,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_SMALL")) c->opt_small = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
+    if (const char* e = getenv("PNN_FUSE_GATHER")) c->opt_fuse_gather = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
     if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
@@ -310,6 +311,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
+    else if (!strcmp(name, "fuse_gather")) c->opt_fuse_gather = value;
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
@@ -416,14 +418,21 @@ int pnn_predict_tbs_device(pnn_ctx* c, int width, const void* d_plane, int pel_b
         float* lf = m->is_fc ? ctxbuf + 3 * w2 : ctxbuf + nb * 3 * w2;
         const long pa = m->is_fc ? 5 * w2 : 3 * w2, pl = m->is_fc ? 5 * w2 : 2 * w2;
         const bool split_ctx = m->is_fc && pass_uses_split(c, m, nb);   // the FC chain starts on the split-precision GEMM
-        GatherParams g;
-        g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs + b0); g.N = (int)nb; g.w = width;
-        g.unit = 4; g.mean = c->mean; g.above = ab; g.left = lf; g.pitch_above = pa; g.pitch_left = pl; g.split = split_ctx ? 1 : 0;
-        HIPCHK(c, launch_gather(g, s));
-        c->stat_launches++;
-        if ((rc = run_net(c, m, ab, pa, lf, pl, nb, d_out_f32 ? d_out_f32 + b0 * w2 : nullptr, d_dst ? d_dst + b0 * w2 : nullptr, s,
-                          split_ctx)))
-            return rc;
+        // convolutional nets whose first convolutions run inside the image kernel: the gather goes in there too
+        const bool lazy = !m->is_fc && nb <= chunk_blocks(c, m) && conv_pass_fuses_first(c, m, nb);
+        if (lazy) {
+            c->lazy.plane = d_plane; c->lazy.tbs = reinterpret_cast<const TbDev*>(d_tbs + b0); c->lazy.pel_bytes = pel_bytes; c->lazy.unit = 4;
+            ab = lf = nullptr;
+        } else {
+            GatherParams g;
+            g.plane = d_plane; g.pel_bytes = pel_bytes; g.tbs = reinterpret_cast<const TbDev*>(d_tbs + b0); g.N = (int)nb; g.w = width;
+            g.unit = 4; g.mean = c->mean; g.above = ab; g.left = lf; g.pitch_above = pa; g.pitch_left = pl; g.split = split_ctx ? 1 : 0;
+            HIPCHK(c, launch_gather(g, s));
+            c->stat_launches++;
+        }
+        rc = run_net(c, m, ab, pa, lf, pl, nb, d_out_f32 ? d_out_f32 + b0 * w2 : nullptr, d_dst ? d_dst + b0 * w2 : nullptr, s, split_ctx);
+        c->lazy = pnn_ctx::LazyGather();
+        if (rc) return rc;
     }
     return PNN_OK;
 }

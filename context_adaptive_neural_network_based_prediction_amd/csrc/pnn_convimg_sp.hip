@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     const int nimg = (int)((long)p.M / SP - img0 < G ? (long)p.M / SP - img0 : G);   // images that exist
 
     // ---- stage the images and the zero pixel -------------------------------------------------------------------------
-    if (p.X0) {
+    if (p.X0 || p.plane0) {
         // Fused first convolution of the branch: the maps are COMPUTED here from the raw f32 context (a few KB per image)
         // instead of being written by conv_cin1_kernel and read back (50 MB each way at batch 1024 for the 16x16 net).
         // Same arithmetic as conv_cin1_kernel's split path (FirstConv: MFMA chain over the taps, scale, bias, LeakyReLU, split),
@@ -64,6 +64,34 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         float* raw = reinterpret_cast<float*>(Bs);
         const int K0 = p.k0, S0 = p.s0, IH0 = p.IH * S0, IW0 = p.IW * S0;
         const int PH = (p.IH - 1) * S0 + K0, PW = (p.IW - 1) * S0 + K0;
+        if (p.plane0) {
+            // the context gather fused in as well: straight from the picture plane through the TB descriptors (same values as
+            // gather_f32x4_kernel writes: (float) pel - mean, unavailable units 0), no gather launch, no 5 KB per block round trip
+            const TbDev* __restrict__ tbs = reinterpret_cast<const TbDev*>(p.tbs0) + img0;
+            const int w0 = p.w0;
+            TbDev d = tbs[0];                          // a thread's elements walk the images in order: one descriptor fetch per image,
+            int dli = 0;                               // not per element
+            for (int idx = tid; idx < nimg * PH * PW; idx += 256) {
+                const int li = idx / (PH * PW), r0 = idx - li * PH * PW;
+                const int r = r0 / PW, c = r0 - r * PW;
+                const int iy = r - p.pad0, ix = c - p.pad0;
+                float v = 0.f;
+                if ((unsigned)iy < (unsigned)IH0 && (unsigned)ix < (unsigned)IW0) {
+                    if (li != dli) { d = tbs[li]; dli = li; }
+                    bool ok;
+                    long off;
+                    if (p.branch0 == 0) {
+                        ok = ix < w0 || ((d.above_mask >> ((ix - w0) / p.unit0)) & 1u);
+                        off = d.origin + (long)(iy - w0) * d.stride + (ix - w0);
+                    } else {
+                        ok = iy < d.left_units * p.unit0;
+                        off = d.origin + (long)iy * d.stride + (ix - w0);
+                    }
+                    if (ok) v = (p.pel0 == 4 ? (float)reinterpret_cast<const int32_t*>(p.plane0)[off] : (float)reinterpret_cast<const uint8_t*>(p.plane0)[off]) - p.mean;
+                }
+                raw[idx] = v;
+            }
+        } else
         for (int idx = tid; idx < nimg * PH * PW; idx += 256) {
             const int li = idx / (PH * PW), r0 = idx - li * PH * PW;
             const int r = r0 / PW, c = r0 - r * PW;

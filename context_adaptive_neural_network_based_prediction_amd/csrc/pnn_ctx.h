@@ -126,6 +126,11 @@ struct pnn_ctx {
     int* h_range = nullptr;
     long range_fallbacks = 0;
     const float* host_input = nullptr;                // host_predict: the caller's f32 input rows (FC nets), valid during the call
+    // pnn_predict_tbs_device, convolutional nets: when BOTH branches' second layers take the image kernel with the fused first
+    // convolution, the context gather is fused in too -- no gather launch; the kernels read the plane through these (valid
+    // during the call; plane == NULL: the contexts were gathered into the staging buffer as usual)
+    struct LazyGather { const void* plane = nullptr; const void* tbs = nullptr; int pel_bytes = 0, unit = 0; } lazy;
+    long opt_fuse_gather = 1;
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
@@ -163,6 +168,7 @@ int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const s
 // pnn_passes.cpp
 long chunk_blocks(const pnn_ctx* c, const Model* m);
 bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb);
+bool conv_pass_fuses_first(pnn_ctx* c, Model* m, long nb);
 int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
             int32_t* d_dst, hipStream_t s, bool ctx_is_split = false);
 

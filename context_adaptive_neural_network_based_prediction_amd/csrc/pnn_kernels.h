@@ -30,6 +30,7 @@ constexpr int kMaxClasses = 4;
 //   fully-connected layer  : one tap, 1x1 "image", Cin = K                            (components.py:169-176)
 // Weights are pre-packed per 16-deep K chunk as [chunk][q = 4][Npad][4] floats (k = 16*chunk + 4*q + e),
 // the order in which one 16x16x4 f32 MFMA lane group consumes them.
+struct TbDev;
 struct TapGemmParams {
     const float* X;    // f32 activations, or the hi f16 plane for the split-precision kernel
     const void* Xlo;   // lo f16 plane (split-precision kernel only)
@@ -42,6 +43,11 @@ struct TapGemmParams {
     // context X0 [images][IH * s0][IW * s0] instead of reading them from X (see pnn_convimg_sp.hip)
     const float* X0; const float* W0; const float* B0; int s0, k0, pad0;
     const float* W0sp; float scale0; int Npad0;   // the first convolution's taps x channels matrix in the split pack (FirstConv, pnn_device_common.h)
+    // ... and, when plane0 != NULL, the context gather too (extraction_context.cpp:3-208): X0 is not read; image i's raw context
+    // comes straight from the picture plane through TB descriptor tbs0[i] -- branch0 = 0: the above portion (rows y - w ..
+    // y - 1, columns x - w .. x + 2w - 1, masked per unit0-pixel unit), 1: the left portion (rows y .. y + 2w - 1, columns
+    // x - w .. x - 1, the first left_units units) --, Pel (pel0 bytes) -> float, minus `mean`
+    const void* plane0; const void* tbs0; int pel0, branch0, unit0, w0;
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)

@@ -68,8 +68,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
 // finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
 int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
                 long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
-                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0)
+                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0, bool* query_fuse_first = nullptr)
 {
+    // query_fuse_first (optional): launch NOTHING; report whether this call would run the image kernel with `first` fused in
+    // -- and is sure of it: no tuning sweep ahead (a sweep launches the other kernel families too, which need the maps in memory)
+    if (query_fuse_first) *query_fuse_first = false;
     // x_is_f32: Xhi holds plain f32 rows (an FC net's input as the caller handed it over); only the small-M kernel takes
     // that (it splits in registers), any other choice gets split_kernel launched in front (into ws[2]).
     // seg_chunks > 0: K-segment mode of an FC output layer (small-M kernel only): raw partials to `part`, see fc_pass.
@@ -99,6 +102,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     // Few output tiles (the in-loop single-block calls, the batching service's handfuls): one wave per 32 x 32 tile over all
     // CUs instead of one or two big workgroups walking K alone.  Same per-output summation order: bit-identical.
     const bool small = seg_chunks > 0 || (!next && !diag0 && c->opt_small && c->opt_sp_cfg < 0 && tapgemm_small_tiles(p) <= c->opt_small_tiles);
+    if (small && query_fuse_first) return PNN_OK;
     if (small) {
         if (seg_chunks > 0) p.part = part;
         if (first) { HIPCHK(c, launch_conv_cin1(*first, s)); c->stat_launches++; }
@@ -125,7 +129,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         if (tiles_out) *tiles_out = seg_chunks > 0 ? (int)(((long)(L.k_total / 16.0) + seg_chunks - 1) / seg_chunks) : 0;
         return PNN_OK;
     }
-    if (x_is_f32) {                                   // the big-tile kernels read split activations
+    if (x_is_f32 && !query_fuse_first) {              // the big-tile kernels read split activations
         const long nin = nblocks * (long)p.IH * p.IW * p.Cin;
         HIPCHK(c, launch_split((const float*)Xhi, nin, c->ws[2].p, nullptr, c->h_range, s));
         c->stat_launches++;
@@ -155,9 +159,15 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
                     TapGemmParams q = p;
                     q.X0 = first->X; q.W0 = first->W; q.B0 = first->bias; q.s0 = first->s; q.k0 = first->k; q.pad0 = first->pad;
                     q.W0sp = first->Wsp; q.scale0 = first->out_scale; q.Npad0 = first->npad;
+                    if (!first->X && c->lazy.plane) {  // the gather fused in as well (pnn_predict_tbs_device decided so by query)
+                        q.plane0 = c->lazy.plane; q.tbs0 = c->lazy.tbs; q.pel0 = c->lazy.pel_bytes; q.unit0 = c->lazy.unit;
+                        q.branch0 = first->IH > first->IW ? 1 : 0;       // above portion w x 3w, left portion 2w x w
+                        q.w0 = q.branch0 ? first->IW : first->IH;
+                    }
                     return launch_convimg_sp(q, code - nsp, g, s);
                 }
             }
+            if (!first->X) return hipErrorInvalidValue;   // contexts not gathered (fused gather) but this configuration needs the maps in memory: never chosen after the query
             const hipError_t e = launch_conv_cin1(*first, s);
             if (e != hipSuccess) return e;
         }
@@ -188,6 +198,20 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         // into a hipGraph (the rule-based choice is used instead, nothing is remembered)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
+    }
+    if (query_fuse_first) {
+        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0));
+        int code = cfg;
+        if (tune && c->opt_sp_cfg < 0) {
+            auto it = c->tuned.find(std::make_pair(key, M));
+            if (it == c->tuned.end()) return PNN_OK;  // a sweep is ahead
+            code = it->second;
+        }
+        if (first && code >= nsp && code < nsp + nci && legal(code)) {
+            const TileCfg t = convimg_sp_cfg(code - nsp);
+            *query_fuse_first = c->opt_fuse_first && convimg_sp_can_fuse_first(p, t, convimg_images(p, t, one_tap), first->s, first->k);
+        }
+        return PNN_OK;
     }
     if (tune && c->opt_sp_cfg < 0) {
         const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0));
@@ -514,6 +538,23 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
 }
 
 }  // namespace
+
+// Would a pass of nb blocks through convolutional model m fuse BOTH branches' first convolutions into the image kernel (so that
+// the context gather can be fused in too)?  Launches nothing.
+bool conv_pass_fuses_first(pnn_ctx* c, Model* m, long nb)
+{
+    if (m->is_fc || !c->opt_fuse_gather || !pass_uses_split(c, m, nb) || c->opt_time_launches || getenv("PNN_PROFILE")) return false;
+    for (int br = 0; br < 2; br++) {
+        if (m->branch[br].empty()) return false;
+        Conv1Params f = m->first[br].proto;
+        f.W = m->first[br].d_w; f.bias = m->first[br].d_bias;
+        f.Wsp = m->first[br].d_w_sp; f.out_scale = m->first[br].sp_inv_scale; f.npad = m->first[br].npad;
+        f.B = (int)nb; f.split = 1;
+        bool fuse = false;
+        if (run_gemm_sp(c, m->branch[br][0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nb, nullptr, nullptr, nullptr, nullptr, &f, false, 0, &fuse) || !fuse) return false;
+    }
+    return true;
+}
 
 // Runs the net over n blocks in chunks. Inputs per block: FC one [5w^2] row; conv above/left portions.
 int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d_l, long pitch_l, long n, float* d_out,
