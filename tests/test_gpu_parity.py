@@ -761,6 +761,12 @@ def test_gather_fused_into_the_image_kernel(pnn, oracle, precision, w, n):
             outs[(pel_bytes, fuse)] = (d_dst.cpu().numpy(), d_f32.cpu().numpy(), net.last_call_stats()["launches"])
         assert np.array_equal(outs[(pel_bytes, 1)][0], outs[(pel_bytes, 0)][0]) and np.array_equal(outs[(pel_bytes, 1)][1], outs[(pel_bytes, 0)][1])
     assert np.array_equal(outs[(1, 1)][0], outs[(4, 1)][0])
+    net.set_option("max_chunk", max(8, n // 3 + 1))                  # several passes per call: every chunk reads ITS descriptors
+    d_dst = torch.full((n, w, w), -1, dtype=torch.int32, device="cuda")
+    assert L.pnn_predict_tbs_device(net.ctx, w, d_plane.data_ptr(), 1, d_tbs.data_ptr(), n, d_dst.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dst.cpu().numpy(), outs[(4, 1)][0])
+    net.set_option("max_chunk", 0)
     if w in (16, 8):
         assert outs[(4, 1)][2] == outs[(4, 0)][2] - 1, "the gather launch is gone"
     m = min(n, 64)
