@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (one gather launch to the
-next), the kernels in launch order with their duration and the idle gap in front of each."""
+"""Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (from the launch behind a pass's last
+kernel -- the reduction of an FC net, the last transposed convolution of a conv net -- to the next such launch; a conv pass
+whose gather is fused into the image kernel has no gather launch to go by), the kernels in launch order with their
+duration and the idle gap in front of each."""
 import csv, glob, sys
 d = sys.argv[1]
 rows = []
@@ -8,10 +10,17 @@ for f in glob.glob(d + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("pnn::", "").replace("void ", "")[:40]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith("gather")]
+LAST = ("fuse_reduce", "tconv_cout1")
+starts = [i for i, r in enumerate(rows) if i > 0 and rows[i - 1][2].startswith(LAST) and not r[2].startswith(LAST)]
 # the timed steps are the longest run of equally long gather-to-gather segments: take the 6 segments before the last 2
 segs = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
-pick = [s for s in segs if s[1] - s[0] == min(b - a for a, b in segs)][-8:-2]
+# the timed steps are the bulk of the equally long segments (0.4 s of ramp-up steps + the timed regions); the per-launch-timed
+# passes of the roofline section at the end have the same kernels with event gaps between them: take the 6 segments around
+# the MEDIAN span, not the last ones
+cand = [s for s in segs if s[1] - s[0] == min(b - a for a, b in segs)]
+cand.sort(key=lambda s: rows[s[1]][0] - rows[s[0]][0])
+mid = len(cand) // 2
+pick = sorted(cand[max(0, mid - 3):mid + 3])
 tot_busy = tot_span = 0
 for a, b in pick:
     tot_span += rows[b][0] - rows[a][0]
