@@ -460,6 +460,51 @@ def test_batching_service_survives_bad_clients(tmp_path):
         s.close()
 
 
+def test_batching_service_many_clients_over_io_threads(tmp_path, monkeypatch):
+    """The server's socket side runs on several I/O threads (a connection belongs to one of them for life; the workers hand a
+    reply to the owner's queue): 48 clients on 4 I/O threads, 60 requests each over the five widths and both input shapes -- every
+    reply must be the answer to ITS request, and clients that vanish in the middle must not disturb the rest."""
+    import threading
+    from context_adaptive_neural_network_based_prediction_amd import service
+
+    def backend(width, above, left):
+        s = above.sum(axis=1) + (left.sum(axis=1) if left is not None and left.size else 0.0)
+        return np.tile(np.round(s).astype(np.int32)[:, None, None], (1, width, width))
+
+    monkeypatch.setenv("PNN_SERVICE_IO_THREADS", "4")
+    monkeypatch.setenv("PNN_CACHE_MB", "0")                  # every request reaches the server
+    sock = str(tmp_path / "pnn.sock")
+    srv = service.serve_in_thread(sock, backend=backend, max_batch=16, window_us=0)
+    bad = []
+
+    def client(k):
+        rng = np.random.RandomState(k)
+        c = service.Client(sock)
+        try:
+            for it in range(60):
+                w = int(rng.choice([4, 8, 16, 32]))
+                if (k + it) % 2:
+                    a = rng.randint(0, 5, 5 * w * w).astype(np.float32)
+                    got, want = c.predict_pel(w, a), int(a.sum())
+                else:
+                    a, l = rng.randint(0, 5, 3 * w * w).astype(np.float32), rng.randint(0, 5, 2 * w * w).astype(np.float32)
+                    got, want = c.predict_pel(w, a, l), int(a.sum() + l.sum())
+                if not np.array_equal(got, np.full((w, w), want, np.int32)):
+                    bad.append((k, it))
+                if k % 12 == 11 and it == 20:
+                    return                                    # this client just goes away (its connection is closed below)
+        finally:
+            c.close()
+    ts = [threading.Thread(target=client, args=(k,)) for k in range(48)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    stats = srv.stop()
+    assert not bad, bad[:5]
+    assert srv.rc == 0 and stats["clients"] == 48 and stats["requests"] == 44 * 60 + 4 * 21
+
+
 def test_host_code_under_sanitizers(tmp_path):
     """the host-only part of the library (context gather, descriptor builder, model-table parser,
     batching server + client incl. misbehaving clients) and the CPU oracle under AddressSanitizer + UBSan
