@@ -374,7 +374,7 @@ def hm_campaigns(which, devices, quick=False):
     for name in which:
         work = tempfile.mkdtemp(prefix="pnn_bench_hm_")
         try:
-            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None))
+            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300)   # per codec process: a wedged service must not hold the line for long
         except Exception as e:                        # noqa: BLE001
             out[name] = {"error": repr(e)[:2000]}
         finally:
