@@ -131,6 +131,7 @@ struct pnn_ctx {
     // during the call; plane == NULL: the contexts were gathered into the staging buffer as usual)
     struct LazyGather { const void* plane = nullptr; const void* tbs = nullptr; int pel_bytes = 0, unit = 0; } lazy;
     long opt_fuse_gather = 1;
+    long opt_ring_pm = 1;                             // ring kernel: position-major tiles that skip the taps in the padding (pnn_gemm_ring.hip)
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;

@@ -36,7 +36,14 @@
 // no longer waits for ~20 MB of dirty lines: kernel-to-kernel 39.1 -> 37.5 us).  The workgroups of a launch end 2.4-3.8 us
 // apart although they execute the same cycle count: the spread is by XCD (each holds its own clock under the power limit).
 #include "pnn_kernels.h"
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <queue>
 #include <type_traits>
+#include <vector>
 #include "pnn_device_common.h"
 
 namespace pnn {
@@ -112,11 +119,37 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     const int l31 = lane & 31, h = lane >> 5;
     const int cls = blockIdx.z;
     const int n0 = blockIdx.y * BN;
-    const int mblk = blockIdx.x * BM;
     const int SP = p.SH * p.SW;
     const int cpt = p.Cin >> 4;
     const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
-    const int nchunks = (t1 - t0) * cpt;
+    // Position-major tiles (p.pm_groups > 0, convolutions at batch): the tile's BM rows are BM blocks at ONE position (pmi,
+    // pmj) of the SH x SW grid, first block mblk.  A tap then lies inside the image for every row or for none, and the taps
+    // that only meet SAME padding (31 % of a 3x3 layer's on a 4x4 map) are skipped -- no loads, no MFMAs.  Their products
+    // are exact zeros, so every output keeps its bits.  tmask = this class's taps that stay (all of them otherwise).
+    const int pmg = p.pm_groups;
+    int pmi = 0, pmj = 0;
+    int mblk = blockIdx.x * BM;
+    unsigned tmask = t1 - t0 >= 32 ? 0xffffffffu : (1u << (t1 - t0)) - 1u;
+    if (pmg) {
+        // launch order: chunks of 8 block groups; within a chunk position rank by position rank, the 8 groups side by side --
+        // workgroups i, i + 8, ... run on one XCD, so each XCD walks the positions of ONE group at a time and its L2 keeps that
+        // group's input maps while the taps re-read them (all groups interleaved: 8x8 conv net at batch 4096 5 % slower)
+        const int gc = blockIdx.x / (SP * 8), r = blockIdx.x - gc * (SP * 8);
+        const int c = gc < (pmg >> 3) ? 8 : (pmg & 7);
+        const int pr = r / c;
+        const int pos = SP <= 64 ? (int)((p.pos_order[pr >> 2] >> ((pr & 3) * 8)) & 0xffu) : pr;
+        pmi = pos / p.SW;
+        pmj = pos - pmi * p.SW;
+        mblk = (gc * 8 + r - pr * c) * BM;
+        unsigned m = 0;
+        for (int t = t0; t < t1; t++) {
+            const int tp = p.tap[t];
+            const int iy = pmi * p.a + (tp >> 16), ix = pmj * p.a + (int)(short)(tp & 0xffff);
+            if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) m |= 1u << (t - t0);
+        }
+        tmask = m ? m : 1u;                          // no tap inside: one of them fetches zeros
+    }
+    const int nchunks = __builtin_popcount(tmask) * cpt;
     const int nstages = (nchunks + KC - 1) / KC;
     const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X);
     const char* __restrict__ Zb = reinterpret_cast<const char*>(p.zero);
@@ -152,17 +185,21 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 const int i = i0 + u * 512;
                 const int ic = i < BM * (BN / 4) ? i : tid;
                 const int row = ic / (BN / 4), q = ic - row * (BN / 4);
-                const int mg = mblk + row;
+                const int mg = mblk + row;          // position-major: the BLOCK
                 const int nq = (n0 >> 2) + q;         // piece index within the output pixel's [Cout/4] pieces
                 size_t opix = mg;
-                if (SP != 1 || p.os != 1) {
+                bool rowok = mg < p.M;
+                if (pmg) {
+                    rowok = mg < p.nblk;
+                    opix = ((size_t)mg * p.OH + pmi * p.os + cpy) * p.OW + pmj * p.os + cpx;
+                } else if (SP != 1 || p.os != 1) {
                     const int pbq = mg / SP;
                     const int rq = mg - pbq * SP;
                     const int piq = rq / p.SW, pjq = rq - piq * p.SW;
                     opix = ((size_t)pbq * p.OH + piq * p.os + cpy) * p.OW + pjq * p.os + cpx;
                 }
                 v[u] = ring[row * OPP + q];
-                dst[u] = (i < BM * (BN / 4) && mg < p.M && nq < (p.Cout >> 2)) ? yo + (opix * (p.Cout >> 2) + nq) : nullptr;
+                dst[u] = (i < BM * (BN / 4) && rowok && nq < (p.Cout >> 2)) ? yo + (opix * (p.Cout >> 2) + nq) : nullptr;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++)
@@ -182,10 +219,12 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
             const int row = L / PPR, slot = L - row * PPR;
             lpiece[r] = slot ^ ((row / RPS) % PPR);
             const int mg = mblk + row;
-            lv[r] = mg < p.M;
+            lv[r] = pmg ? mg < p.nblk : mg < p.M;
             const int mc = lv[r] ? mg : 0;
             if (SP == 1) {                            // fully-connected layer (wave-uniform): no divisions on the start-up path
                 lb[r] = mc; li[r] = 0; lj[r] = 0;
+            } else if (pmg) {
+                lb[r] = mc; li[r] = pmi; lj[r] = pmj;
             } else {
                 const unsigned b = (unsigned)mc / (unsigned)SP;
                 const unsigned q = (unsigned)mc - b * (unsigned)SP;
@@ -225,9 +264,14 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
             boff[r] = (unsigned)(((j * 4 + qq) * p.Npad + n0 + nn) << 4);
         }
         const unsigned bstride = (unsigned)(KC * 4 * p.Npad) << 4;   // bytes per stage in the packed weights
-        int it = t0, icc = 0, istage = 0;               // issue-side position
-        int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
-        tap_setup(p.tap[t0]);
+        // issue-side position: tap `it` (the lowest of tmask first), chunk icc within it, ring stage istage, stage wst of the
+        // class's packed weights (== istage unless taps are skipped); rem = the taps after `it`
+        unsigned rem = tmask;
+        int it = t0 + __builtin_ctz(rem), icc = 0, istage = 0;
+        rem &= rem - 1;
+        int wst = (it - t0) * (cpt / KC);
+        int tp_next = p.tap[rem ? t0 + __builtin_ctz(rem) : it];
+        tap_setup(p.tap[it]);
         auto issue = [&]() {                             // fetch stage `istage` into ring buffer istage % D, then advance
             f32x4* dst = ring + (istage % D) * SS;
 #pragma unroll
@@ -238,14 +282,17 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
             }
 #pragma unroll
             for (int r = 0; r < NLB; r++)
-                if (wave + 4 * r < NBI) blds16(wrsrc, boff[r] + (unsigned)istage * bstride, dst + ASLOTS + 64 * (wave + 4 * r));   // wave-uniform
+                if (wave + 4 * r < NBI) blds16(wrsrc, boff[r] + (unsigned)wst * bstride, dst + ASLOTS + 64 * (wave + 4 * r));   // wave-uniform
             ++istage;
+            ++wst;
             icc += KC;
-            if (icc >= cpt && it + 1 < t1) {             // wave-uniform
+            if (icc >= cpt && rem) {                     // wave-uniform
                 icc = 0;
-                ++it;
+                it = t0 + __builtin_ctz(rem);
+                rem &= rem - 1;
+                wst = (it - t0) * (cpt / KC);
                 tap_setup(tp_next);
-                tp_next = p.tap[it + 1 < t1 ? it + 1 : it];
+                tp_next = p.tap[rem ? t0 + __builtin_ctz(rem) : it];
             }
         };
 
@@ -515,13 +562,16 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
         for (int rt = 0; rt < RT; rt++) {
             const int lrow = wm * (32 * RT) + rt * 32 + l31;
             const int mg = mblk + lrow;
-            const bool rowok = mg < p.M;
+            const bool rowok = pmg ? mg < p.nblk : mg < p.M;
             size_t obase = 0;
             if (kDirect) {
                 const int mc = rowok ? mg : 0;
-                const int pbq = mc / SP;
-                const int rq = mc - pbq * SP;
-                const int piq = rq / p.SW, pjq = rq - piq * p.SW;
+                int pbq = mc, piq = pmi, pjq = pmj;
+                if (!pmg) {
+                    pbq = mc / SP;
+                    const int rq = mc - pbq * SP;
+                    piq = rq / p.SW; pjq = rq - piq * p.SW;
+                }
                 const int oy = piq * p.os + py, ox = pjq * p.os + px;
                 obase = (((size_t)pbq * p.OH + oy) * p.OW + ox) * p.Cout;
             }
@@ -724,6 +774,97 @@ hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, cons
     return hipGetLastError();
 }
 
+// Position-major tiles (see ring_layer): when are they the faster launch?  Skipping the padding taps makes the workgroups
+// unequal (a corner of a 3x3 layer keeps 4 taps of 9, the interior all 9), and at the batch sizes of the bench a layer is only
+// one or two workgroups per CU, so what counts is not the work saved but the LAST workgroup to finish.  Both launches are
+// therefore list-scheduled on the chip's workgroup slots with a cost of (kWgFixed + stages) per workgroup -- measured: start
+// and epilogue of a 128 x 128 tile cost about as much as ten stages -- and position-major tiles are taken when they do not
+// end later (a tie is a win in practice: less traffic and power for the same critical path; conv 16x16 at batch 1024, same
+// box: 40.8 -> 39.8, 30.5 -> 28.7, 19.8 -> 18.7, 30.7 -> 27.5 us on the four layers where that holds).  One block group's
+// input maps must fit an XCD's L2 (the positions of a group run on one XCD and re-read them tap by tap): 192-row tiles on
+// the 8x24x64 maps of the 16x16 net's third layer fetched 190 MB instead of 71 and ran 78 us instead of 61.
+// p.pm_groups on entry: -1 = never (option ring_pm = 0), 1 = whenever possible (ring_pm = 2, tests), 0 = by this model.
+namespace {
+constexpr double kWgFixed = 10.0;
+struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; };
+
+double list_schedule(const std::vector<double>& cost, int slots)
+{
+    if ((int)cost.size() <= slots) return cost.empty() ? 0.0 : *std::max_element(cost.begin(), cost.end());
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < slots; i++) free_at.push(0.0);
+    double end = 0.0;
+    for (double c : cost) {
+        const double t = free_at.top() + c;
+        free_at.pop();
+        free_at.push(t);
+        end = std::max(end, t);
+    }
+    return end;
+}
+
+PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_t lds)
+{
+    PmPlan plan;
+    const int SP = p.SH * p.SW, ntaps = p.tap_begin[p.ncls];
+    if (p.pm_groups < 0 || SP <= 1 || ntaps <= p.ncls || p.W2p || p.M % SP || (p.Cin / 16) % KC) return plan;
+    const long B = p.M / SP;
+    if (2 * B < BM) return plan;
+    const long groups = (B + BM - 1) / BM;
+    if (groups * SP > 0x7fffffffL / BM) return plan;
+    std::vector<int> cnt((size_t)SP * p.ncls), total(SP, 0);         // in-image taps per (class, position)
+    long inside = 0;
+    for (int pos = 0; pos < SP; pos++) {
+        const int i = pos / p.SW, j = pos % p.SW;
+        for (int cls = 0; cls < p.ncls; cls++) {
+            int n = 0;
+            for (int t = p.tap_begin[cls]; t < p.tap_begin[cls + 1]; t++) {
+                const int iy = i * p.a + (p.tap[t] >> 16), ix = j * p.a + (int)(short)(p.tap[t] & 0xffff);
+                n += iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            }
+            cnt[(size_t)cls * SP + pos] = n ? n : 1;
+            total[pos] += n ? n : 1;
+        }
+        inside += total[pos];
+    }
+    if (inside >= (long)SP * ntaps) return plan;                     // nothing to skip
+    std::vector<int> order(SP);
+    for (int i = 0; i < SP; i++) order[i] = i;
+    if (SP <= 64) {                                  // heaviest positions first: the light ones fill the tail of the launch
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return total[a] > total[b]; });
+        for (int i = 0; i < SP; i++) plan.order[i >> 2] |= (unsigned)order[i] << ((i & 3) * 8);
+    }
+    plan.groups = (int)groups;
+    if (p.pm_groups == 1) { plan.use = true; return plan; }
+    if ((double)BM * p.IH * p.IW * p.Cin * 4.0 > 4.5 * 1048576.0) return plan;   // a block group's input against the 4 MB L2 of an XCD
+    const int slots = 256 * (lds <= 80 * 1024 ? 2 : 1);
+    const int spt = p.Cin / 16 / KC, gy = (p.Cout + BN - 1) / BN;
+    std::vector<double> bm, pm;
+    for (int cls = 0; cls < p.ncls; cls++) {
+        const int nt = p.tap_begin[cls + 1] - p.tap_begin[cls];
+        bm.insert(bm.end(), (size_t)((p.M + BM - 1) / BM) * gy, kWgFixed + (double)nt * spt);
+        for (int y = 0; y < gy; y++)
+            for (long g0 = 0; g0 < groups; g0 += 8)                  // the kernel's launch order: chunks of 8 groups
+                for (int pr = 0; pr < SP; pr++) pm.insert(pm.end(), (size_t)std::min(8L, groups - g0), kWgFixed + (double)cnt[(size_t)cls * SP + order[pr]] * spt);
+    }
+    plan.use = list_schedule(pm, slots) <= list_schedule(bm, slots);
+    return plan;
+}
+
+// the plan of a launch shape is computed once per thread (a few microseconds of host time otherwise, per launch)
+const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds)
+{
+    typedef std::array<int, 14> Key;
+    thread_local std::map<Key, PmPlan> plans;
+    int taps_hash = 0;
+    for (int t = 0; t < p.tap_begin[p.ncls]; t++) taps_hash = taps_hash * 31 + p.tap[t];
+    const Key key = {p.M, p.SH, p.SW, p.IH, p.IW, p.Cin, p.Cout, p.a, p.ncls, taps_hash, BM, BN, KC * 4 + (p.pm_groups + 1), (int)(lds >> 10)};
+    auto it = plans.find(key);
+    if (it == plans.end()) it = plans.emplace(key, plan_position_major(p, BM, BN, KC, lds)).first;
+    return it->second;
+}
+}  // namespace
+
 template <int RT, int NT, int KC, int WM, int D, bool FUSE = false>
 static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
 {
@@ -737,7 +878,20 @@ static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
         attr_set = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
-    pnn_launch(tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>, grid, dim3(512), lds, s, p);
+    TapGemmParams q = p;
+    q.pm_groups = 0;
+    if (!FUSE && p.pm_groups >= 0 && p.SH * p.SW > 1) {
+        const PmPlan& plan = position_major_plan(p, BM, BN, KC, lds);
+        if (plan.use) {
+            q.pm_groups = plan.groups;
+            q.nblk = p.M / (p.SH * p.SW);
+            for (int i = 0; i < 16; i++) q.pos_order[i] = plan.order[i];
+            grid.x = (unsigned)(plan.groups * p.SH * p.SW);
+            static const bool debug = getenv("PNN_DEBUG") != nullptr;
+            if (debug) fprintf(stderr, "[pnn] ring %dx%d: position-major tiles, %d block groups x %d positions\n", BM, BN, plan.groups, p.SH * p.SW);
+        }
+    }
+    pnn_launch(tapgemm_ring_kernel<RT, NT, KC, WM, D, FUSE>, grid, dim3(512), lds, s, q);
     return hipGetLastError();
 }
 

@@ -68,6 +68,12 @@ struct TapGemmParams {
     int chunk_begin[kMaxClasses + 1];   // first packed 16-deep chunk of each class (classes padded to kChunkPad)
     int py[kMaxClasses], px[kMaxClasses];
     int tap[kMaxTaps];   // (dy << 16) | (dx & 0xffff): one scalar load per tap
+    // ring kernel, position-major tiles (set by launch_tapgemm_ring, see pnn_gemm_ring.hip): pm_groups > 0 = a workgroup's BM
+    // rows are BM BLOCKS at ONE position of the SH x SW grid (block group blockIdx.x % pm_groups, position rank blockIdx.x /
+    // pm_groups), so a tap that falls outside the image does so for the whole tile and is skipped; nblk = number of blocks;
+    // pos_order = the positions by decreasing number of in-image taps, one byte each (grids of <= 64 positions; else rank = position)
+    int pm_groups, nblk;
+    unsigned pos_order[16];
 };
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 

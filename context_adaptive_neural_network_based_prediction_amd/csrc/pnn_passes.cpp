@@ -90,6 +90,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         p.Xlo = c->stage_tbs.p;
     } p.bias = L.d_bias; p.Y = Y; p.Yhi = Yhi; p.Ylo = Ylo; p.Yi = Yi;
     p.mean = c->mean; p.out_scale = L.sp_inv_scale; p.range_flag = c->h_range;
+    p.pm_groups = c->opt_ring_pm == 0 ? -1 : c->opt_ring_pm == 2 ? 1 : 0;   // ring kernel, position-major tiles: never / whenever possible / by its model (launch_tapgemm_ring)
     const long M = nblocks * p.SH * p.SW;
     if (M > 0x7fffffffL) return fail(c, PNN_E_ARG, "batch too large for one pass");
     p.M = (int)M;

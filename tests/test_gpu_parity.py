@@ -308,6 +308,38 @@ def test_split_gemm_kernel_families_bit_identical(pnn, precision, w, is_fc, n):
             assert np.array_equal(run(), want), "split-GEMM configuration code %d changes the result" % code
 
 
+@pytest.mark.parametrize("w,n", [(16, 384), (16, 300), (8, 1024), (32, 130)])
+def test_ring_position_major_tiles_bit_identical(pnn, oracle, precision, w, n):
+    """Convolutions at batch on the ring kernel take position-major tiles (a tile = many blocks at ONE position of the map)
+    and skip the taps that only meet the SAME padding there.  The skipped products are exact zeros: with the option off
+    (ring_pm = 0: block-major tiles, every tap) not one bit of the float predictions may differ -- whole block groups (384 = 3 x 128),
+    a ragged last group (300, 130), stride-2 convolutions and the four classes of the stride-2 transposed ones."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, False, 77, out_gain=util.out_gain(w, False))
+    above, left = util.make_contexts(w, n, 78)
+    net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
+    net.set_option("canonical_order", 1)
+    net.set_option("autotune", 0)
+    ncodes = L.pnn_num_split_configs()
+    want = None
+    for code in range(-1, ncodes):                                   # -1: the rule-based choice; the ring kernel's codes are among the rest
+        net.set_option("sp_cfg", code)
+        net.set_option("ring_pm", 0)
+        plain = net.predict(above, left)
+        for mode in (2, 1):                                          # 2: wherever possible; 1 (default): where the launch model expects a gain
+            net.set_option("ring_pm", mode)
+            assert np.array_equal(net.predict(above, left), plain), "position-major tiles change the result (configuration code %d)" % code
+        if want is None:
+            want = plain
+        assert np.array_equal(plain, want)
+    m = min(n, 48)
+    np.testing.assert_allclose(want[:m, ..., 0], oracle.conv_forward(params, w, above[:m], left[:m]), rtol=0, atol=FLOAT_ATOL)
+    net.close()
+
+
 @pytest.mark.parametrize("w,is_fc", [(8, True), (16, False)])
 def test_prediction_cache_for_single_block_calls(pnn, w, is_fc):
     """`cache_mb`: a repeated single-block call (HM's RDO re-evaluates the same TB) is answered from the cache with the
