@@ -199,7 +199,7 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
     if (rc) return rc;
     free_model(c->models[idx]);
     c->models[idx] = m;
-    c->tuned.clear();                                 // keys point into the replaced model
+    c->tuned.clear(); c->tune_gen++;                                 // keys point into the replaced model
     cache_clear(c);
     return PNN_OK;
 }
@@ -302,18 +302,18 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
     else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
     else if (!strcmp(name, "precision")) c->opt_precision = value;
-    else if (!strcmp(name, "autotune")) c->opt_autotune = value;
-    else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); }
-    else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); }
+    else if (!strcmp(name, "autotune")) { c->opt_autotune = value; c->tune_gen++; }
+    else if (!strcmp(name, "convimg")) { c->opt_convimg = value; c->tuned.clear(); c->tune_gen++; }
+    else if (!strcmp(name, "ring")) { c->opt_ring = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "small")) c->opt_small = value;
     else if (!strcmp(name, "small_max_tiles")) c->opt_small_tiles = value;
     else if (!strcmp(name, "pair")) c->opt_pair = value;
     else if (!strcmp(name, "fc_out")) c->opt_fc_out = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
-    else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); }
+    else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "fuse_gather")) c->opt_fuse_gather = value;
-    else if (!strcmp(name, "ring_pm")) { c->opt_ring_pm = value; c->tuned.clear(); }
+    else if (!strcmp(name, "ring_pm")) { c->opt_ring_pm = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }

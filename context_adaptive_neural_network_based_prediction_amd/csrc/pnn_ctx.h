@@ -117,6 +117,11 @@ struct pnn_ctx {
     long opt_convimg = 1;                             // 1: stride/tap layers whose images fit LDS use convimg_sp_kernel
     long opt_autotune = 2;                            // on-device choice of the split-GEMM configuration: 0 never, 1 always, 2 big launches only
     std::map<std::pair<const void*, long>, int> tuned;
+    // conv passes at batch: the branches' later layers overlap on two streams (pnn_passes.cpp, "branch_streams") only once a
+    // pass of the same (model, blocks) has run on ONE stream without a tuning sweep -- a sweep times launches on its stream and
+    // must not have the other branch beside it.  tune_gen counts sweeps and resets of `tuned`; the map holds its value after such a pass
+    long tune_gen = 0;
+    std::map<std::pair<const void*, long>, long> overlap_ready;
     long opt_time_launches = 0;                       // 1: bracket every tap-GEMM launch with HIP events (bench roofline)
     struct LaunchRec { hipEvent_t e0, e1; int kind; double flops; };
     std::vector<LaunchRec> launch_recs;

@@ -14,6 +14,7 @@ int tuned_cfg(pnn_ctx* c, const void* key_ptr, long M, int ncodes, int rule, con
     const auto key = std::make_pair(key_ptr, M);
     auto it = c->tuned.find(key);
     if (it != c->tuned.end()) { *cfg = it->second; if (best_us) *best_us = -1.f; return PNN_OK; }
+    c->tune_gen++;                                    // a sweep runs: see pnn_ctx::overlap_ready
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));

@@ -699,6 +699,30 @@ def test_contexts_sharing_the_gpu_stay_repeatable(pnn):
     assert out == {"fc8-a": 0, "fc8-b": 0, "conv16": 0}, out
 
 
+@pytest.mark.parametrize("w,n", [(16, 384), (32, 96)])
+def test_conv_branches_overlap_at_batch(pnn, oracle, precision, w, n):
+    """Passes at batch overlap the two branches on two streams as well -- from the third pass of a shape on (the first may
+    tune, the second proves that nothing is left to tune).  Same predictions as on one stream, pass after pass, also when a
+    smaller batch and single-block calls (their own overlap rules, the shared side buffers) come in between."""
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    params = util.make_params(w, False, 83, out_gain=util.out_gain(w, False))
+    above, left = util.make_contexts(w, n, 84)
+    net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
+    net.set_option("branch_streams", 0)
+    want = net.predict(above, left).copy()
+    small = net.predict(above[:5], left[:5]).copy()
+    net.set_option("branch_streams", 1)
+    for rep in range(6):
+        assert np.array_equal(net.predict(above, left), want), "pass %d differs" % rep
+        if rep == 3:
+            assert np.array_equal(net.predict(above[:5], left[:5]), small)
+            assert np.array_equal(net.predict(above[:1], left[:1]), small[:1])
+    m = min(n, 32)
+    np.testing.assert_allclose(want[:m, ..., 0], oracle.conv_forward(params, w, above[:m], left[:m]), rtol=0, atol=FLOAT_ATOL)
+    net.close()
+
+
 @pytest.mark.parametrize("w", [16, 32, 64])
 def test_conv_branches_on_two_streams(pnn, oracle, w):
     """Option "branch_streams": small conv passes run the two branches concurrently on two HIP streams (fork / join by
