@@ -92,8 +92,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * "split_min_px" (-1, default: built-in rule; >= 0: with precision 1, passes through a convolutional net use the
  * split-precision kernels from this many block pixels (blocks x w^2) on and the exact-f32 kernels below -- tuning aid),
  * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
- * calls -- run the two independent branches on two HIP streams, forked and joined by events; 2: every small conv
- * pass; 0: one stream.  Results do not depend on it),
+ * calls -- run the two independent branches on two HIP streams, forked and joined by events, and so do passes at batch
+ * (>= 65536 block pixels on the split-precision kernels) from the third pass of a shape on, i.e. once a one-stream pass
+ * needed no tuning sweep; 2: also every small conv pass; 0: one stream.  Results do not depend on it),
  * "small" (1, default: split-precision GEMMs with at most "small_max_tiles" (512) output tiles of 32 x 32 -- single-block
  * calls, small batches -- run on tapgemm_small_kernel, one wave per tile spread over the chip, in the SAME per-output
  * summation order as the big-tile kernels; 0: big-tile kernels only),
