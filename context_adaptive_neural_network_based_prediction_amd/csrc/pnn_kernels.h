@@ -41,13 +41,23 @@ struct TapGemmParams {
     // convimg kernel, fused FIRST convolution of a branch (Cin = 1 -> this layer's Cin channels, stride s0, kernel k0 x k0,
     // SAME padding with pad0 before, LeakyReLU): X0 != NULL makes the kernel compute its input maps from the raw f32
     // context X0 [images][IH * s0][IW * s0] instead of reading them from X (see pnn_convimg_sp.hip)
-    const float* X0; const float* W0; const float* B0; int s0, k0, pad0;
-    const float* W0sp; float scale0; int Npad0;   // the first convolution's taps x channels matrix in the split pack (FirstConv, pnn_device_common.h)
-    // ... and, when plane0 != NULL, the context gather too (extraction_context.cpp:3-208): X0 is not read; image i's raw context
-    // comes straight from the picture plane through TB descriptor tbs0[i] -- branch0 = 0: the above portion (rows y - w ..
-    // y - 1, columns x - w .. x + 2w - 1, masked per unit0-pixel unit), 1: the left portion (rows y .. y + 2w - 1, columns
-    // x - w .. x - 1, the first left_units units) --, Pel (pel0 bytes) -> float, minus `mean`
-    const void* plane0; const void* tbs0; int pel0, branch0, unit0, w0;
+    // (The ring kernel never reads these fields; its position-major launches keep their position order in the same bytes --
+    // pos_order below -- so that the argument block stays at 8 lines of 64 bytes: every line is a round trip at kernel entry,
+    // and a ninth cost the FC 8x8 pass 0.7 %.)
+    union {
+        struct {
+            const float* X0; const float* W0; const float* B0; int s0, k0, pad0;
+            const float* W0sp; float scale0; int Npad0;   // the first convolution's taps x channels matrix in the split pack (FirstConv, pnn_device_common.h)
+            // ... and, when plane0 != NULL, the context gather too (extraction_context.cpp:3-208): X0 is not read; image i's raw context
+            // comes straight from the picture plane through TB descriptor tbs0[i] -- branch0 = 0: the above portion (rows y - w ..
+            // y - 1, columns x - w .. x + 2w - 1, masked per unit0-pixel unit), 1: the left portion (rows y .. y + 2w - 1, columns
+            // x - w .. x - 1, the first left_units units) --, Pel (pel0 bytes) -> float, minus `mean`
+            const void* plane0; const void* tbs0; int pel0, branch0, unit0, w0;
+        };
+        // ring kernel, position-major tiles: the positions by decreasing number of in-image taps, one byte each (grids of <= 64
+        // positions; larger grids: rank = position)
+        unsigned pos_order[16];
+    };
     const float* Wp;
     const float* bias;
     float* Y;          // float output (may be null when Yi is set)
@@ -69,12 +79,11 @@ struct TapGemmParams {
     int py[kMaxClasses], px[kMaxClasses];
     int tap[kMaxTaps];   // (dy << 16) | (dx & 0xffff): one scalar load per tap
     // ring kernel, position-major tiles (set by launch_tapgemm_ring, see pnn_gemm_ring.hip): pm_groups > 0 = a workgroup's BM
-    // rows are BM BLOCKS at ONE position of the SH x SW grid (block group blockIdx.x % pm_groups, position rank blockIdx.x /
-    // pm_groups), so a tap that falls outside the image does so for the whole tile and is skipped; nblk = number of blocks;
-    // pos_order = the positions by decreasing number of in-image taps, one byte each (grids of <= 64 positions; else rank = position)
+    // rows are BM BLOCKS at ONE position of the SH x SW grid, so a tap that falls outside the image does so for the whole
+    // tile and is skipped; pm_groups = number of block groups, nblk = number of blocks; the position order: pos_order above
     int pm_groups, nblk;
-    unsigned pos_order[16];
 };
+static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.

@@ -6,6 +6,10 @@ export TMPDIR=/tmp
 r=${1:-r01}
 out=gpurun_out/profiles_$r
 mkdir -p $out
+# kernel durations are taken with the branches of a conv pass on ONE stream (PNN_BRANCH_STREAMS=0): side by side on two
+# streams (the default at batch) two kernels share the chip and each one's begin -> end says little;
+# bench.py's own per-launch timing (roofline.achieved) runs on one stream too.  conv16_step_timeline_overlap.txt is the default.
+export PNN_BRANCH_STREAMS=0
 for wl in fc8 conv16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_trace -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-sustained > $out/${wl}_trace.log 2>&1
   python3 tools/trace_summary.py $out/${wl}_trace > $out/${wl}_kernel_summary.txt
@@ -36,5 +40,9 @@ for wl in fc8 conv16; do   # timeline of one steady-state step (rule-based tiles
   python3 tools/trace_gaps.py $out/${wl}_tl > $out/${wl}_step_timeline.txt
   rm -rf $out/${wl}_tl
 done
+unset PNN_BRANCH_STREAMS
+PNN_AUTOTUNE=0 rocprofv3 --kernel-trace --output-format csv -d $out/conv16_tl2 -- python3 bench.py --workload conv16 --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-sustained > /dev/null 2>&1
+python3 tools/trace_gaps.py $out/conv16_tl2 > $out/conv16_step_timeline_overlap.txt
+rm -rf $out/conv16_tl2
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 ls -la $out

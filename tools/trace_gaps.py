@@ -21,14 +21,28 @@ cand = [s for s in segs if s[1] - s[0] == min(b - a for a, b in segs)]
 cand.sort(key=lambda s: rows[s[1]][0] - rows[s[0]][0])
 mid = len(cand) // 2
 pick = sorted(cand[max(0, mid - 3):mid + 3])
-tot_busy = tot_span = 0
+tot_busy = tot_span = tot_union = 0
 for a, b in pick:
     tot_span += rows[b][0] - rows[a][0]
     tot_busy += sum(r[1] - r[0] for r in rows[a:b])
+    end = rows[a][0]                                 # time with at least one kernel running (kernels of two streams overlap)
+    for r in rows[a:b]:
+        tot_union += max(0, r[1] - max(end, r[0]))
+        end = max(end, r[1])
 a, b = pick[-1]
+t0 = rows[a][0]
 prev_end = rows[a - 1][1]
+overlap = tot_busy > 1.02 * tot_union           # a few ns of timestamp overlap between back-to-back kernels are not concurrency
 print("one step (of %d averaged):" % len(pick))
 for r in rows[a:b]:
-    print("  gap %6.1f us | %-40s %7.1f us" % ((r[0] - prev_end) / 1e3, r[2], (r[1] - r[0]) / 1e3))
-    prev_end = r[1]
-print("mean step span %.1f us, kernels busy %.1f us, idle between kernels %.1f us" % (tot_span / len(pick) / 1e3, tot_busy / len(pick) / 1e3, (tot_span - tot_busy) / len(pick) / 1e3))
+    if overlap:                                      # start relative to the step's first kernel: concurrent kernels show as such
+        print("  start %6.1f us | %-40s %7.1f us" % ((r[0] - t0) / 1e3, r[2], (r[1] - r[0]) / 1e3))
+    else:
+        print("  gap %6.1f us | %-40s %7.1f us" % ((r[0] - prev_end) / 1e3, r[2], (r[1] - r[0]) / 1e3))
+    prev_end = max(prev_end, r[1])
+n = len(pick)
+if overlap:
+    print("mean step span %.1f us, sum of kernel durations %.1f us (kernels of two streams run side by side), no kernel running %.1f us"
+          % (tot_span / n / 1e3, tot_busy / n / 1e3, (tot_span - tot_union) / n / 1e3))
+else:
+    print("mean step span %.1f us, kernels busy %.1f us, idle between kernels %.1f us" % (tot_span / n / 1e3, tot_busy / n / 1e3, (tot_span - tot_busy) / n / 1e3))
