@@ -308,12 +308,12 @@ def test_split_gemm_kernel_families_bit_identical(pnn, precision, w, is_fc, n):
             assert np.array_equal(run(), want), "split-GEMM configuration code %d changes the result" % code
 
 
-@pytest.mark.parametrize("w,n", [(16, 384), (16, 300), (8, 1024), (32, 130)])
+@pytest.mark.parametrize("w,n", [(16, 384), (16, 300), (16, 1200), (8, 1024), (32, 130)])
 def test_ring_position_major_tiles_bit_identical(pnn, oracle, precision, w, n):
     """Convolutions at batch on the ring kernel take position-major tiles (a tile = many blocks at ONE position of the map)
     and skip the taps that only meet the SAME padding there.  The skipped products are exact zeros: with the option off
     (ring_pm = 0: block-major tiles, every tap) not one bit of the float predictions may differ -- whole block groups (384 = 3 x 128),
-    a ragged last group (300, 130), stride-2 convolutions and the four classes of the stride-2 transposed ones."""
+    a ragged last group (300, 130), a partial chunk of groups behind a whole one (1200 = 9.4 x 128), stride-2 convolutions and the four classes of the stride-2 transposed ones."""
     if precision != "split_f16":
         pytest.skip("split-precision kernels only")
     from context_adaptive_neural_network_based_prediction_amd import _lib
