@@ -104,6 +104,20 @@ int wait_stream(pnn_ctx* c, hipStream_t s)
     return PNN_OK;
 }
 
+// The last kernel of the pass took a completion signal (take_done_signal): spin on the flag word it raises in pinned host
+// memory behind its results.  Bounded: a launch that failed never raises it, the stream then says why.
+int wait_done_flag(pnn_ctx* c, hipStream_t s)
+{
+    const unsigned* flag = reinterpret_cast<const unsigned*>(c->h_range) + 1;
+    for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; spins++) {
+        if (spins < 200000) { __builtin_ia32_pause(); continue; }   // ~ a few milliseconds
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
+        break;
+    }
+    return PNN_OK;
+}
+
 // A host pass left the f16 range of the split-precision kernels (*c->h_range raised, stream idle).  Only the blocks that
 // overflow ALONE are recomputed on the exact-f32 kernels; every other block keeps its split-precision result -- the value it
 // gets in any other batch (canonical_order) -- so one overflowing block behind the batching service does not change the last
@@ -175,11 +189,17 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
     if (const char* e = getenv("PNN_FC_OUT")) c->opt_fc_out = atol(e);
     if (const char* e = getenv("PNN_SPIN_WAIT")) c->opt_spin_wait = atol(e);
+    if (const char* e = getenv("PNN_FLAG_WAIT")) c->opt_flag_wait = atol(e);
     if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
     }
     *c->h_range = 0;
+    c->h_range[1] = 0;                                // the completion flag of the small host calls (signal_done)
+    if (hipMalloc((void**)&c->d_done, 256) != hipSuccess || hipMemset(c->d_done, 0, 256) != hipSuccess) {
+        pnn_destroy(c);
+        return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the completion counter failed");
+    }
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -270,6 +290,7 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
+    if (c->d_done) (void)hipFree(c->d_done);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -310,6 +331,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "pair")) c->opt_pair = value;
     else if (!strcmp(name, "fc_out")) c->opt_fc_out = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
+    else if (!strcmp(name, "flag_wait")) c->opt_flag_wait = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "fuse_gather")) c->opt_fuse_gather = value;
@@ -556,9 +578,13 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         static const bool host_trace = getenv("PNN_HOST_TRACE") != nullptr;   // diagnostic: where a single-block call spends its time
         timespec ht0, ht1, ht2;
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht0);
-        if ((rc = pass(0, n))) return rc;
+        c->done_want = c->opt_flag_wait != 0;
+        c->done_armed = false;
+        rc = pass(0, n);
+        c->done_want = false;
+        if (rc) return rc;
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht1);
-        if ((rc = wait_stream(c, s))) return rc;
+        if ((rc = c->done_armed ? wait_done_flag(c, s) : wait_stream(c, s))) return rc;
         if (host_trace) {
             clock_gettime(CLOCK_MONOTONIC, &ht2);
             static double s_launch = 0, s_wait = 0; static long s_n = 0;

@@ -136,6 +136,13 @@ struct pnn_ctx {
     // during the call; plane == NULL: the contexts were gathered into the staging buffer as usual)
     struct LazyGather { const void* plane = nullptr; const void* tbs = nullptr; int pel_bytes = 0, unit = 0; } lazy;
     long opt_fuse_gather = 1;
+    // Completion flag of the small host calls (signal_done, pnn_device_common.h): h_range[1] is the flag word, d_done the
+    // workgroup counter; done_want = this pass is the last of a host call that will spin on the flag, done_armed = its last
+    // kernel took the signal (kernels that cannot -- the exact-f32 FC output layer -- leave it unset: the call then waits for the stream)
+    unsigned* d_done = nullptr;
+    unsigned done_seq = 0;
+    bool done_want = false, done_last_chunk = true, done_armed = false;
+    long opt_flag_wait = 1;
     long opt_ring_pm = 1;                             // ring kernel: position-major tiles that skip the taps in the padding (pnn_gemm_ring.hip)
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
@@ -169,6 +176,13 @@ int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double 
 // First sighting of (key, M): every legal configuration code in [0, ncodes) runs the real launch (idempotent) on stream
 // `s`, the fastest is remembered in c->tuned and returned in *cfg; later sightings return the remembered code.  `rule` =
 // the rule-based choice (kept unless beaten by > 3 %).  PNN_OK, or the error of a failed launch.
+// the completion signal for the last kernel of the current pass, or an empty one (see pnn_ctx::done_want)
+inline DoneSignal take_done_signal(pnn_ctx* c)
+{
+    if (!c->done_want || !c->done_last_chunk || !c->d_done) return DoneSignal{nullptr, nullptr, 0, 0};
+    c->done_armed = true;
+    return DoneSignal{c->d_done, reinterpret_cast<unsigned*>(c->h_range) + 1, ++c->done_seq, 0};
+}
 int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const std::function<bool(int)>& legal,
               const std::function<hipError_t(int)>& launch, hipStream_t s, int* cfg, float* best_us);
 // pnn_passes.cpp

@@ -21,6 +21,31 @@ __device__ __forceinline__ void touch_kernargs()
     asm volatile("" ::"s"(t));
 }
 
+// Completion signal of a host call (option "flag_wait", pnn_abi.cpp): the LAST kernel of the call -- after its results, which it
+// writes straight into pinned host memory -- raises a sequence number in pinned host memory, and the host thread spins on that
+// word instead of waiting for the runtime's completion signal (which the command processor writes only after the end-of-kernel
+// cache write-back, and which hipStreamSynchronize turns into a return a few microseconds later still).  Every thread of every
+// workgroup calls signal_done() after its last store; workgroups count themselves on a device-memory counter (agent-scope
+// atomics execute memory-side, coherent across the XCDs), the last one resets it and writes the flag.
+__device__ __forceinline__ void signal_done(const DoneSignal& d)
+{
+    if (!d.host_flag) return;                        // launch-uniform
+    __threadfence_system();                          // this thread's results are on their way to the host ...
+    __syncthreads();                                 // ... and so are the whole workgroup's
+    if (threadIdx.x == 0) {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        bool last = nwg == 1;
+        if (!last) {
+            last = atomicAdd(d.counter, 1u) == nwg - 1;
+            if (last) atomicExch(d.counter, 0u);
+        }
+        if (last) {
+            __threadfence_system();
+            __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // pnn/tfutils.py:192, max(0.1 v, v).  fmaxf() would put a canonicalising v_max_f32 v, v in front (the IEEE quieting of a
 // signalling NaN the compiler cannot rule out): three VALU instructions per value in epilogues that are VALU-bound; the
 // values here come out of v_fma_f32, which never produces a signalling NaN.

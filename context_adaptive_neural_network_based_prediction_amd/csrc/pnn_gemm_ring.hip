@@ -753,24 +753,26 @@ size_t tapgemm_ring_lds_bytes(const TileCfg& t)
 // Sums the column tiles' partial products of a fused layer in tile order, undoes the weight scale, adds the bias and
 // writes float and / or HM-epilogue outputs: Y[m][n] = bias[n] + scale * sum_t part[t][m][n], n < N2 <= 64.
 __global__ __launch_bounds__(256) void fuse_reduce_kernel(const float* __restrict__ part, int ntiles, int M, int N2, const float* __restrict__ bias,
-                                                          float scale, float mean, float* __restrict__ Y, int32_t* __restrict__ Yi)
+                                                          float scale, float mean, float* __restrict__ Y, int32_t* __restrict__ Yi, const DoneSignal done)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 consecutive columns
     const int m = (int)(i >> 4), n = (int)(i & 15) << 2;
-    if (m >= M || n >= N2) return;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < ntiles; t++) acc += *reinterpret_cast<const f32x4*>(part + ((size_t)t * M + m) * 64 + n);
-    const f32x4 v = acc * scale + *reinterpret_cast<const f32x4*>(bias + n);
-    if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)m * N2 + n) = v;
-    if (Yi) *reinterpret_cast<int4*>(Yi + (size_t)m * N2 + n) = make_int4(hm_round(v[0], mean), hm_round(v[1], mean), hm_round(v[2], mean), hm_round(v[3], mean));
+    if (m < M && n < N2) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < ntiles; t++) acc += *reinterpret_cast<const f32x4*>(part + ((size_t)t * M + m) * 64 + n);
+        const f32x4 v = acc * scale + *reinterpret_cast<const f32x4*>(bias + n);
+        if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)m * N2 + n) = v;
+        if (Yi) *reinterpret_cast<int4*>(Yi + (size_t)m * N2 + n) = make_int4(hm_round(v[0], mean), hm_round(v[1], mean), hm_round(v[2], mean), hm_round(v[3], mean));
+    }
+    signal_done(done);
 }
 
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
-                              hipStream_t s)
+                              hipStream_t s, const DoneSignal& done)
 {
     if (M <= 0) return hipSuccess;
     if (N2 % 4 || N2 > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fuse_reduce_kernel, dim3((unsigned)(((long)M * 16 + 255) / 256)), dim3(256), 0, s, part, ntiles, M, N2, bias, scale, mean, Y, Yi);
+    hipLaunchKernelGGL(fuse_reduce_kernel, dim3((unsigned)(((long)M * 16 + 255) / 256)), dim3(256), 0, s, part, ntiles, M, N2, bias, scale, mean, Y, Yi, done);
     return hipGetLastError();
 }
 

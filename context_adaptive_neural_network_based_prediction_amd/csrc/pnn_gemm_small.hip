@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void tapgemm_small_pair_kernel(const SmallArgs
 // operands go global -> registers (a segment is 10 chunks: NPF of them in flight, no LDS ring, no barrier in the loop);
 // the partials meet in LDS and are added in segment order, scaled, biased and rounded exactly as fuse_reduce_kernel does.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct FcOutArgs { TapGemmParams p; int seg; };
+struct FcOutArgs { TapGemmParams p; int seg; int pad; DoneSignal done; };
 template <int SEG>
 __global__ __launch_bounds__(512) void fc_out_small_kernel(const FcOutArgs args)
 {
@@ -352,12 +352,15 @@ __global__ __launch_bounds__(512) void fc_out_small_kernel(const FcOutArgs args)
     // fuse_reduce_kernel's arithmetic, one thread per 4 consecutive columns of a row
     const int mr = tid >> 4, n = (tid & 15) << 2;
     const int mg = mblk + mr;
-    if (mg >= p.M || n >= p.Cout) return;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nseg; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][mr][n]);
-    const f32x4 v = sum * p.out_scale + *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
-    if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    if (mg < p.M && n < p.Cout) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nseg; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][mr][n]);
+        const f32x4 v = sum * p.out_scale + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
+        if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    }
+    const DoneSignal done = {k->done.counter, k->done.host_flag, k->done.seq, 0};
+    signal_done(done);
 }
 
 // p: the output layer as a one-tap GEMM (X = split activations [M][Cin], Wp = its split pack, bias, out_scale, mean, Y / Yi);
@@ -368,10 +371,10 @@ bool fc_out_small_fits(const TapGemmParams& p, int seg_chunks)
     return seg_chunks == 10 && p.ncls == 1 && p.SH * p.SW == 1 && p.Cout <= 64 && p.Cout % 4 == 0 && (nchunks + seg_chunks - 1) / seg_chunks <= 8 && p.M > 0;
 }
 
-hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s)
+hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s, const DoneSignal& done)
 {
     if (!fc_out_small_fits(p, seg_chunks)) return hipErrorInvalidValue;
-    const FcOutArgs a{p, seg_chunks};
+    const FcOutArgs a{p, seg_chunks, 0, done};
     pnn_launch(fc_out_small_kernel<10>, dim3((unsigned)((p.M + 31) / 32)), dim3(512), 0, s, a);
     return hipGetLastError();
 }

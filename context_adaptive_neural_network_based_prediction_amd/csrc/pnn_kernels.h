@@ -7,6 +7,8 @@
 
 namespace pnn {
 
+struct DoneSignal { unsigned* counter; unsigned* host_flag; unsigned seq, pad; };   // see signal_done, pnn_device_common.h
+
 // Per-launch timing (pnn_abi.cpp, option time_launches): when set, the GEMM launchers attach these events to the kernel
 // itself (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end -- what rocprofv3
 // reports -- instead of the record-to-record time of two hipEventRecord calls around the launch (~4 us more).
@@ -100,7 +102,7 @@ TileCfg tapgemm_ring_cfg(int idx);
 size_t tapgemm_ring_lds_bytes(const TileCfg& t);
 bool tapgemm_ring_can_fuse(int idx);
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
-                              hipStream_t s);
+                              hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);
@@ -116,7 +118,7 @@ long tapgemm_small_tiles(const TapGemmParams& p);
 hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_chunks, hipStream_t s, const float* host_input = nullptr);
 // Output layer (<= 64 outputs) of an FC net at small M in one launch: K segments + their reduction (pnn_gemm_small.hip)
 bool fc_out_small_fits(const TapGemmParams& p, int seg_chunks);
-hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s);
+hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
@@ -139,6 +141,7 @@ struct TConv1Params {
     const float* X; const float* W; /* [k][k][Cin] */ float bias; float* Y; int32_t* Yi;
     int B, IH, IW, Cin, s, k, pad; float mean;
     int ni;   // images per workgroup (set by the launcher)
+    DoneSignal done;   // host_flag != NULL: this is the last kernel of a host call, see signal_done (pnn_device_common.h)
 };
 hipError_t launch_tconv_cout1(const TConv1Params& p, hipStream_t s);
 

@@ -404,12 +404,12 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
                         r.kind = 5; r.flops = flops;
                         const LaunchEvents ev{r.e0, r.e1};
                         g_launch_events = &ev;
-                        const hipError_t le = launch_fc_out_small(q, kFuseSegChunks, s);
+                        const hipError_t le = launch_fc_out_small(q, kFuseSegChunks, s, take_done_signal(c));
                         g_launch_events = nullptr;
                         HIPCHK(c, le);
                         c->launch_recs.push_back(r);
                     } else {
-                        HIPCHK(c, launch_fc_out_small(q, kFuseSegChunks, s));
+                        HIPCHK(c, launch_fc_out_small(q, kFuseSegChunks, s, take_done_signal(c)));
                     }
                     c->stat_gemm_launches++; c->stat_launches++;
                     c->stat_gemm_flops += flops;
@@ -418,7 +418,7 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
                 if ((rc = run_gemm_sp(c, m->fc[3], P0, nullptr, nullptr, nullptr, nullptr, nullptr, nb, s, nullptr, part, &tiles, nullptr, false, kFuseSegChunks))) return rc;
             }
             if (tiles <= 0 || tiles > 20) return fail(c, PNN_E_ARG, "output layer: %d K segments do not fit the partial buffer", tiles);
-            HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s));
+            HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, m->fc[3].sp_inv_scale, c->mean, d_out, d_dst, s, take_done_signal(c)));
             c->stat_launches++;
             return PNN_OK;
         }
@@ -559,6 +559,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     }
     TConv1Params tp = m->last.proto;
     tp.X = P[cur]; tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
+    tp.done = take_done_signal(c);
     HIPCHK(c, launch_tconv_cout1(tp, s));
     c->stat_launches++;
     // a pass of this shape went through on one stream without a tuning sweep: the next one may overlap its branches
@@ -601,11 +602,13 @@ int run_net(pnn_ctx* c, Model* m, const float* d_a, long pitch_a, const float* d
         float* o = d_out ? d_out + b0 * w * w : nullptr;
         int32_t* di = d_dst ? d_dst + b0 * w * w : nullptr;
         c->host_input = host_rows ? host_rows + b0 * pitch_a : nullptr;
+        c->done_last_chunk = b0 + nb >= n;            // only the call's last kernel may raise the completion flag
         rc = m->is_fc ? fc_pass(c, m, d_a + b0 * pitch_a, ctx_is_split, nb, o, di, s)
                       : conv_pass(c, m, d_a + b0 * pitch_a, d_l + b0 * pitch_l, nb, o, di, s);
         if (rc) break;
     }
     c->host_input = host_rows;
+    c->done_last_chunk = true;
     return rc;
 }
 

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
         if (p.Y) p.Y[o] = v;
         if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
     }
+    signal_done(p.done);
 }
 
 // The same layer for Cin == 64 (every reference net ends in it: k = 5, s = 2, 64 -> 1) on the fp32 matrix cores.
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void tconv_cout1_mfma_kernel(const TConv1Param
         if (p.Y) p.Y[o] = v;
         if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
     }
+    signal_done(p.done);
 }
 
 hipError_t launch_tconv_cout1(const TConv1Params& pin, hipStream_t s)

@@ -85,6 +85,10 @@ float pnn_mean(const pnn_ctx* ctx);
  * "fuse_gather" (1, default: pnn_predict_tbs_device / _cost_device on a convolutional net whose first convolutions run fused
  * inside the image kernel let that kernel read the contexts straight from the picture plane through the TB descriptors -- no
  * gather launch; bit-identical; 0: always gather first),
+ * "flag_wait" (1, default: a small host call -- pnn_predict_pel / pnn_predict_f32 / pnn_predict_f32_pel on up to 64 KiB of input,
+ * i.e. what HM and the batching service issue -- ends when the call's LAST kernel, behind its results in pinned host memory,
+ * raises a sequence number there, which the calling thread spins on, instead of when the runtime reports the stream idle:
+ * 3-7 us less per call; 0: hipStreamSynchronize.  Results do not depend on it),
  * "ring_pm" (1, default: convolutions at batch on the LDS-DMA ring kernel take position-major tiles -- a tile = many blocks at
  * ONE position of the feature map, so a tap that only meets the SAME padding there is skipped for the whole tile -- where
  * the launch model of pnn_gemm_ring.hip expects them to finish no later; 2: wherever possible; 0: never.  The skipped products
@@ -113,7 +117,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */

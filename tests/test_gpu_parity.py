@@ -830,6 +830,31 @@ def test_gather_fused_into_the_image_kernel(pnn, oracle, precision, w, n):
     net.close()
 
 
+@pytest.mark.parametrize("w,is_fc,n", [(4, True, 1500), (8, True, 600), (16, False, 300), (32, False, 60)])
+def test_completion_flag_of_small_host_calls(pnn, precision, w, is_fc, n):
+    """Option "flag_wait": a small host call returns when its last kernel has raised the completion flag behind its results in
+    pinned host memory.  A call that returned early would hand back the PREVIOUS call's block: n different blocks one after
+    the other, then in handfuls (several workgroups count themselves in) and in chunks (only the last chunk's last kernel
+    may signal), must equal what the same context returns when it waits for the stream."""
+    params = util.make_params(w, is_fc, 91, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 92)
+    rows = util.flatten_fc(above, left) if is_fc else None
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    net.set_option("canonical_order", 1)
+    call = (lambda a, b: net.predict_pel(rows[a:b])) if is_fc else (lambda a, b: net.predict_pel(above[a:b], left[a:b]))
+    net.set_option("flag_wait", 0)
+    want = np.concatenate([call(i, min(i + 50, n)) for i in range(0, n, 50)])
+    net.set_option("flag_wait", 1)
+    for i in range(n):
+        assert np.array_equal(call(i, i + 1)[0], want[i]), "single-block call %d" % i
+    for i in range(0, n - 7, 7):
+        assert np.array_equal(call(i, i + 7), want[i:i + 7]), "handful at %d" % i
+    net.set_option("max_chunk", 2)
+    for i in range(0, min(n, 60) - 5, 5):
+        assert np.array_equal(call(i, i + 5), want[i:i + 5]), "chunked call at %d" % i
+    net.close()
+
+
 def test_chunked_host_calls_carry_their_own_rows(pnn, oracle, precision):
     """with max_chunk below the batch size, every chunk of a host call through an FC net must be predicted
     from ITS rows -- the inline copy of small inputs (first kernel's argument block) used to stay on the first chunk's."""
