@@ -183,6 +183,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
     if (const char* e = getenv("PNN_FUSE_GATHER")) c->opt_fuse_gather = atol(e);
+    if (const char* e = getenv("PNN_FUSE_TAIL")) c->opt_fuse_tail = atol(e);
     if (const char* e = getenv("PNN_RING_PM")) c->opt_ring_pm = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
     if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
@@ -335,6 +336,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "fuse_gather")) c->opt_fuse_gather = value;
+    else if (!strcmp(name, "fuse_tail")) { c->opt_fuse_tail = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "ring_pm")) { c->opt_ring_pm = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
     else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;

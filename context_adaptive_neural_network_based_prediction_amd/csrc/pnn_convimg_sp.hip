@@ -367,6 +367,67 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 #else
     const bool tile_fits = (size_t)BM * OPP <= (size_t)2 * KC * E + ((size_t)G * NPIN + 1) * PITCH;
 #endif
+    if constexpr (WN == 1 && NT == 2) {
+    if (p.k1) {
+        // ---- the net's LAST layer on the tile in registers (launch_convimg_sp checked: Cout == 64 == BN, one class, stride-1 grid)
+        // The one-output-channel transposed convolution that ends every reference net (TConv1Params) reads exactly what this
+        // layer writes, 256 bytes per pixel there and back.  Here a wave holds all 64 channels of its 32 pixels in the
+        // accumulator layout -- lane (pixel l31, half h) owns channels 8q + 4h + i -- which IS the operand order of
+        // tconv_cout1_mfma_kernel's phase 1 (its K permutation was chosen for the global loads of the same 16-byte pieces), so
+        // T[pixel][tap] = sum_c x[pixel][c] w[tap][c] is the same v_mfma_f32_32x32x2_f32 chain on the same values, and phase 2
+        // (col2im, bias, HM epilogue) the same sums in the same order: bit-identical to the two launches.  T goes where the
+        // images were (dead after the tap loop).
+        constexpr int TP = 33;                        // kTcTP of pnn_small.hip
+        float* Tl = reinterpret_cast<float*>(lds);
+        const int KK = p.k1 * p.k1;
+        f32x4 wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            wv[q] = l31 < KK ? *reinterpret_cast<const f32x4*>(p.W1 + l31 * 64 + 8 * q + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            f32x16 t = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int nt = q >> 2, g = q & 3;
+                f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} * p.out_scale + bvs[nt][g];
+                if (act) {
+                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) t = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], wv[q][i], t, 0, 0, 0);
+            }
+            const int row0 = wm * (32 * RT) + rt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; r++) Tl[(row0 + 8 * (r >> 2) + 4 * h + (r & 3)) * TP + l31] = t[r];
+        }
+        __syncthreads();
+        const int K1 = p.k1, S1 = p.s1;
+        const int OH1 = p.OH * S1, OW1 = p.OW * S1;     // this layer's output map = the last layer's input map
+        for (int idx = tid; idx < nimg * OH1 * OW1; idx += 256) {
+            const int gi = idx / (OH1 * OW1), o = idx - gi * (OH1 * OW1);
+            const int oy = o / OW1, ox = o - oy * OW1;
+            float v = 0.f;
+            const int ky0 = (oy + p.pad1) % S1, kx0 = (ox + p.pad1) % S1;
+            for (int a = 0; a < (K1 + S1 - 1) / S1; a++) {
+                const int ky = ky0 + a * S1;
+                const int iy = (oy + p.pad1 - ky + S1 * K1) / S1 - K1;
+                if (ky >= K1 || iy < 0 || iy > p.OH - 1) continue;
+                for (int cc = 0; cc < (K1 + S1 - 1) / S1; cc++) {
+                    const int kx = kx0 + cc * S1;
+                    const int ix = (ox + p.pad1 - kx + S1 * K1) / S1 - K1;
+                    if (kx >= K1 || (unsigned)ix >= (unsigned)p.OW) continue;
+                    v += Tl[(gi * SP + iy * p.OW + ix) * TP + ky * K1 + kx];
+                }
+            }
+            v += p.bias1;
+            const size_t oo = ((size_t)(img0 + gi) * OH1 + oy) * OW1 + ox;
+            if (p.Y1) p.Y1[oo] = v;
+            if (p.Yi1) p.Yi1[oo] = hm_round(v, p.mean);
+        }
+        return;
+    }
+    }
     if (p.Yhi && !p.Y && !p.Yi && tile_fits) {
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
@@ -446,6 +507,18 @@ bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, 
     const size_t scratch_floats = 2 * (size_t)t.kc * 4 * bn * 4;               // the weight staging area
     const size_t ph = (size_t)(p.IH - 1) * s0 + k0, pw = (size_t)(p.IW - 1) * s0 + k0;
     return (k0 == 3 || k0 == 5) && (p.Cin == 32 || p.Cin == 64) && (size_t)G * ph * pw <= scratch_floats;
+}
+
+// Can this configuration apply the net's last layer (TConv1Params: Cin -> 1 transposed convolution) to its output tile?  Every
+// wave must hold all channels of its pixels (one column of waves, two 32-channel tiles: Cout == 64), the layer must be a
+// stride-1 single-class one whose rows are whole output maps, the last layer one that tconv_cout1_mfma_kernel takes (the same
+// arithmetic), and the T tile ([rows][33] floats) must fit the LDS the kernel has anyway.
+bool convimg_sp_can_fuse_last(const TapGemmParams& p, const TileCfg& t, int G, const TConv1Params& last)
+{
+    if (t.wm != 4 || t.nt != 2 || p.Cout != 64 || p.ncls != 1 || p.os != 1 || p.SH != p.OH || p.SW != p.OW) return false;
+    if (last.Cin != 64 || !((last.s == 2 && last.k == 5) || (last.s == 1 && last.k == 3)) || last.pad > last.k - 1) return false;
+    if (last.IH != p.OH || last.IW != p.OW) return false;
+    return (size_t)32 * t.rt * 4 * 33 * 4 <= convimg_sp_lds_bytes(p, t, G);
 }
 
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)

@@ -136,6 +136,7 @@ struct pnn_ctx {
     // during the call; plane == NULL: the contexts were gathered into the staging buffer as usual)
     struct LazyGather { const void* plane = nullptr; const void* tbs = nullptr; int pel_bytes = 0, unit = 0; } lazy;
     long opt_fuse_gather = 1;
+    long opt_fuse_tail = 1;                           // conv nets: the image kernel of the last 64-channel layer applies the net's last layer too (pnn_convimg_sp.hip)
     // Completion flag of the small host calls (signal_done, pnn_device_common.h): h_range[1] is the flag word, d_done the
     // workgroup counter; done_want = this pass is the last of a host call that will spin on the flag, done_armed = its last
     // kernel took the signal (kernels that cannot -- the exact-f32 FC output layer -- leave it unset: the call then waits for the stream)

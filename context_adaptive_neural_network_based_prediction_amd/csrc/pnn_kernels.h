@@ -39,7 +39,12 @@ struct TapGemmParams {
     const void* zero;  // >= 256 bytes of zeros (ring kernel: source of padding / out-of-range pieces)
     // ring kernel, fused next fully-connected layer (<= 64 outputs): its split-packed weights, their Npad, the number of
     // packed 16-deep chunks, and the partial-product buffer [column tiles][M][64] (see pnn_gemm_ring.hip)
-    const float* W2p; int Npad2; int K2chunks; float* part;
+    // (the image kernel never reads these; when it applies a net's LAST layer to its output tile -- k1 != 0 below, see
+    // pnn_convimg_sp.hip -- that layer's weights [k1][k1][Cout], and the net's outputs (float and / or HM epilogue) live in the same bytes)
+    union {
+        struct { const float* W2p; int Npad2; int K2chunks; float* part; };
+        struct { const float* W1; float* Y1; int32_t* Yi1; };
+    };
     // convimg kernel, fused FIRST convolution of a branch (Cin = 1 -> this layer's Cin channels, stride s0, kernel k0 x k0,
     // SAME padding with pad0 before, LeakyReLU): X0 != NULL makes the kernel compute its input maps from the raw f32
     // context X0 [images][IH * s0][IW * s0] instead of reading them from X (see pnn_convimg_sp.hip)
@@ -84,6 +89,8 @@ struct TapGemmParams {
     // rows are BM BLOCKS at ONE position of the SH x SW grid, so a tap that falls outside the image does so for the whole
     // tile and is skipped; pm_groups = number of block groups, nblk = number of blocks; the position order: pos_order above
     int pm_groups, nblk;
+    // image kernel, fused last layer (Cout == 64 -> 1 transposed convolution, kernel k1, stride s1, pad1 before, bias1): k1 != 0
+    float bias1; int k1, s1, pad1;
 };
 static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
@@ -108,6 +115,8 @@ int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
 bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0);   // the raw context tiles fit the weight staging area
+struct TConv1Params;
+bool convimg_sp_can_fuse_last(const TapGemmParams& p, const TileCfg& t, int G, const TConv1Params& last);   // the net's last layer on the output tile (k1 != 0)
 hipError_t launch_convimg_sp(const TapGemmParams& p, int idx, int G, hipStream_t s);   // G images per workgroup, resident in LDS
 hipError_t launch_split(const float* x, long n, void* hi, void* lo, int* range_flag, hipStream_t s);
 // Small-M split-precision tap GEMM (pnn_gemm_small.hip): one wave per 32 x 32 output tile, same per-output summation

@@ -68,8 +68,12 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
 // finishes with launch_fuse_reduce).  Y / Yhi / Yi must be null in that case.
 int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo, float* Y, void* Yhi, void* Ylo, int32_t* Yi,
                 long nblocks, hipStream_t s, const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr,
-                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0, bool* query_fuse_first = nullptr)
+                const Conv1Params* first = nullptr, bool x_is_f32 = false, int seg_chunks = 0, bool* query_fuse_first = nullptr,
+                const TConv1Params* lastp = nullptr)
 {
+    // `lastp` (optional): the net's last layer (the one-output-channel transposed convolution), which reads this layer's float
+    // output Y.  It has NOT been launched: an image-kernel configuration that can applies it to its output tile in registers
+    // (no Y round trip, one launch less), any other configuration gets it launched here behind the GEMM.
     // query_fuse_first (optional): launch NOTHING; report whether this call would run the image kernel with `first` fused in
     // -- and is sure of it: no tuning sweep ahead (a sweep launches the other kernel families too, which need the maps in memory)
     if (query_fuse_first) *query_fuse_first = false;
@@ -128,6 +132,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         c->stat_gemm_launches++; c->stat_launches++;
         c->stat_gemm_flops += flops;
         if (tiles_out) *tiles_out = seg_chunks > 0 ? (int)(((long)(L.k_total / 16.0) + seg_chunks - 1) / seg_chunks) : 0;
+        if (lastp) { HIPCHK(c, launch_tconv_cout1(*lastp, s)); c->stat_launches++; }
         return PNN_OK;
     }
     if (x_is_f32 && !query_fuse_first) {              // the big-tile kernels read split activations
@@ -151,7 +156,9 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         if (code < nsp + nci) return !diag && c->opt_convimg && convimg_images(p, convimg_sp_cfg(code - nsp), one_tap) > 0;
         return !diag && c->opt_ring && (one_tap || cpt % tapgemm_ring_cfg(code - nsp - nci).kc == 0);
     };
+    bool fused_last = false;                          // the last launch(code) had the image kernel apply `lastp`
     auto launch = [&](int code) {
+        fused_last = false;
         if (first) {
             if (code >= nsp && code < nsp + nci) {
                 const TileCfg t = convimg_sp_cfg(code - nsp);
@@ -172,12 +179,23 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
             const hipError_t e = launch_conv_cin1(*first, s);
             if (e != hipSuccess) return e;
         }
-        if (code < nsp) return launch_tapgemm_sp(p, code, s);
-        if (code < nsp + nci) {
+        hipError_t e;
+        if (code < nsp) e = launch_tapgemm_sp(p, code, s);
+        else if (code < nsp + nci) {
             const TileCfg t = convimg_sp_cfg(code - nsp);
-            return launch_convimg_sp(p, code - nsp, convimg_images(p, t, one_tap), s);
-        }
-        return launch_tapgemm_ring(p, code - nsp - nci, s);
+            const int g = convimg_images(p, t, one_tap);
+            // (a last layer that carries the completion signal of a host call is launched: the fused form has no such signal)
+            if (lastp && c->opt_fuse_tail && !lastp->done.host_flag && convimg_sp_can_fuse_last(p, t, g, *lastp)) {
+                TapGemmParams q = p;
+                q.Y = nullptr;
+                q.W1 = lastp->W; q.Y1 = lastp->Y; q.Yi1 = lastp->Yi; q.bias1 = lastp->bias; q.k1 = lastp->k; q.s1 = lastp->s; q.pad1 = lastp->pad;
+                fused_last = true;
+                return launch_convimg_sp(q, code - nsp, g, s);
+            }
+            e = launch_convimg_sp(p, code - nsp, g, s);
+        } else e = launch_tapgemm_ring(p, code - nsp - nci, s);
+        if (e != hipSuccess || !lastp) return e;
+        return launch_tconv_cout1(*lastp, s);
     };
     int cfg = choose_cfg_sp(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
     if (c->opt_sp_cfg >= nsp && legal((int)c->opt_sp_cfg)) cfg = (int)c->opt_sp_cfg;
@@ -194,14 +212,14 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     // (~70 x 4 launches) costs a few tens of milliseconds and the choice is worth 10-20 %; 0 = rule-based choice only.
     // All configurations give bit-identical results, so the choice never shows in the predictions.
     bool tune = c->opt_autotune == 1 || (c->opt_autotune == 2 && 2.0 * (double)M * L.k_total * p.Cout >= 4.0e9);
-    if (tune && c->tuned.find(std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0)), M)) == c->tuned.end()) {
+    if (tune && c->tuned.find(std::make_pair((const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0) + (lastp ? 4 : 0)), M)) == c->tuned.end()) {
         // timing configurations means synchronising on the caller's stream: never while that stream is being captured
         // into a hipGraph (the rule-based choice is used instead, nothing is remembered)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
     }
     if (query_fuse_first) {
-        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0));
+        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0) + (lastp ? 4 : 0));
         int code = cfg;
         if (tune && c->opt_sp_cfg < 0) {
             auto it = c->tuned.find(std::make_pair(key, M));
@@ -215,7 +233,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         return PNN_OK;
     }
     if (tune && c->opt_sp_cfg < 0) {
-        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0));
+        const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0) + (lastp ? 4 : 0));
         const int rule = cfg;
         float best_us = -1.f;
         const int trc = tuned_cfg(c, key, M, nsp + nci + nrg, rule, legal, launch, s, &cfg, &best_us);
@@ -276,6 +294,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
                 M, L.k_total, p.Cout, tt.rt, tt.nt, tt.kc, tt.wm, nwg, sum[0] / nwg / stages, sum[1] / nwg / stages, sum[2] / nwg / stages, sum[3] / nwg / stages);
     }
     c->stat_gemm_launches++; c->stat_launches++;
+    if (lastp && !fused_last) c->stat_launches++;    // the net's last layer went out as a launch of its own
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
     if (next) {
         c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
@@ -550,18 +569,26 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;
     int cur = 0;
+    TConv1Params tp = m->last.proto;
+    tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
+    tp.done = take_done_signal(c);
+    bool last_done = false;                          // the last layer went out with (or inside) the GEMM in front of it
     for (size_t i = 0; i < nt; i++) {
         const bool last = i + 1 == nt;
-        if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, last ? P[cur ^ 1] : nullptr, last ? nullptr : P[cur ^ 1], nullptr, nullptr, nb, s);
+        if (sp && last) {                            // run_gemm_sp launches the net's last layer too, or has the image kernel apply it
+            tp.X = P[cur ^ 1];
+            rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, P[cur ^ 1], nullptr, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, false, 0, nullptr, &tp);
+            last_done = true;
+        } else if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, nullptr, P[cur ^ 1], nullptr, nullptr, nb, s);
         else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s);
         if (rc) return rc;
         cur ^= 1;
     }
-    TConv1Params tp = m->last.proto;
-    tp.X = P[cur]; tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
-    tp.done = take_done_signal(c);
-    HIPCHK(c, launch_tconv_cout1(tp, s));
-    c->stat_launches++;
+    if (!last_done) {
+        tp.X = P[cur];
+        HIPCHK(c, launch_tconv_cout1(tp, s));
+        c->stat_launches++;
+    }
     // a pass of this shape went through on one stream without a tuning sweep: the next one may overlap its branches
     if (batch_overlap && !par && !pair && c->tune_gen == gen_before) c->overlap_ready[shape] = c->tune_gen;
     return PNN_OK;

@@ -93,6 +93,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * ONE position of the feature map, so a tap that only meets the SAME padding there is skipped for the whole tile -- where
  * the launch model of pnn_gemm_ring.hip expects them to finish no later; 2: wherever possible; 0: never.  The skipped products
  * are exact zeros: bit-identical in every mode),
+ * "fuse_tail" (1, default: when the last 64-channel layer of a convolutional net runs on the LDS-resident-image kernel, that
+ * kernel applies the net's last layer -- the one-output-channel transposed convolution -- to its output tile in registers: no
+ * round trip of the 64-channel maps, one launch less; 0: separate launch.  Bit-identical either way),
  * "split_min_px" (-1, default: built-in rule; >= 0: with precision 1, passes through a convolutional net use the
  * split-precision kernels from this many block pixels (blocks x w^2) on and the exact-f32 kernels below -- tuning aid),
  * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
@@ -117,7 +120,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */

@@ -855,6 +855,37 @@ def test_completion_flag_of_small_host_calls(pnn, precision, w, is_fc, n):
     net.close()
 
 
+@pytest.mark.parametrize("w,n", [(16, 1024), (16, 333), (8, 2048), (32, 128)])
+def test_last_layer_fused_into_the_image_kernel(pnn, oracle, precision, w, n):
+    """Option "fuse_tail": the image kernel of the last 64-channel layer applies the net's last layer (64 -> 1 transposed
+    convolution) to its tile in registers.  Same MFMA chain on the same values, same col2im order: float predictions and HM
+    blocks equal the two-launch path bit for bit, one launch less where it applies."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    if precision != "split_f16":
+        pytest.skip("split-precision kernels only")
+    L = _lib.lib()
+    params = util.make_params(w, False, 95, out_gain=util.out_gain(w, False))
+    above, left = util.make_contexts(w, n, 96)
+    net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
+    net.set_option("autotune", 0)
+    net.set_option("branch_streams", 0)
+    d_a, d_l = torch.from_numpy(above).cuda(), torch.from_numpy(left).cuda()
+    res = {}
+    for fuse in (0, 1):
+        net.set_option("fuse_tail", fuse)
+        d_out = torch.zeros((n, w, w), dtype=torch.float32, device="cuda")
+        assert L.pnn_predict_conv_device(net.ctx, w, d_a.data_ptr(), d_l.data_ptr(), n, d_out.data_ptr(), None) == 0, L.pnn_last_error(net.ctx)
+        torch.cuda.synchronize()
+        res[fuse] = (d_out.cpu().numpy(), net.predict_pel(above, left), net.last_call_stats()["launches"])
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    if w == 16 and n == 1024:
+        assert res[1][2] == res[0][2] - 1, "the last layer's launch is gone"
+    m = min(n, 32)
+    np.testing.assert_allclose(res[1][0][:m], oracle.conv_forward(params, w, above[:m], left[:m]), rtol=0, atol=FLOAT_ATOL)
+    net.close()
+
+
 def test_chunked_host_calls_carry_their_own_rows(pnn, oracle, precision):
     """with max_chunk below the batch size, every chunk of a host call through an FC net must be predicted
     from ITS rows -- the inline copy of small inputs (first kernel's argument block) used to stay on the first chunk's."""
