@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     constexpr int NLD = (E + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     f32x4* Bs = lds;                                  // [2][KC][E]
-    f32x4* Ai = lds + 2 * KC * E;                     // [(G*NPIN + 1)][PITCH]
+    f32x4* Ai = lds + 2 * KC * E;                     // [G*NPIN][PITCH] | zero region [ZP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -53,6 +53,12 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     const int SP = p.SH * p.SW;
     const int NPIN = p.IH * p.IW;
     const int PITCH = (p.Cin >> 2) + 1;
+    // the zero region behind the images: Cin/4 + 16 slots.  A lane whose tap leaves the image reads zeros from the slot of this
+    // region that falls on the banks its in-image slot would have had (slot index mod 16: a 64-lane read covers 16 lanes x
+    // 16 bytes = all 64 banks per cycle, and consecutive pixels at pitch Cin/4 + 1 are consecutive mod 16) -- with ONE zero pixel
+    // for everyone it collided with whichever neighbour shares that class: 23 % of the LDS cycles of the 16x16 net's image
+    // launches were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r03_conv16_pmc_summary.txt)
+    const int ZP = (p.Cin >> 2) + 16;
     const int nimg = (int)((long)p.M / SP - img0 < G ? (long)p.M / SP - img0 : G);   // images that exist
 
     // ---- stage the images and the zero pixel -------------------------------------------------------------------------
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         };
         if (K0 == 5) conv0(std::integral_constant<int, 5>{}); else conv0(std::integral_constant<int, 3>{});
         report_range(p.range_flag, amax0);
-        for (int idx = tid; idx < PITCH; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < ZP; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                              // the scratch becomes the weight staging area again
     } else {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.X) + (size_t)img0 * NPIN * (p.Cin >> 2);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                 if (idx < total) Ai[pix * PITCH + c4] = v[u];
             }
         }
-        for (int idx = tid; idx < PITCH; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < ZP; idx += 256) Ai[G * NPIN * PITCH + idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- this lane's output pixels ---------------------------------------------------------------------------------
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         for (int rt = 0; rt < RT; rt++) {
             const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
             const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-            abase[rt] = (ok ? (pg[rt] * NPIN + iy * p.IW + ix) : G * NPIN) * PITCH;
+            const int nat = (pg[rt] * NPIN + iy * p.IW + ix) * PITCH;          // where the pixel is -- or would be
+            abase[rt] = ok ? nat : G * NPIN * PITCH + ((nat - G * NPIN * PITCH) & 15);
         }
     };
     unsigned bsrc[NLD];                              // byte offsets into the packed weights (buffer loads: a 32-bit offset per lane
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 #ifdef PNN_CI_DIRECT_EPILOGUE   // A/B build: the stores from the accumulator layout
     const bool tile_fits = false;
 #else
-    const bool tile_fits = (size_t)BM * OPP <= (size_t)2 * KC * E + ((size_t)G * NPIN + 1) * PITCH;
+    const bool tile_fits = (size_t)BM * OPP <= (size_t)2 * KC * E + (size_t)G * NPIN * PITCH + ZP;
 #endif
     if constexpr (WN == 1 && NT == 2) {
     if (p.k1) {
@@ -524,7 +531,7 @@ bool convimg_sp_can_fuse_last(const TapGemmParams& p, const TileCfg& t, int G, c
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)
 {
     const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
-    const size_t slots = 2 * (size_t)t.kc * 4 * bn + ((size_t)G * p.IH * p.IW + 1) * ((size_t)(p.Cin >> 2) + 1);
+    const size_t slots = 2 * (size_t)t.kc * 4 * bn + (size_t)G * p.IH * p.IW * ((size_t)(p.Cin >> 2) + 1) + (size_t)(p.Cin >> 2) + 16;   // weights | images | zero region
     return slots * 16;
 }
 
