@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of the timed steps in a rocprofv3 --kernel-trace CSV directory: per step (from the launch behind a pass's last
 kernel -- the reduction of an FC net, the last transposed convolution of a conv net -- to the next such launch; a conv pass
-whose gather is fused into the image kernel has no gather launch to go by), the kernels in launch order with their
+whose gather is fused into the image kernel has no gather launch to go by, and one whose last layer is fused in has no
+last-layer launch: see below), the kernels in launch order with their
 duration and the idle gap in front of each."""
 import csv, glob, sys
 d = sys.argv[1]
@@ -12,6 +13,20 @@ for f in glob.glob(d + "/*/*_kernel_trace.csv"):
 rows.sort()
 LAST = ("fuse_reduce", "tconv_cout1")
 starts = [i for i, r in enumerate(rows) if i > 0 and rows[i - 1][2].startswith(LAST) and not r[2].startswith(LAST)]
+if len(starts) < 3:
+    # a conv pass whose last layer runs inside the image kernel in front of it (fuse_tail) has no last-layer launch either:
+    # behind the merger come the transposed-convolution stack, which ends in an image-kernel launch, and then the next pass,
+    # which begins with one -- a step starts at the SECOND image-kernel launch after a merger
+    starts = []
+    seen = -1
+    for i, r in enumerate(rows):
+        if r[2].startswith("merger"):
+            seen = 0
+        elif seen >= 0 and r[2].startswith("convimg_sp_kernel"):
+            seen += 1
+            if seen == 2:
+                starts.append(i)
+                seen = -1
 # the timed steps are the longest run of equally long gather-to-gather segments: take the 6 segments before the last 2
 segs = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 # the timed steps are the bulk of the equally long segments (0.4 s of ramp-up steps + the timed regions); the per-launch-timed
