@@ -862,7 +862,10 @@ const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC
     for (int t = 0; t < p.tap_begin[p.ncls]; t++) taps_hash = taps_hash * 31 + p.tap[t];
     const Key key = {p.M, p.SH, p.SW, p.IH, p.IW, p.Cin, p.Cout, p.a, p.ncls, taps_hash, BM, BN, KC * 4 + (p.pm_groups + 1), (int)(lds >> 10)};
     auto it = plans.find(key);
-    if (it == plans.end()) it = plans.emplace(key, plan_position_major(p, BM, BN, KC, lds)).first;
+    if (it == plans.end()) {
+        if (plans.size() >= 4096) plans.clear();     // a caller that never repeats a batch size: start over rather than grow
+        it = plans.emplace(key, plan_position_major(p, BM, BN, KC, lds)).first;
+    }
     return it->second;
 }
 }  // namespace
