@@ -667,13 +667,13 @@ def test_fused_first_convolution_bit_identical(pnn, precision, w, n):
 
 
 def test_contexts_sharing_the_gpu_stay_repeatable(pnn):
-    """Three contexts in three host threads on one GPU (two big FC passes = matrix-core kernels, one conv net = VALU-heavy
-    first layers): every call must reproduce the context's first result bit for bit.  Before the library was built
+    """Four contexts in four host threads on one GPU (two big FC passes = matrix-core kernels, a conv net in small passes =
+    VALU-heavy first layers, a conv net at batch = two streams of its own): every call must reproduce the context's first result bit for bit.  Before the library was built
     without packed-fp32 instructions the conv net showed rare one-pixel errors here (gfx950: an in-place v_pk_fma_f32 can
     read an already-overwritten half while another wave on its SIMD issues MFMAs -- tools/pkfma_probe.hip)."""
     import threading
     out, errs = {}, []
-    bar = threading.Barrier(3)
+    bar = threading.Barrier(4)
 
     def worker(name, w, fc, n, seed, reps):
         try:
@@ -690,13 +690,16 @@ def test_contexts_sharing_the_gpu_stay_repeatable(pnn):
 
     ts = [threading.Thread(target=worker, args=("fc8-a", 8, True, 2048, 5, 150)),
           threading.Thread(target=worker, args=("fc8-b", 8, True, 1536, 7, 150)),
-          threading.Thread(target=worker, args=("conv16", 16, False, 64, 9, 150))]
+          threading.Thread(target=worker, args=("conv16", 16, False, 64, 9, 150)),
+          # round 3: a conv net at batch -- position-major ring tiles, the two branches side by side on two streams (from its
+          # third pass on), the last layer inside the image kernel -- beside the others
+          threading.Thread(target=worker, args=("conv16-batch", 16, False, 384, 11, 120))]
     for t in ts:
         t.start()
     for t in ts:
         t.join()
     assert not errs, errs
-    assert out == {"fc8-a": 0, "fc8-b": 0, "conv16": 0}, out
+    assert out == {"fc8-a": 0, "fc8-b": 0, "conv16": 0, "conv16-batch": 0}, out
 
 
 @pytest.mark.parametrize("w,n", [(16, 384), (32, 96)])
