@@ -732,7 +732,8 @@ __global__ __launch_bounds__(512) void tapgemm_ring_kernel(const TapGemmParams p
     X(1, 4, 2, 4, 4) X(1, 4, 2, 4, 3) X(2, 2, 2, 2, 4) X(2, 2, 2, 2, 3) X(2, 4, 2, 4, 3) X(4, 2, 2, 2, 3) X(2, 3, 2, 2, 3) X(1, 3, 2, 4, 3) \
     X(1, 2, 2, 4, 4) X(1, 2, 2, 4, 3) X(2, 1, 2, 2, 4) X(2, 1, 2, 2, 3) X(1, 2, 2, 2, 4) X(2, 2, 2, 4, 3) X(1, 5, 2, 4, 4) X(1, 5, 2, 4, 3) \
     X(2, 3, 2, 4, 3) X(3, 2, 2, 2, 3) X(1, 3, 2, 4, 4) X(2, 3, 2, 2, 4) \
-    X(1, 5, 1, 4, 8) X(1, 2, 1, 4, 8)
+    X(1, 5, 1, 4, 8) X(1, 2, 1, 4, 8) \
+    X(3, 2, 2, 2, 4)
 
 static const TileCfg kCfgsRing[] = {
 #define X(rt, nt, kc, wm, d) {rt, nt, kc, 316, wm, d},

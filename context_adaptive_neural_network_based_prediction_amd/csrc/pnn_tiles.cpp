@@ -136,7 +136,7 @@ int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total
         if (!wide && !underfilled && !few_images) return -1;
         int rt = 1, wm = 2, d = 4;                    // 64 x 128
         if (wide) {
-            if ((double)((M + 191) / 192) * col_tiles >= 192.0) { rt = 3; d = 3; }        // 192 x 128
+            if ((double)((M + 191) / 192) * col_tiles >= 192.0) { rt = 3; d = 4; }        // 192 x 128, four stages = all 160 KB of LDS (round 3: 0.2 % / 0.8 % on the 16x16 / 32x32 passes over the 3-deep ring -- its ~1880-cycle stage for 1152 cycles of MFMA work is LDS bandwidth, 80 KB of fragment reads + 40 KB of DMA writes per stage, not the missing stage of slack)
             else if ((double)((M + 127) / 128) * col_tiles >= 192.0) rt = 2;              // 128 x 128
         }
         for (int i = 0; i < tapgemm_ring_num_cfgs(); i++) {
