@@ -44,7 +44,7 @@ for a, b in pick:
     for r in rows[a:b]:
         tot_union += max(0, r[1] - max(end, r[0]))
         end = max(end, r[1])
-a, b = pick[-1]
+a, b = pick[len(pick) // 2]                      # the step that is printed: one from the middle
 t0 = rows[a][0]
 prev_end = rows[a - 1][1]
 overlap = tot_busy > 1.02 * tot_union           # a few ns of timestamp overlap between back-to-back kernels are not concurrency
