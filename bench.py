@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the PNN intra-prediction hot path on MI355X (contract: see DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fc8|conv16|...] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fc8|conv16|...] [--batch B] [--arithmetic f32|split]
 
 One "step" = one pass of the hot path (L-context gather -> PNN -> +mean/clamp/round -> int32 Pel) over one
 batch of synthetic transform blocks per GPU, inputs (reconstructed planes + TB descriptors) resident in
 HBM.  Default workload = BASELINE.json configs[1]: 8x8 fully-connected PNN, batch 4096, 1 x MI355X.
 For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own batch
 (independent blocks: no data-path collective, weak scaling) and the time is the max over ranks.
-Prints ONE JSON line on rank 0.  Top level = the workload on the library's default arithmetic (f32 emulated with split
-f16 operands, see DTYPE); at N = 1 the line also carries `reference_arithmetic` (the same workload on exact-f32 MFMA, the
-reference's own arithmetic -- the figure to quote against a float32 TF graph), `conv16` (BASELINE.json configs[2], both
-arithmetics) and `sustained` (>= 2 s of back-to-back steps per workload and arithmetic: the power-limited steady state),
-each with its own parity check and roofline; compact copies of the first and the last sit inside `roofline`.
+
+Rank 0 prints ONE JSON line of < 4 KB (build_line; tests/test_host.py checks the size on canned results).  Its top level
+-- value, dtype, roofline, cpu_baseline -- is the workload on the REFERENCE's arithmetic, IEEE float32 (`precision` = 0,
+pnn/components.py:169-176); `fast_arithmetic` is the same workload on the library's split-f16 mode, and `per_width` the
+table BASELINE.json's metric asks for ("blocks/s (per width)": FC 4, FC 8, conv 16 / 32 / 64, both arithmetics, each checked
+against the oracle).  Everything else -- every region's time, the CPU legs, the other kernels of the pass -- goes to
+`bench_detail.json` (--detail-file).  The HM campaigns (configs[3] / [4]) run only under `--workload hm_kodak | hm_bsds`.
 `--gpus N` without a launcher (WORLD_SIZE unset) starts its own ranks: `python -m torch.distributed.run` as a CHILD process.
 """
 import argparse
@@ -29,28 +31,33 @@ sys.path.insert(0, ROOT)
 
 RAMP_SECONDS = 0.4          # untimed device ramp-up before the warm-up steps (see measure)
 REPEATS = 5                 # timed regions of K steps each; value = the median region
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
-SUSTAIN_SECONDS = 2.0       # one region of back-to-back steps per (workload, arithmetic): the steady state the SMI sampler can see
-DTYPE = {1: "f32 emulated: 2 x f16 per operand (hi + lo, 22-bit significand), 3 of the 4 partial products on f16 MFMA "
-            "(lo*lo dropped), f32 accumulate",
-         0: "f32 (IEEE float32 operands on f32 MFMA, f32 accumulate: the reference's arithmetic)"}
+SUSTAIN_SECONDS = 2.0       # --sustained: one region of back-to-back steps per (workload, arithmetic), clocks sampled meanwhile
+LINE_LIMIT = 4096           # the driver keeps the tail of stdout: the line must fit with room to spare
+DTYPE = {0: "f32",
+         1: "f32-class split: 2 x f16 per operand (22-bit significand), 3 f16-MFMA products, f32 accumulate"}
+DTYPE_LONG = {1: "f32 emulated: 2 x f16 per operand (hi + lo, 22-bit significand), 3 of the 4 partial products on f16 MFMA "
+                 "(lo*lo dropped), f32 accumulate",
+              0: "f32 (IEEE float32 operands on f32 MFMA, f32 accumulate: the reference's arithmetic)"}
+ARITH = {"f32": 0, "split": 1}
 
 WORKLOADS = {                      # name -> (width, is_fc, default batch per GPU, BASELINE.json config)
-    "fc4": (4, True, 4096, "4x4 fully-connected PNN"),
+    "fc4": (4, True, 4096, "4x4 fully-connected PNN, batch 4096"),
     "fc8": (8, True, 4096, "configs[1]: 8x8 fully-connected PNN, batch 4096"),
     "conv16": (16, False, 1024, "configs[2]: 16x16 convolutional PNN, batch 1024"),
-    "conv32": (32, False, 256, "32x32 convolutional PNN"),
-    "conv64": (64, False, 64, "64x64 convolutional PNN"),
-    "conv8": (8, False, 4096, "8x8 convolutional PNN"),
-    "conv4": (4, False, 4096, "4x4 convolutional PNN"),
+    "conv32": (32, False, 256, "32x32 convolutional PNN, batch 256"),
+    "conv64": (64, False, 64, "64x64 convolutional PNN, batch 64"),
+    "conv8": (8, False, 4096, "8x8 convolutional PNN, batch 4096"),
+    "conv4": (4, False, 4096, "4x4 convolutional PNN, batch 4096"),
 }
-KERNELS = ((0, "tapgemm_kernel (exact f32 MFMA 16x16x4, LDS-staged weights)"),
+PER_WIDTH = ("fc4", "fc8", "conv16", "conv32", "conv64")   # the nets HM uses per width (pnn/PredictionNeuralNetwork.py:119-137, TComPrediction.cpp:130-171)
+KERNELS = ((0, "tapgemm_kernel (exact f32 MFMA, LDS-staged weights)"),
            (1, "tapgemm_splitk_kernel (f32 MFMA, small M)"),
-           (2, "tapgemm_sp_kernel (f32-class split products on 3 x f16 MFMA 32x32x16, register-staged operands)"),
-           (3, "convimg_sp_kernel (same split-product MFMAs, feature maps resident in LDS)"),
-           (4, "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)"),
-           (5, "tapgemm_small_kernel (same split-product MFMAs; one 32 x 32 tile per workgroup, 1 MFMA + 3 loader waves: small M)"))
+           (2, "tapgemm_sp_kernel (split products on 3 x f16 MFMA 32x32x16, register-staged operands)"),
+           (3, "convimg_sp_kernel (split-product MFMAs, feature maps resident in LDS)"),
+           (4, "tapgemm_ring_kernel (split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)"),
+           (5, "tapgemm_small_kernel (split-product MFMAs; one 32 x 32 tile per workgroup: small M)"))
 
 
 def flops_per_block(width, is_fc):
@@ -133,7 +140,7 @@ def stagger(dist, fn):
         dist.barrier()
 
 
-def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sustain_s=0.0):
+def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sustain_s=0.0, ramp_s=RAMP_SECONDS):
     """Times the hot path of workload `wl` on arithmetic `precision` (1: split products on f16 MFMA, 0: exact-f32 MFMA)
     and derives the dominant kernel's roofline from HIP events attached to every tap-GEMM launch."""
     import torch
@@ -157,7 +164,7 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sus
         torch.cuda.synchronize()
     stagger(dist, first)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < RAMP_SECONDS:
+    while time.perf_counter() - t_ramp < ramp_s:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
@@ -171,7 +178,7 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sus
     world = dist.get_world_size() if dist is not None else 1
     res = {
         "value": float(n) * world * steps / elapsed, "unit": "blocks/s", "ms_per_step": 1e3 * elapsed / steps,
-        "dtype": DTYPE[precision], "steps": steps,
+        "dtype": DTYPE_LONG[precision], "precision": precision, "steps": steps, "workload": wl.name, "batch_per_gpu": n,
         "repeats": {"n": repeats, "regions_of_steps": steps, "value_is": "median region",
                     "blocks_per_s_min": float(n) * world * steps / max(regions), "blocks_per_s_max": float(n) * world * steps / min(regions),
                     "ms_per_step_all": [round(1e3 * r / steps, 5) for r in regions]},
@@ -266,7 +273,7 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
     from tests import util
     w, fc, default_batch, _ = WORKLOADS[workload]
     params = util.make_params(w, fc, seed=1, out_gain=30.0)
-    nb = min(default_batch, 4096 if fc else (512 if w <= 16 else 64))
+    nb = default_batch                                  # the GPU batch
     above, left = util.make_contexts(w, nb, seed=7)
     ctx = util.flatten_fc(above, left) if fc else None
     if kind == "oracle":
@@ -291,38 +298,108 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
                       "blocks_per_s_spread": [per_call / float(np.max(ts)), per_call / float(np.min(ts))]}))   # slowest / fastest run of this leg
 
 
-def cpu_legs(wl, budget_s=2.0):
+def cpu_legs(workload, budget_s=1.0, full=False):
     """the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
-    an independent PyTorch-CPU formulation (oneDNN / MKL), each batched and at batch 1 sequential (what HM does per TB).
-    Bounded samples: every leg runs for about `budget_s` in its own process, at the best of a few thread counts
-    ({all, 64, 32, 16} cores batched, {8, 1} at batch 1: a single block rarely profits from many cores)."""
+    an independent PyTorch-CPU formulation (oneDNN / MKL), each batched (the GPU batch where the oracle finishes it in seconds)
+    and at batch 1 sequential (what HM does per TB).  Bounded samples: every leg runs for about `budget_s` in its own process.
+    Thread counts: 64 (or all, below 64 cores) batched and 8 at batch 1 -- the best of the full candidate lists
+    ({all, 64, 32, 16} / {8, 1}, `--cpu-legs-full`) on the 256-core GPU boxes of rounds 1-3."""
     import subprocess
     ncores = os.cpu_count()
 
     def run(kind, batch1, threads):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", kind, "--workload", wl.name, "--leg-batch1", str(int(batch1)),
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", kind, "--workload", workload, "--leg-batch1", str(int(batch1)),
                             "--leg-threads", str(threads), "--leg-budget", str(budget_s)], env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": r.stderr[-400:]}
         return json.loads(r.stdout.strip().splitlines()[-1])
 
+    batched_threads = sorted({ncores, min(ncores, 64), min(ncores, 32), min(ncores, 16)}, reverse=True) if full else [min(ncores, 64)]
+    batch1_threads = sorted({min(ncores, 8), 1}, reverse=True) if full else [min(ncores, 8)]
     legs = {}
     for kind, tag in (("oracle", "oracle"), ("torch", "torch_cpu")):
-        # the best thread count per leg: on the 256-core GPU box every core is NOT the fastest choice for these sizes
-        # (measured: PyTorch-CPU FC 8x8 x 4096 on 256 threads 1.9 k blocks/s, slower than its own batch-1 leg)
-        cands = [run(kind, False, t) for t in sorted({ncores, min(ncores, 64), min(ncores, 32), min(ncores, 16)}, reverse=True)]
+        cands = [run(kind, False, t) for t in batched_threads]
         legs[tag + "_batched"] = max(cands, key=lambda r: r.get("blocks_per_s", 0.0))
         legs[tag + "_batched"]["threads_tried"] = [c.get("threads") for c in cands]
-        cands = [run(kind, True, t) for t in sorted({min(ncores, 8), 1}, reverse=True)]
+        cands = [run(kind, True, t) for t in batch1_threads]
         legs[tag + "_batch1"] = max(cands, key=lambda r: r.get("blocks_per_s", 0.0))
     best = max(("oracle_batched", "torch_cpu_batched"), key=lambda k: legs[k].get("blocks_per_s", 0.0))
-    return {"value": legs[best].get("blocks_per_s"), "unit": "blocks/s", "cores": legs[best].get("threads", ncores), "host_cores": ncores, "kind": "port", "value_leg": best,
-            "sample": "batched legs: batches of %s blocks; batch-1 legs: 16 single-block calls in sequence (what HM issues per TB); median of the "
-                      "runs that fit ~%.0f s per leg, each leg in its own process; `value` = the FASTER of the two batched legs (oracle/pnn_oracle.c "
-                      "with OpenMP -O3 -mavx2 -mfma; PyTorch-CPU functional formulation on oneDNN / MKL).  Stand-ins for the reference's TF-1.9 "
-                      "CPU path, which cannot be installed here" % (legs["oracle_batched"].get("blocks_per_run"), budget_s),
+    best1 = max(("oracle_batch1", "torch_cpu_batch1"), key=lambda k: legs[k].get("blocks_per_s", 0.0))
+    return {"value": legs[best].get("blocks_per_s"), "unit": "blocks/s", "cores": legs[best].get("threads", ncores), "host_cores": ncores, "kind": "port",
+            "value_leg": best, "batch1_value": legs[best1].get("blocks_per_s"), "batch1_leg": best1, "batch1_cores": legs[best1].get("threads"),
+            "sample": "batches of %s blocks (batch-1: 16 single-block calls in sequence, what HM issues per TB); median of the runs that fit ~%.1f s "
+                      "per leg, each leg its own process; value = the faster of oracle/pnn_oracle.c (OpenMP, -O3 -mavx2 -mfma) and a PyTorch-CPU "
+                      "(oneDNN) formulation -- stand-ins for the TF-1.9 CPU path, which cannot be installed" % (legs["oracle_batched"].get("blocks_per_run"), budget_s),
             "legs": legs}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline.traffic measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+# pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over a few steps of the same workload and arithmetic, rule-based tiles.
+# Counter-only passes (no tracing); the children are started as child processes, never exec'ed.
+# ---------------------------------------------------------------------------------------------------------------------
+GEMM_NAMES = {0: ("tapgemm_kernel", "tapgemm32_kernel", "tapgemm_splitk_kernel", "tapgemm_f32"),
+              1: ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")}
+
+
+def pmc_child(workload, batch, precision, steps):
+    """`bench.py --pmc-child`: a few steps of the hot path and nothing else (the profiler's child)."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork
+    wl = Workload(workload, batch, 0, 0)
+    net = PredictionNeuralNetwork(wl.batch, wl.width, wl.is_fc, params=wl.params, device=0)
+    net.set_option("precision", precision)
+    net.set_option("autotune", 0)                     # no tuning launches among the counted dispatches
+    for _ in range(steps):
+        rc = wl.L.pnn_predict_tbs_device(net.ctx, wl.width, wl.d_plane.data_ptr(), 4, wl.d_tbs.data_ptr(), wl.batch, wl.d_dst.data_ptr(), None, None)
+        if rc:
+            raise RuntimeError(wl.L.pnn_last_error(net.ctx))
+    torch.cuda.synchronize()
+    net.close()
+
+
+def parse_pmc_dir(path, counter, names):
+    """Mean per dispatch of `counter` over the dispatches of the kernels in `names`, and the dispatch count."""
+    import csv
+    import glob
+    per = {}
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("void ", "").replace("pnn::", "")
+            if r["Counter_Name"] == counter and k.startswith(names):
+                per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return (sum(per.values()) / len(per), len(per)) if per else (None, 0)
+
+
+def live_traffic(workload, batch, precision, steps=3, timeout=90):
+    """HBM bytes per GEMM launch from this run's own counter passes: 2 x FETCH_SIZE (gfx950 tallies 128-byte reads as 64) +
+    WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section).  None when rocprofv3 is absent or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals, work = {}, tempfile.mkdtemp(prefix="pnn_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                                "--workload", workload, "--batch", str(batch), "--arithmetic", "f32" if precision == 0 else "split", "--steps", str(steps)],
+                               env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=timeout)
+            v, nd = parse_pmc_dir(d, ctr, GEMM_NAMES[precision])
+            if r.returncode != 0 or v is None:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d GEMM dispatches; %s" % (ctr, r.returncode, nd, r.stderr[-300:])}
+            vals[ctr] = (v, nd)
+    except Exception as e:                            # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0, "fetch_kib_raw_mean": vals["FETCH_SIZE"][0],
+            "write_kib_mean": vals["WRITE_SIZE"][0], "launches": vals["FETCH_SIZE"][1],
+            "source": "this run: child rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate, counters only) over %d steps, rule-based tiles; "
+                      "mean over the pass's GEMM dispatches of 2 x FETCH_SIZE + WRITE_SIZE" % steps}
 
 
 def self_launch(args):
@@ -357,7 +434,7 @@ def self_launch(args):
     raise SystemExit(r.returncode if r.returncode or line else 1)
 
 
-def hm_campaigns(which, devices, quick=False):
+def hm_campaigns(which, devices, quick=False, pictures="synthetic"):
     """BASELINE.json configs[3] / configs[4] at their stated picture counts through the reference's own HM binaries
     (tools/hm/campaign.py; built by __graft_entry__.build() where /root/reference exists, they travel with the tree).
     Returns {name: record}; a missing binary or a failed run is recorded, never raised -- the kernel line must survive."""
@@ -374,12 +451,83 @@ def hm_campaigns(which, devices, quick=False):
     for name in which:
         work = tempfile.mkdtemp(prefix="pnn_bench_hm_")
         try:
-            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300)   # per codec process: a wedged service must not hold the line for long
+            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300, picture_set=pictures)   # per codec process: a wedged service must not hold the line for long
         except Exception as e:                        # noqa: BLE001
             out[name] = {"error": repr(e)[:2000]}
         finally:
             shutil.rmtree(work, ignore_errors=True)
     return out
+
+
+def _r(x, nd=4):
+    """Rounded to `nd` significant digits (the line is read by people and by a 4 KB tail buffer)."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float("%.*g" % (nd, x))
+
+
+def compact(res):
+    """One measurement as the line carries it."""
+    rf = res["roofline"]
+    return {"value": _r(res["value"], 5), "ms_per_step": _r(res["ms_per_step"], 5), "frac": _r(rf["frac"], 3),
+            "pass_frac": _r(rf["whole_pass"]["frac_of_peak"], 3), "launches": res["launches_per_step"], "lsb": res.get("max_abs_lsb_vs_oracle")}
+
+
+def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=None, cpu=None, cpu_conv16=None, detail_file=None, extra_config=None,
+               rccl_ranks_seen=None):
+    """The ONE JSON line of rank 0 (< LINE_LIMIT bytes).  `main_res` / `fast` / `per_width[name][arith]` are measure() results."""
+    rf = main_res["roofline"]
+    out = {
+        "metric": "pnn_intra_pred_blocks_per_s", "value": _r(main_res["value"], 6), "unit": "blocks/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": _r(main_res["ms_per_step"], 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE[main_res["precision"]], "data": "synthetic",
+        "config": {"workload": cfg_name, "batch_per_gpu": main_res["batch_per_gpu"], "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
+                   "weights": "seeded random init (reference initialisers' statistics)", "parallelism": "independent blocks sharded over ranks, no collective",
+                   "timing": "%d regions of K steps, median" % main_res["repeats"]["n"]},
+        "max_abs_lsb_vs_oracle": main_res.get("max_abs_lsb_vs_oracle"),
+        "pred_psnr_delta_db": _r((main_res.get("pred_psnr") or {}).get("delta_db"), 3),
+        "roofline": {"bound": "mfma", "kernel": rf["kernel"].split(" (")[0], "achieved": _r(rf["achieved"]), "peak": _r(rf["peak"]), "unit": "TFLOP/s",
+                     "frac": _r(rf["frac"], 3), "traffic": _r(rf["traffic"]), "traffic_source": (rf.get("traffic_source") or "")[:60] or None,
+                     "flops_per_launch": _r(rf["flops_per_launch"]), "avg_launch_us": _r(rf["avg_launch_us"]), "launches_timed": rf["launches_timed"],
+                     "whole_pass_frac": _r(rf["whole_pass"]["frac_of_peak"], 3)},
+        "cpu_baseline": None,
+    }
+    if extra_config:
+        out["config"].update(extra_config)
+    if cpu:
+        out["cpu_baseline"] = {k: (_r(cpu.get(k)) if k != "sample" else cpu[k][:200]) for k in
+                               ("value", "unit", "cores", "host_cores", "kind", "value_leg", "batch1_value", "batch1_cores", "sample")}
+        if cpu.get("value"):
+            out["cpu_baseline"]["gpu_over_cpu"] = _r(main_res["value"] / world / cpu["value"], 3)
+    if cpu_conv16 and cpu_conv16.get("value"):
+        out["cpu_baseline"]["conv16"] = {"value": _r(cpu_conv16["value"]), "cores": cpu_conv16.get("cores"), "value_leg": cpu_conv16.get("value_leg"),
+                                         "batch1_value": _r(cpu_conv16.get("batch1_value"))}
+    if fast:
+        out["fast_arithmetic"] = dict(compact(fast), dtype=DTYPE[1], peak=_r(fast["roofline"]["peak"]))
+    if per_width:
+        tab = {}
+        for name in PER_WIDTH:
+            if name not in per_width:
+                continue
+            w, fc, _, _ = WORKLOADS[name]
+            row = {"arch": "fc" if fc else "conv", "batch": next(iter(per_width[name].values()))["batch_per_gpu"]}
+            for arith, r in per_width[name].items():
+                row[arith] = compact(r)
+            tab[str(w)] = row
+        out["per_width"] = tab
+        out["per_width_note"] = "f32 frac vs 157.3, split frac vs 2500/3 TFLOP/s; frac = dominant GEMM kernel, pass_frac = whole step; conv FLOPs count padding taps"
+    if rccl_ranks_seen is not None:
+        out["rccl_ranks_seen"] = rccl_ranks_seen
+    if detail_file:
+        out["detail_file"] = detail_file
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                       # never let bulk push the head of the line out of the driver's tail buffer
+        for k in ("per_width_note", "pred_psnr_delta_db", "detail_file"):
+            out.pop(k, None)
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"].pop("sample", None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 def main():
@@ -388,35 +536,54 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS) + ["hm_kodak", "hm_bsds"])
-    ap.add_argument("--no-hm", action="store_true", help="skip the configs[3] / configs[4] HM campaigns of the default N = 1 line")
+    ap.add_argument("--arithmetic", default=None, choices=sorted(ARITH), help="top-level arithmetic (default f32 = the reference's; env PNN_PRECISION=1 -> split)")
     ap.add_argument("--hm-quick", action="store_true", help=argparse.SUPPRESS)   # 4 pictures per campaign (plumbing tests)
+    ap.add_argument("--hm-pictures", default="synthetic", choices=["synthetic", "natural"], help="hm_* workloads: picture set")
     ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the reference_arithmetic / conv16 sub-measurements")
-    ap.add_argument("--no-sustained", action="store_true", help="skip the >= %.0f s sustained regions" % SUSTAIN_SECONDS)
+    ap.add_argument("--cpu-legs-full", action="store_true", help="CPU legs at every candidate thread count (slower)")
+    ap.add_argument("--no-extras", action="store_true", help="only the top-level measurement (no fast_arithmetic / per_width / live traffic)")
+    ap.add_argument("--no-per-width", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_traffic.json instead of this run's own counter passes")
+    ap.add_argument("--sustained", action="store_true", help="add a >= %.0f s region per measurement (detail file)" % SUSTAIN_SECONDS)
+    ap.add_argument("--no-sustained", action="store_true", help=argparse.SUPPRESS)   # accepted, ignored (the default since round 4)
+    ap.add_argument("--no-hm", action="store_true", help=argparse.SUPPRESS)          # accepted, ignored (campaigns run only under --workload hm_*)
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"))
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)       # internal: one CPU-baseline leg, see cpu_leg_worker
     ap.add_argument("--leg-batch1", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--leg-threads", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--leg-budget", type=float, default=3.0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the profiled child of live_traffic
     args = ap.parse_args()
     if args.cpu_leg:
         return cpu_leg_worker(args.cpu_leg, args.workload, bool(args.leg_batch1), args.leg_threads, args.leg_budget)
+    precision = ARITH[args.arithmetic] if args.arithmetic else int(os.environ.get("PNN_PRECISION", "0"))
+    if args.pmc_child:
+        return pmc_child(args.workload, args.batch, precision, args.steps)
 
     from context_adaptive_neural_network_based_prediction_amd import sharding
     if args.workload.startswith("hm_"):
         # configs[3] / configs[4]: whole encodes through the reference's HM binaries, one batching service per device; this
         # process never touches the GPU (the services and the codecs are child processes)
         name = args.workload[3:]
-        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick)
+        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick, args.hm_pictures)
         r = rec.get(name, rec)
         ok = "error" not in r
+        with open(args.detail_file, "w") as f:
+            json.dump({"hm": rec}, f, indent=1)
+        cpu_pnn = r.get("cpu_pnn") or {}
         print(json.dumps({
-            "metric": "pnn_intra_pred_blocks_per_s", "value": r["service"]["pnn_blocks_per_s_over_the_wall"] if ok else None, "unit": "blocks/s",
-            "n_gpus": args.gpus, "steps": 1, "warmup": 0, "ms_per_step": 1e3 * r["wall_s_all_encodes_and_decodes"] if ok else None,
+            "metric": "pnn_intra_pred_blocks_per_s", "value": _r(r["service"]["pnn_blocks_per_s_over_the_wall"], 6) if ok else None, "unit": "blocks/s",
+            "n_gpus": args.gpus, "steps": 1, "warmup": 0, "ms_per_step": _r(1e3 * r["wall_s_all_encodes_and_decodes"], 6) if ok else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[1], "data": "synthetic",
-            "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign",
-                       "parallelism": "independent encodes dealt over one batching service per device, no collective"},
-            "hm": r, "roofline": None, "cpu_baseline": r.get("yardstick_hm_16_15_regular")}))
+            "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign", "pictures": r.get("pictures"),
+                       "picture_set": args.hm_pictures, "parallelism": "independent encodes dealt over one batching service per device, no collective"},
+            "hm": {k: r.get(k) for k in ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular", "every_decode_equals_its_encoder",
+                                         "service_start_s", "error")} if isinstance(r, dict) else None,
+            "roofline": None,
+            "cpu_baseline": {"value": cpu_pnn.get("pictures_per_s"), "unit": "pictures/s", "cores": cpu_pnn.get("cores"), "kind": "port",
+                             "sample": cpu_pnn.get("sample"), "hm_16_15_regular": r.get("yardstick_hm_16_15_regular")} if ok else None,
+            "detail_file": os.path.basename(args.detail_file)}, separators=(",", ":")))
         raise SystemExit(0 if ok else 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                     # before anything initialises HIP in this process
@@ -436,70 +603,61 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = sharding.init_ranks("gloo" if share else "nccl", None if share else torch.device("cuda", local_rank))   # "nccl" = RCCL on ROCm; None at N = 1
+    ranks_seen = None
+    if dist is not None:
+        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": sharding.count_distinct_devices(dist, local_rank, share)}
 
-    precision = int(os.environ.get("PNN_PRECISION", "1"))
+    t_start = time.perf_counter()
     wl = Workload(args.workload, args.batch, rank, local_rank)
     single = world == 1
-    sustain = 0.0 if args.no_sustained else SUSTAIN_SECONDS
+    sustain = SUSTAIN_SECONDS if args.sustained else 0.0
     main_res = measure(wl, precision, args.steps, args.warmup, dist, check=(rank == 0 and single), sustain_s=sustain)
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "pnn_intra_pred_blocks_per_s",
-            "value": main_res["value"], "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": main_res["dtype"], "data": "synthetic",
-            "config": {"workload": wl.cfg_name, "width": wl.width, "arch": "fully_connected" if wl.is_fc else "convolutional",
-                       "batch_per_gpu": wl.batch, "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
-                       "weights": "seeded random init with the reference initialisers' statistics",
-                       "parallelism": "independent blocks sharded over ranks, no data-path collective" + (" [PNN_BENCH_SHARE_GPU=1: all ranks on ONE device, plumbing check only]" if share else ""),
-                       "tile_autotune": "on first use, before the warm-up steps (pnn_set_option autotune)",
-                       "device_ramp": "%.2f s of untimed steps before the W warm-up steps (clock ramp)" % RAMP_SECONDS,
-                       "timed_regions": "%d regions of exactly K steps, each bracketed by barrier + synchronize; value = median region" % REPEATS,
-                       "arithmetic": "library default (`precision` = 1), see dtype; the same workload on the reference's IEEE-f32 arithmetic is "
-                                     "`reference_arithmetic` (and roofline.reference_arithmetic)",
-                       "rank_placement": ("rank 0 bound to cpus %s (its GPU's NUMA node)" % bound) if bound else "no NUMA binding (one node / not exposed)"},
-        }
-        for k in ("repeats", "launches_per_step", "max_abs_lsb_vs_oracle", "parity_detail", "pred_psnr", "roofline"):
-            out[k] = main_res.get(k)
-        out["cpu_baseline"] = None
-        out["sustained"] = {wl.name + ("_split_f16" if precision == 1 else "_f32"): main_res.get("sustained")}
+    detail = {"cmd": " ".join(sys.argv), "n_gpus": world, "main": main_res,
+              "config": {"rank_placement": ("rank 0 bound to cpus %s (its GPU's NUMA node)" % bound) if bound else "no NUMA binding (one node / not exposed)",
+                         "tile_autotune": "split kernels: on first use, before the warm-up steps; f32 kernels: rule-based",
+                         "device_ramp_s": RAMP_SECONDS, "share_gpu_plumbing_check": share}}
+    fast, per_width, cpu, cpu16 = None, None, None, None
     if single and not args.no_extras:
-        # the reference's own arithmetic on the same workload, and configs[2] on both
-        extras = {}
-        compact = lambda r: {"value": r["value"], "unit": "blocks/s", "ms_per_step": r["ms_per_step"], "dtype": r["dtype"],
-                             "roofline_frac": r["roofline"]["frac"], "roofline_peak_tflops": r["roofline"]["peak"],
-                             "roofline_achieved_tflops": r["roofline"]["achieved"], "max_abs_lsb_vs_oracle": r.get("max_abs_lsb_vs_oracle")}
-        if precision != 0:
-            ref = measure(wl, 0, args.steps, args.warmup, None, sustain_s=sustain)
-            extras["reference_arithmetic"] = ref
-            out["roofline"]["reference_arithmetic"] = compact(ref)
-            out["sustained"][wl.name + "_f32"] = ref.pop("sustained", None)
-        if args.workload != "conv16":
-            wc = Workload("conv16", 0, rank, local_rank)
-            k16 = max(20, args.steps // 4)
-            c_sp, c_f32 = measure(wc, 1, k16, args.warmup, None, sustain_s=sustain), measure(wc, 0, k16, args.warmup, None, sustain_s=sustain)
-            out["sustained"]["conv16_split_f16"] = c_sp.pop("sustained", None)
-            out["sustained"]["conv16_f32"] = c_f32.pop("sustained", None)
-            extras["conv16"] = {"config": {"workload": wc.cfg_name, "batch_per_gpu": wc.batch, "steps": k16},
-                                "split_f16": c_sp, "reference_arithmetic": c_f32}
-            out["roofline"]["conv16"] = {"split_f16": compact(c_sp), "reference_arithmetic": compact(c_f32)}
-            if not args.no_cpu_baseline:
-                extras["conv16"]["cpu_baseline"] = cpu_legs(wc, budget_s=1.5)
-        out.update(extras)
-        out["roofline"]["sustained"] = out["sustained"]
+        k_pw = min(args.steps, 20)
+        per_width = {args.workload: {("f32" if precision == 0 else "split"): main_res}} if args.workload in PER_WIDTH else {}
+        fast = measure(wl, 1 - precision, args.steps, args.warmup, None, sustain_s=sustain)
+        if args.workload in PER_WIDTH:
+            per_width[args.workload]["f32" if precision == 1 else "split"] = fast
+        if precision == 1:                            # `fast_arithmetic` is always the split mode; with --arithmetic split the f32 twin sits in per_width
+            fast = None
+        if not args.no_per_width:
+            for name in PER_WIDTH:
+                if name == args.workload:
+                    continue
+                wn = Workload(name, 0, rank, local_rank)
+                per_width[name] = {a: measure(wn, ARITH[a], k_pw, args.warmup, None, repeats=3, ramp_s=0.25, sustain_s=sustain) for a in ("f32", "split")}
+                del wn
+                torch.cuda.empty_cache()
+        detail["per_width"] = per_width
+        detail["fast_arithmetic"] = fast
+    if rank == 0 and single and not args.no_extras and not args.no_live_traffic:
+        lt = live_traffic(args.workload, wl.batch, precision)
+        detail["live_traffic"] = lt
+        if lt and "bytes_per_launch" in lt:
+            main_res["roofline"]["traffic"], main_res["roofline"]["traffic_source"] = lt["bytes_per_launch"], "this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE"
     if rank == 0 and single and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_legs(wl)
-    if rank == 0 and single and not args.no_extras and not args.no_hm:
-        # BASELINE.json configs[3] / configs[4] at their stated counts (24 x 768x512 through hm_16_15_substitution, 100 x 480x320
-        # through hm_16_15_switch), after the kernel measurements: child processes only, ~30 s on the 256-core GPU box
-        out["hm"] = hm_campaigns(["kodak", "bsds"], [local_rank], args.hm_quick)
-        if isinstance(out.get("cpu_baseline"), dict):
-            out["cpu_baseline"]["hm_16_15_regular"] = {k: v.get("yardstick_hm_16_15_regular") for k, v in out["hm"].items() if isinstance(v, dict)}
-            out["cpu_baseline"]["hm"] = {k: {kk: v.get(kk) for kk in ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
-                                                                     "every_decode_equals_its_encoder")} for k, v in out["hm"].items() if isinstance(v, dict)}
+        cpu = cpu_legs(args.workload, full=args.cpu_legs_full)
+        detail["cpu_baseline"] = cpu
+        if not args.no_extras and args.workload != "conv16":
+            cpu16 = cpu_legs("conv16", full=args.cpu_legs_full)
+            detail["cpu_baseline_conv16"] = cpu16
     if rank == 0:
-        print(json.dumps(out))
+        detail["wall_s"] = time.perf_counter() - t_start
+        try:
+            with open(args.detail_file, "w") as f:
+                json.dump(detail, f, indent=1)
+            dfile = os.path.basename(args.detail_file)
+        except OSError as e:
+            sys.stderr.write("bench.py: cannot write %s: %s\n" % (args.detail_file, e))
+            dfile = None
+        print(build_line(main_res, world, args.steps, args.warmup, wl.cfg_name, fast, per_width, cpu, cpu16, dfile,
+                         {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"} if share else None, ranks_seen))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -30,7 +30,9 @@ def init_ranks(backend, device=None):
 
 def timed_steps(step, n_steps, sync, dist=None, device=None):
     """The bench contract's timed region: barrier + device synchronisation, EXACTLY n_steps calls of `step`, device
-    synchronisation + barrier, and the job's time = the MAX over ranks (seconds, the same value on every rank).
+    synchronisation, and the job's time = the MAX over ranks (seconds, the same value on every rank).  The clock of a rank
+    stops when ITS device is idle, before any exchange: the closing rendezvous is the max-reduction itself (an all-reduce
+    every rank must reach), so its 30-100 us on RCCL never enter a region that may last only a few milliseconds.
     `sync` waits for this rank's device work (torch.cuda.synchronize on a GPU rank, a no-op on the CPU)."""
     sync()
     if dist is not None:
@@ -40,9 +42,17 @@ def timed_steps(step, n_steps, sync, dist=None, device=None):
     for _ in range(n_steps):
         step()
     sync()
-    if dist is not None:
-        dist.barrier()
-    return max_over_ranks(time.perf_counter() - t0, dist, device)
+    elapsed = time.perf_counter() - t0
+    return max_over_ranks(elapsed, dist, device)      # the closing barrier: every rank waits here for the slowest one
+
+
+def count_distinct_devices(dist, local_rank, share=False):
+    """How many different (host, device) pairs the ranks of the initialised group sit on -- gathered over the group itself, so
+    a bench line that says N ranks were on N devices has been through N-way collectives (RCCL when the backend is "nccl")."""
+    import socket
+    objs = [None] * dist.get_world_size()
+    dist.all_gather_object(objs, (socket.gethostname(), 0 if share else int(local_rank)))
+    return len(set(objs))
 
 
 def shard_bounds(n_items, rank, world_size):

@@ -1072,8 +1072,10 @@ def test_bench_two_ranks_on_one_gpu(precision, tmp_path, launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 10
     assert d["config"]["batch_per_gpu"] == 1024
-    assert abs(d["value"] - 2 * 1024 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]   # whole-job blocks over the slowest rank's time
-    assert d["cpu_baseline"] is None and "reference_arithmetic" not in d       # the extras are N = 1 only
+    assert abs(d["value"] - 2 * 1024 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 2e-5 * d["value"]   # whole-job blocks over the slowest rank's time (6 significant digits each)
+    assert d["cpu_baseline"] is None and "fast_arithmetic" not in d and "per_width" not in d   # the extras are N = 1 only
+    assert d["dtype"] == "f32" and len(lines[0]) < 4096
+    assert d["rccl_ranks_seen"] == {"backend": "gloo", "world_size": 2, "devices": 1}          # share mode: both ranks on device 0, joined over gloo
 
 
 @pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (8, False), (16, False), (32, False)])

@@ -337,6 +337,12 @@ assert 0.02 * world * k <= t < 0.02 * world * k + 0.5, t
 both = [None, None]
 dist.all_gather_object(both, t)
 assert both[0] == both[1], "ranks disagree on the job's time: %%r" %% (both,)
+# the clock stops BEFORE the closing rendezvous: a rank that is late to it does not lengthen the region
+t2 = sharding.timed_steps(lambda: None, 3, (lambda: time.sleep(0.3 * rank)) , dist)    # `sync` of rank 1 is slow; two of its three calls precede t0
+assert t2 < 0.3 + 0.25, t2
+# bench.py's rccl_ranks_seen: two ranks on one host, same local device 0 -> one distinct device in share mode, two otherwise
+assert sharding.count_distinct_devices(dist, rank, share=False) == 2
+assert sharding.count_distinct_devices(dist, rank, share=True) == 1
 dist.barrier()
 dist.destroy_process_group()
 print("rank %%d ok" %% rank)
@@ -606,6 +612,50 @@ def test_bench_self_launch_without_a_gpu():
                            text=True, timeout=300, cwd=root)
         assert r.returncode != 0 and "no HIP device visible" in r.stderr, r.stderr[-2000:]
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _canned_measurement(name, precision, lsb=0):
+    import bench
+    w, fc, batch, _ = bench.WORKLOADS[name]
+    return {"value": 1.6234567e7, "unit": "blocks/s", "ms_per_step": 0.25234567, "dtype": bench.DTYPE_LONG[precision], "precision": precision, "steps": 20,
+            "workload": name, "batch_per_gpu": batch, "launches_per_step": 14, "max_abs_lsb_vs_oracle": lsb,
+            "repeats": {"n": 5, "ms_per_step_all": [0.25234567] * 5}, "pred_psnr": {"gpu_db": 11.123456, "oracle_db": 11.123456, "delta_db": 1.234e-7},
+            "roofline": {"bound": "mfma", "kernel": "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)",
+                         "achieved": 118.7654321, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.7550123456, "traffic": 59355500.61482544,
+                         "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE", "flops_per_launch": 8912345678.9, "avg_launch_us": 75.0123456,
+                         "launches_timed": 150, "whole_pass": {"tflops": 107.123456, "frac_of_peak": 0.681234567}}}
+
+
+def test_bench_line_fits_the_driver_tail_buffer():
+    """The ONE JSON line bench.py prints must stay below 4 KB whatever the run measured (round 3's 24 KB line lost its head --
+    value, roofline, cpu_baseline -- in the driver's 8 KB tail buffer): build_line on canned results of every sub-measurement,
+    with the longest strings and full-precision floats the real run can produce."""
+    import json
+    import bench
+    main = _canned_measurement("fc8", 0, lsb=1)
+    fast = _canned_measurement("fc8", 1)
+    per_width = {n: {"f32": _canned_measurement(n, 0), "split": _canned_measurement(n, 1)} for n in bench.PER_WIDTH}
+    cpu = {"value": 12345.678901, "unit": "blocks/s", "cores": 64, "host_cores": 256, "kind": "port", "value_leg": "torch_cpu_batched",
+           "batch1_value": 234.5678901, "batch1_leg": "torch_cpu_batch1", "batch1_cores": 8, "sample": "x" * 600, "legs": {"bulk": "y" * 5000}}
+    line = bench.build_line(main, 8, 20, 5, bench.WORKLOADS["fc8"][3], fast, per_width, cpu, dict(cpu), "bench_detail.json",
+                            {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"}, {"backend": "nccl", "world_size": 8, "devices": 8})
+    assert len(line) < bench.LINE_LIMIT and "\n" not in line, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "fast_arithmetic", "per_width", "rccl_ranks_seen"):
+        assert k in d, k
+    assert d["dtype"] == "f32" and d["n_gpus"] == 8 and d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "flops_per_launch", "avg_launch_us"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 2e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert sorted(d["per_width"]) == ["16", "32", "4", "64", "8"]
+    for row in d["per_width"].values():
+        assert row["arch"] in ("fc", "conv") and {"value", "frac", "lsb"} <= set(row["f32"]) and {"value", "frac", "lsb"} <= set(row["split"])
+    # the minimal line (N > 1 ranks: no extras) carries the contract keys too
+    d2 = json.loads(bench.build_line(main, 2, 20, 5, "w", rccl_ranks_seen={"backend": "nccl", "world_size": 2, "devices": 2}))
+    assert d2["cpu_baseline"] is None and d2["rccl_ranks_seen"]["devices"] == 2 and d2["value"] == d["value"]
 
 
 def test_gpu_placement_helpers(tmp_path):

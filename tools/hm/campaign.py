@@ -68,7 +68,7 @@ def _service_stats(stdout_text, stderr_text):
     return out
 
 
-def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800):
+def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800, picture_set="synthetic"):
     cfg = CONFIGS[config]
     n = int(pictures or cfg["pictures"])
     h, w, variant = cfg["height"], cfg["width"], cfg["variant"]
