@@ -177,6 +177,8 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
     if (const char* e = getenv("PNN_PRECISION")) c->opt_precision = atol(e);
     if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
+    if (const char* e = getenv("PNN_F32_KERNEL")) c->opt_f32_kernel = atol(e);
+    if (const char* e = getenv("PNN_F32_CFG")) c->opt_f32_cfg = atol(e);
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_SMALL")) c->opt_small = atol(e);
@@ -342,6 +344,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
+    else if (!strcmp(name, "f32_kernel")) { c->opt_f32_kernel = value; c->tuned.clear(); c->tune_gen++; }
+    else if (!strcmp(name, "f32_cfg")) c->opt_f32_cfg = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
     cache_clear(c);                                   // any option may change the arithmetic path: cached predictions are dropped

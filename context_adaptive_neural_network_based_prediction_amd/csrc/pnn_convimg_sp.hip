@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         float* raw = reinterpret_cast<float*>(Bs);
         const int K0 = p.k0, S0 = p.s0, IH0 = p.IH * S0, IW0 = p.IW * S0;
         const int PH = (p.IH - 1) * S0 + K0, PW = (p.IW - 1) * S0 + K0;
+        bool in_bad = false;                           // a raw context element outside the f16 range (leaves_f16, pnn_device_common.h)
         if (p.plane0) {
             // the context gather fused in as well: straight from the picture plane through the TB descriptors (same values as
             // gather_f32x4_kernel writes: (float) pel - mean, unavailable units 0), no gather launch, no 5 KB per block round trip
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                     }
                     if (ok) v = (p.pel0 == 4 ? (float)reinterpret_cast<const int32_t*>(p.plane0)[off] : (float)reinterpret_cast<const uint8_t*>(p.plane0)[off]) - p.mean;
                 }
+                in_bad |= leaves_f16(v);
                 raw[idx] = v;
             }
         } else
@@ -102,8 +104,11 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             const int li = idx / (PH * PW), r0 = idx - li * PH * PW;
             const int r = r0 / PW, c = r0 - r * PW;
             const int iy = r - p.pad0, ix = c - p.pad0;
-            raw[idx] = ((unsigned)iy < (unsigned)IH0 && (unsigned)ix < (unsigned)IW0) ? p.X0[((size_t)(img0 + li) * IH0 + iy) * IW0 + ix] : 0.f;
+            const float v = ((unsigned)iy < (unsigned)IH0 && (unsigned)ix < (unsigned)IW0) ? p.X0[((size_t)(img0 + li) * IH0 + iy) * IW0 + ix] : 0.f;
+            in_bad |= leaves_f16(v);
+            raw[idx] = v;
         }
+        if (in_bad && p.range_flag) *p.range_flag = 1;
         __syncthreads();
         // The contraction over the taps on the matrix cores (FirstConv, pnn_device_common.h): a wave takes 32 staged pixels at a
         // time, builds its operand from the raw tile, runs one MFMA chain per 32-channel column tile and writes scale / bias /

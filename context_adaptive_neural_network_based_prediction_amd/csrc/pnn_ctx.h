@@ -103,6 +103,10 @@ struct pnn_ctx {
     long opt_canonical = 1;
     long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
     long opt_sp_cfg = -1;
+    // exact-f32 passes: 1 (default) = tapgemm_f32_kernel (32x32x2 MFMA, one wave per SIMD; FC nets: output layer fused into the last
+    // hidden layer's launch); 0 = the round-1 kernels (tapgemm_kernel on 16x16x4 MFMA, tapgemm_splitk_kernel for small M)
+    long opt_f32_kernel = 1;
+    long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
@@ -173,6 +177,7 @@ int choose_cfg_convimg(const TapGemmParams& p, bool one_tap);
 bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total);
 int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false);
 int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total);
+int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused);
 // pnn_tuner.cpp
 // First sighting of (key, M): every legal configuration code in [0, ncodes) runs the real launch (idempotent) on stream
 // `s`, the fastest is remembered in c->tuned and returned in *cfg; later sightings return the remembered code.  `rule` =

@@ -80,6 +80,11 @@ __device__ __forceinline__ void report_range(int* flag, float amax)
 {
     if (flag && !(amax < kF16Max)) *flag = 1;
 }
+// The same guard for values that are split WITHOUT passing store_split4: the raw context a first convolution reads (FirstConv
+// below splits its taps in registers).  A finite context element of 1e5 would give hi = inf, lo = -inf and a NaN out of the MFMA
+// chain -- which amax4 / fmaxf then DROP, so the output-side guard alone stays silent.  Checked where the plane is staged into
+// LDS: one compare per input element (a 16x16-net image: 1280 elements against ~10 k tap reads), NaN and infinity included.
+__device__ __forceinline__ bool leaves_f16(float v) { return !(fabsf(v) < kF16Max); }
 
 // hi = (f16) v, lo = (f16)(v - (float) hi), four values at a time, in 6 VALU instructions instead of 14: both halves of a
 // pair are rounded by one v_cvt_pk_f16_f32 (round to nearest even, like the scalar conversion), and v_fma_mix{lo,hi}_f16

@@ -1,0 +1,448 @@
+// Exact-f32 tap GEMM on v_mfma_f32_32x32x2_f32 with ONE wave per SIMD and nothing left for that wave to wait for.
+//
+// Same contract as tapgemm_kernel / tapgemm32_kernel (TapGemmParams, pnn_kernels.h):
+//   Y[pix(m)][n] = act( sum_{taps, ci} X[b, i*a+dy, j*a+dx, ci] * W[tap][ci][n] + bias[n] )
+// i.e. the FC layers, convolutions and transposed convolutions of pnn/components.py:10-261 in the REFERENCE's arithmetic
+// (IEEE float32 products, float32 accumulation: pnn/tfutils.py:107-139, components.py:169-176).  Same per-output summation order
+// as tapgemm32_kernel (16-deep chunks in K order; MFMA step e of a chunk adds x[8h + e] * w[8h + e] for the two k-halves h),
+// so every tile of either kernel gives the same bits: this is the canonical f32 order of the library.
+//
+// Why another kernel (tools/mfma_peak.hip, tools/f32_sweep.py; profiles/r04_f32_tile_sweep.txt): the 32x32x2 instruction sustains
+// 154.5 TFLOP/s (0.98 of the 157.3 peak) with one or two waves per SIMD and 124 with four, the 16x16x4 instruction 124-139 with
+// as many waves as fit -- the f32 roof is only within reach of a kernel that runs FEW waves with BIG wave tiles.  tapgemm32_kernel
+// has the tiles but not the schedule: one wave per SIMD exposes every wait (fragment reads at the head of a stage, the issue
+// time of its ten 1-KiB global loads, ds_write + barrier at its end), and its 128 x 128 / 128 x 160 tiles measured 63-78 TFLOP/s
+// on the FC 8x8 layers where the 64 x 64 tiles of the 16x16x4 kernel reach 109.  Here:
+//   * workgroup = 4 waves, wave w owns rows [32*RT*w, +32*RT) of the BM = 128*RT row tile and all BN = 32*NT columns (FC 8x8 at
+//     batch 4096: 128 x 160 tiles = 32 x 8 workgroups, exactly one per CU, 0.9375 of the columns real);
+//   * weights: global -> LDS by LDS-DMA (no staging registers, no ds_write), THREE stage buffers of KC chunks; the one barrier of a
+//     stage sits BEFORE its last chunk, so that the first fragments of the next stage are read under that chunk's MFMAs, and stage
+//     s+2 is fetched all along stage s into the buffer stage s-1 left (a whole stage to land);
+//   * fragments: two register sets, chunk j+1's read under chunk j's MFMAs; activations: global -> registers a stage ahead,
+//     two sets alternating by stage parity (the loop body is instantiated for both parities: no copies);
+//   * every memory instruction sits alone between two MFMAs (sched_barrier after each): a 1-KiB vector-memory instruction
+//     holds its wave for about as long as a 32x32x2 MFMA runs (64 cycles), two in a row stall the matrix pipe.  First version of
+//     this file, pairs of loads per k-step: FC 1200 x 1200 at batch 4096 99 us; one per MFMA slot: see DESIGN.md section 4;
+//   * FUSE: the net's output layer (<= 64 outputs, no activation: components.py:173-176) is applied to the activated output
+//     tile straight from the accumulators -- the D layout of one MFMA (lane = row m, registers = columns 8g + 4h + r) IS the
+//     B-operand layout of the next -- and leaves as per-column-tile partial sums [tile][M][64] for fuse_reduce_kernel.  The column
+//     tiles are the K segments of the output layer's canonical order; fc_out_f32_kernel reproduces them from stored activations
+//     for the batch sizes that do not take this tile.
+#include "pnn_kernels.h"
+#include "pnn_device_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace pnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4* l)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_le()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+template <int RT, int NT, int KC, bool FUSE>
+__global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
+{
+    touch_kernargs<sizeof(TapGemmParams)>();
+    static_assert(KC >= 2 && KC % 2 == 0, "fragment sets alternate by chunk parity");
+    constexpr int BM = 128 * RT, BN = 32 * NT;
+    constexpr int E = 4 * BN;                        // 16-byte pieces per staged weight chunk: [q = 4][BN]
+    constexpr int SE = KC * E;                       // pieces per stage
+    constexpr int NDMA = SE / 64;                    // LDS-DMA wave-instructions per stage = 2 KC NT, dealt round-robin to the 4 waves
+    constexpr int NPW = NDMA / 4;
+    constexpr int W2R = BN / 4;                      // FUSE: rows of 64 pieces of the output layer's weight tile
+    static_assert(SE % 64 == 0 && NDMA % 4 == 0, "a stage is a whole number of wave instructions, the same number for every wave");
+    // memory work of one chunk, one instruction per MFMA slot: 2 NT fragment reads (next chunk), 2 RT activation loads (this chunk
+    // of the NEXT stage), this chunk's share of the LDS-DMA of stage s+2
+    constexpr int SLOTS = 8 * NT * RT;
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // [3][SE] weight stages | FUSE: [W2R][64] output-layer tile
+    f32x4* const W2s = lds + 3 * SE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cls = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM + wave * (32 * RT);
+#ifdef PNN_F32_DIAG             // diagnostic library only (make diag): cycle stamps of wave 0 -> p.Xlo[workgroup][8]
+    const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dq1 = 0, dq2 = 0;
+#endif
+
+    int pb[RT], pi[RT], pj[RT];
+    bool mv[RT];
+    const int SP = p.SH * p.SW;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int mg = m0 + rt * 32 + l31;
+        mv[rt] = mg < p.M;
+        const int mc = mv[rt] ? mg : 0;
+        if (SP == 1) { pb[rt] = mc; pi[rt] = 0; pj[rt] = 0; }       // fully-connected layer (launch-uniform): no divisions
+        else {
+            const int b = mc / SP;
+            const int r = mc - b * SP;
+            pb[rt] = b;
+            pi[rt] = r / p.SW;
+            pj[rt] = r - pi[rt] * p.SW;
+        }
+    }
+
+    const int cpt = p.Cin >> 4;                      // 16-deep chunks per tap (a multiple of KC, or one tap)
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    const int nchunks = (t1 - t0) * cpt;
+    const int nstages = (nchunks + KC - 1) / KC;     // the packed weights are zero-padded to whole stages (kChunkPad)
+
+    // ---- weights: this lane's pieces of a stage (LDS-DMA: lane-linear destination, per-lane source) ------------------------
+    const unsigned wbytes = (unsigned)p.chunk_begin[p.ncls] * 4u * (unsigned)p.Npad * 16u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, wbytes, 0x00020000);
+    const unsigned wcls = (unsigned)p.chunk_begin[cls] * 4u * (unsigned)p.Npad * 16u;
+    const unsigned wstage = (unsigned)(KC * 4) * (unsigned)p.Npad * 16u;      // bytes per stage
+    unsigned bsrc[NPW];
+#pragma unroll
+    for (int ii = 0; ii < NPW; ii++) {
+        const int i = wave + 4 * ii;
+        const int e = 64 * i + lane;
+        const int j = e / E, ee = e - j * E;
+        const int q = ee / BN, nn = ee - q * BN;
+        bsrc[ii] = (unsigned)(((j * 4 + q) * p.Npad + n0 + nn) << 4) + wcls;
+    }
+    auto dma_b = [&](int stage, int buf, int ii) {   // instruction ii of this wave
+        dma16(wrsrc, bsrc[ii], (unsigned)stage * wstage, lds + buf * SE + 64 * (wave + 4 * ii));
+    };
+
+    // ---- activations: buffer-descriptor loads, out-of-image taps / rows past M read zeros, per-tap byte offsets ------------
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+    unsigned aoff[RT];
+    auto tap_setup = [&](int tp) {                   // tp = (dy << 16) | (dx & 0xffff)
+        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
+            const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            const unsigned off = ((unsigned)((pb[rt] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin + (h << 3)) << 2;
+            aoff[rt] = ok ? off : 0x80000000u;
+        }
+    };
+    // cursor of the NEXT stage to be loaded
+    int lt = t0, lcc = 0, ltp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
+    tap_setup(p.tap[t0]);
+    auto load_a_chunk = [&](int j, f32x4 (&dst)[KC][RT][2]) {
+        const int cj = lcc + j < cpt ? lcc + j : cpt - 1;          // padding chunk: zero weights, any finite data will do
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            dst[j][rt][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt], cj << 6, 0));
+            dst[j][rt][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[rt] + 16u, cj << 6, 0));
+        }
+    };
+    auto advance_a = [&]() {                         // to the stage after the one just loaded (wave-uniform)
+        lcc += KC;
+        if (lcc >= cpt && lt + 1 < t1) {
+            lcc = 0;
+            ++lt;
+            tap_setup(ltp_next);
+            ltp_next = p.tap[lt + 1 < t1 ? lt + 1 : lt];
+        }
+    };
+
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
+
+    auto read_wf = [&](int buf, int j, int nt, f32x4 (&wf)[NT][2]) {
+        wf[nt][0] = lds[buf * SE + j * E + (2 * h) * BN + nt * 32 + l31];
+        wf[nt][1] = lds[buf * SE + j * E + (2 * h + 1) * BN + nt * 32 + l31];
+    };
+
+    // ---- prologue: stages 0 and 1 on their way, the output layer's weight tile behind them -------------------------------
+    f32x4 a0[KC][RT][2], a1[KC][RT][2];              // activations of the even / odd stages
+    f32x4 wf0[NT][2], wf1[NT][2];                    // weight fragments of the even / odd chunks
+#pragma unroll
+    for (int ii = 0; ii < NPW; ii++) dma_b(0, 0, ii);
+#pragma unroll
+    for (int j = 0; j < KC; j++) load_a_chunk(j, a0);
+    advance_a();
+    const int s1 = nstages > 1 ? 1 : 0;
+#pragma unroll
+    for (int ii = 0; ii < NPW; ii++) dma_b(s1, 1, ii);
+    if (FUSE) {
+        // rows n/4 in [n0/4, n0/4 + BN/4) of the output layer's pack [k/4][Npad2][4 floats]: its first 64 columns, 1 KiB per row;
+        // rows past its K read zeros (descriptor bound)
+        const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2p, 0, (unsigned)p.K2chunks * 4u * (unsigned)p.Npad2 * 16u, 0x00020000);
+        for (int r = wave; r < W2R; r += 4) dma16(w2rsrc, (unsigned)(((n0 >> 2) + r) * p.Npad2 + lane) << 4, 0, W2s + r * 64);
+    }
+    wait_vm_le<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) read_wf(0, 0, nt, wf0);
+
+    // ---- one stage: KC chunks of 8 k-steps x NT x RT MFMAs; after each MFMA at most ONE memory instruction -------------------
+    // chunk j carries: the fragment reads of chunk j+1 (the last chunk: the next stage's first, from its buffer), the
+    // activation loads of chunk j of stage s+1, and its share of the LDS-DMA of stage s+2 into buffer (s+2) % 3.
+    auto stage = [&](int s, int buf, f32x4 (&acur)[KC][RT][2], f32x4 (&anxt)[KC][RT][2]) {
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;      // (s+1) % 3, (s+2) % 3
+        const int s2 = s + 2 < nstages ? s + 2 : nstages - 1;       // past the end: the last stage again (harmless, no exec-masked code)
+#pragma unroll
+        for (int j = 0; j < KC; j++) {
+            constexpr int kLast = KC - 1;
+            const int d0 = j * NPW / KC, d1 = (j + 1) * NPW / KC;   // this chunk's LDS-DMA instructions [d0, d1)
+            const int nops = 2 * NT + 2 * RT + (d1 - d0);
+            if (j == kLast) {
+                // every LDS-DMA of stage s+1 has landed (issued during stage s-1; what this stage issued so far -- 2 RT activation
+                // loads and the DMA share per chunk, all younger -- may stay in flight), this wave's fragment reads are complete:
+                // after the barrier stage s+1 is whole in its buffer
+                wait_vm_le<(2 * RT) * (KC - 1) + (KC - 1) * NPW / KC>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            f32x4 (&wc)[NT][2] = (j & 1) ? wf1 : wf0;
+            f32x4 (&wn)[NT][2] = (j & 1) ? wf0 : wf1;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nt][e >> 2][e & 3], acur[j][rt][e >> 2][e & 3], acc[rt][nt], 0, 0, 0);
+                        // the memory instruction of this MFMA slot, if any: operation k of the chunk sits in slot k * SLOTS / nops
+                        const int sl = (e * NT + nt) * RT + rt;
+                        const int k = (sl * nops + SLOTS - 1) / SLOTS;
+                        if (k < nops && k * SLOTS / nops == sl) {
+                            if (k < 2 * NT) {                       // fragment k of the next chunk
+                                const int fnt = k >> 1, fh = k & 1;
+                                const int src = (j == kLast ? buf1 * SE : buf * SE + (j + 1) * E) + (2 * h + fh) * BN + fnt * 32 + l31;
+                                wn[fnt][fh] = lds[src];
+                            } else if (k < 2 * NT + 2 * RT) {       // activations of chunk j of stage s+1
+                                const int ar = (k - 2 * NT) >> 1, ah = (k - 2 * NT) & 1;
+                                const int cj = lcc + j < cpt ? lcc + j : cpt - 1;   // padding chunk: zero weights, any finite data will do
+                                anxt[j][ar][ah] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[ar] + 16u * ah, cj << 6, 0));
+                            } else {
+                                dma_b(s2, buf2, d0 + (k - 2 * NT - 2 * RT));
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+        advance_a();
+    };
+#ifdef PNN_F32_DIAG
+    dq1 = __builtin_amdgcn_s_memtime();
+#endif
+    int s = 0, buf = 0;
+    for (; s + 1 < nstages; s += 2) {
+        stage(s, buf, a0, a1);
+        buf = buf == 2 ? 0 : buf + 1;
+        stage(s + 1, buf, a1, a0);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (s < nstages) stage(s, buf, a0, a1);
+#ifdef PNN_F32_DIAG
+    dq2 = __builtin_amdgcn_s_memtime();
+    auto diag_out = [&]() {
+        if (tid == 0 && p.Xlo) {
+            unsigned long long* d = (unsigned long long*)p.Xlo + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = __builtin_amdgcn_s_memtime() - dq2; d[3] = __builtin_amdgcn_s_memrealtime() - dr0;
+            d[4] = dr0;
+        }
+    };
+#else
+    auto diag_out = [&]() {};
+#endif
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    const int py = p.py[cls], px = p.px[cls];
+    f32x4 bvs[NT][4];                                // all bias loads before the first store (see pnn_gemm_sp.hip)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + nt * 32 + 8 * g + 4 * h;
+            bvs[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.Cout ? n : 0));
+        }
+    if (FUSE && p.W2p) {
+        // out2[m][o] = sum_n leaky(acc[m][n] + bias[n]) * W2[n][o] over this tile's BN columns n: accumulator register 4g + r of
+        // column tile nt is n = n0 + 32 nt + 8g + 4h + r of row m = lane & 31 -- fed as the B operand of k-step (g, r); the A
+        // operand (rows o = 32 ot + (lane & 31)) is piece ((32 nt + 8g + 4h) / 4, o) of the output layer's pack, element r.
+        // Columns past Cout: zero weights in both layers.
+        static_assert(!FUSE || RT == 1, "the fused output layer is written for one row tile per wave");
+        constexpr int OT = 2;                        // 64 outputs
+        f32x16 acc2[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[ot][i] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f32x4 w2[4][OT];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) w2[g][ot] = W2s[(8 * nt + 2 * g + h) * 64 + ot * 32 + l31];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                f32x4 v = (f32x4){acc[0][nt][4 * g], acc[0][nt][4 * g + 1], acc[0][nt][4 * g + 2], acc[0][nt][4 * g + 3]} + bvs[nt][g];
+                if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[g][ot][r], v[r], acc2[ot], 0, 0, 0);
+            }
+        }
+        if (mv[0]) {
+            float* dst = p.part + ((size_t)blockIdx.y * p.M + (m0 + l31)) * 64;
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *reinterpret_cast<f32x4*>(dst + ot * 32 + 8 * g + 4 * h) =
+                        (f32x4){acc2[ot][4 * g], acc2[ot][4 * g + 1], acc2[ot][4 * g + 2], acc2[ot][4 * g + 3]};
+        }
+        diag_out();
+        return;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        if (!mv[rt]) continue;
+        const int oy = pi[rt] * p.os + py, ox = pj[rt] * p.os + px;
+        const size_t obase = (((size_t)pb[rt] * p.OH + oy) * p.OW + ox) * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + nt * 32 + 8 * g + 4 * h;
+                if (n < p.Cout) {
+                    f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} + bvs[nt][g];
+                    if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                    if (p.Yi) {
+                        int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+                        *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
+                    }
+                }
+            }
+    }
+    diag_out();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Output layer (<= 64 outputs) of an FC net from STORED activations, in the fused kernel's order: K segment t = columns
+// [160 t, 160 t + 160) of the last hidden layer, one chain of 80 k-steps per segment (5 column tiles x (g, r), the two k-halves
+// h = hidden units 8g + r and 8g + 4 + r of the tile), partial sums [segment][M][64] for fuse_reduce_kernel.  One wave per
+// (32 rows, segment).  For the batch sizes whose last hidden layer does not run on the fused 128 x 160 tile.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fc_out_f32_kernel(const TapGemmParams p)
+{
+    constexpr int NT = 5, OT = 2;
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const int m = blockIdx.x * 32 + l31, seg = blockIdx.y, n0 = seg * 32 * NT;
+    const bool mv = m < p.M;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)p.chunk_begin[1] * 4u * (unsigned)p.Npad * 16u, 0x00020000);
+    f32x16 acc2[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc2[ot][i] = 0.f;
+    f32x4 x[NT][4], w2[NT][4][OT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + 32 * nt + 8 * g + 4 * h;
+            // activations past Cin (the last segment: 1120 + 160 > 1200) and rows past M read zeros
+            const unsigned xo = (mv && n < p.Cin) ? ((unsigned)m * (unsigned)p.Cin + (unsigned)n) << 2 : 0x80000000u;
+            x[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0));
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++)
+                w2[nt][g][ot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)((n >> 2) * p.Npad + ot * 32 + l31) << 4, 0, 0));
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[nt][g][ot][r], x[nt][g][r], acc2[ot], 0, 0, 0);
+    if (mv) {
+        float* dst = p.part + ((size_t)seg * p.M + m) * 64;
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<f32x4*>(dst + ot * 32 + 8 * g + 4 * h) = (f32x4){acc2[ot][4 * g], acc2[ot][4 * g + 1], acc2[ot][4 * g + 2], acc2[ot][4 * g + 3]};
+    }
+}
+
+hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments)
+{
+    if (p.M <= 0) return hipSuccess;
+    const int segs = (p.Cin + 159) / 160;
+    if (segments) *segments = segs;
+    pnn_launch(fc_out_f32_kernel, dim3((p.M + 31) / 32, segs), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+// {rt, nt, kc, fuse-capable}
+#define PNN_F32_CFGS(X) \
+    X(1, 5, 4) X(1, 5, 2) X(1, 4, 4) X(1, 4, 2) X(1, 3, 4) X(1, 2, 4) X(1, 2, 2) X(1, 1, 4) X(1, 1, 2) \
+    X(2, 4, 2) X(2, 2, 4) X(2, 2, 2) X(2, 1, 4) X(2, 3, 2)
+
+static const TileCfg kCfgsF32[] = {
+#define X(rt, nt, kc) {rt, nt, kc, 32},
+    PNN_F32_CFGS(X)
+#undef X
+};
+
+int tapgemm_f32_num_cfgs() { return (int)(sizeof(kCfgsF32) / sizeof(kCfgsF32[0])); }
+TileCfg tapgemm_f32_cfg(int idx) { return kCfgsF32[idx]; }
+size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse) { return ((size_t)3 * t.kc * 4 * 32 * t.nt + (fuse ? (size_t)8 * t.nt * 64 : 0)) * 16; }
+bool tapgemm_f32_can_fuse(int idx) { return kCfgsF32[idx].rt == 1 && kCfgsF32[idx].nt == 5; }
+
+template <int RT, int NT, int KC>
+static hipError_t launch_f32(const TapGemmParams& p, bool fuse, hipStream_t s)
+{
+    dim3 grid((p.M + 128 * RT - 1) / (128 * RT), (p.Cout + 32 * NT - 1) / (32 * NT), p.ncls);
+    const TileCfg t{RT, NT, KC, 32};
+    if constexpr (RT == 1 && NT == 5) {
+        if (fuse) {
+            static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)attr;
+            pnn_launch(tapgemm_f32_kernel<RT, NT, KC, true>, grid, dim3(256), tapgemm_f32_lds_bytes(t, true), s, p);
+            return hipGetLastError();
+        }
+    }
+    if (fuse) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
+    pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false>, grid, dim3(256), tapgemm_f32_lds_bytes(t, false), s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStream_t s)
+{
+    if (p.M <= 0) return hipSuccess;
+    int i = 0;
+#define X(rt, nt, kc) if (idx == i++) return launch_f32<rt, nt, kc>(p, fuse, s);
+    PNN_F32_CFGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pnn

@@ -132,6 +132,15 @@ hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams
 int tapgemm_num_cfgs();
 TileCfg tapgemm_cfg(int idx);
 hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
+// Exact-f32 tap GEMM on v_mfma_f32_32x32x2_f32, one wave per SIMD (pnn_gemm_f32.hip): the canonical f32 summation order.
+// fuse: apply the output layer p.W2p (f32 pack, <= 64 outputs) to the activated tile, partial sums to p.part[column tile][M][64]
+int tapgemm_f32_num_cfgs();
+TileCfg tapgemm_f32_cfg(int idx);
+size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse);
+bool tapgemm_f32_can_fuse(int idx);
+hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStream_t s);
+// the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
+hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);
 
 // Cin == 1 forward convolution (first layer of each branch): direct VALU kernel.
 struct Conv1Params {

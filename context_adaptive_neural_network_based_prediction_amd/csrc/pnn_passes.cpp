@@ -14,7 +14,11 @@
 namespace pnn {
 namespace {
 
-int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s)
+// Exact-f32 launch.  `next` (optional): the net's output layer (<= 64 outputs) applied to this layer's activated tile inside the
+// launch (tapgemm_f32_kernel, 128 x 160 tile); `part` then receives the per-column-tile partial sums [tiles][M][64], *tiles_out
+// their count, and the caller finishes with launch_fuse_reduce.  Y / Yi must be null in that case.
+int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s,
+             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr)
 {
     TapGemmParams p = L.proto;
     p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
@@ -24,42 +28,105 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     const double xb = 4.0 * (double)nblocks * p.IH * p.IW * p.Cin;
     if (xb >= 2147483648.0) return fail(c, PNN_E_ARG, "activation tensor of %.0f bytes exceeds the 2 GiB descriptor bound", xb);
     p.x_bytes = (unsigned)xb;
-    const int cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
     static const bool debug = getenv("PNN_DEBUG") != nullptr;
-    if (debug) {
-        const TileCfg t = tapgemm_cfg(cfg);
-        fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> cfg %d {rt %d, nt %d, kc %d}\n", M, L.k_total, p.Cout, p.ncls,
-                cfg, t.rt, t.nt, t.kc);
-    }
     static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch timing, synchronous
+    const double flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
+    // ---- which kernel: tapgemm_f32_kernel (32x32x2 MFMA, the canonical f32 order) unless switched off, or, with canonical_order = 0,
+    // for launches too small to fill the chip with 128-row tiles (the split-K kernel spreads those over all CUs)
+    const bool one_tap = (L.k_total == (double)p.Cin);
+    const int cpt = p.Cin / 16;
+    bool f32k = c->opt_f32_kernel && c->opt_tile_cfg < 0;
+    if (f32k && !c->opt_canonical && !next && ((M + 127) / 128) * ((p.Cout + 31) / 32) * p.ncls < 192) f32k = false;
+    if (next && !f32k) return fail(c, PNN_E_ARG, "the fused output layer needs the tapgemm_f32 kernel");
+    int cfg = -1;
+    std::function<hipError_t(int)> launch;
+    if (f32k) {
+        if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
+        auto legal = [&](int i) {
+            const TileCfg t = tapgemm_f32_cfg(i);
+            return (one_tap || cpt % t.kc == 0) && (!next || tapgemm_f32_can_fuse(i));
+        };
+        launch = [&, p](int i) { return launch_tapgemm_f32(p, i, next != nullptr, s); };
+        cfg = choose_cfg_f32(c, M, p.Cout, p.ncls, p.Cin, L.k_total, next != nullptr);
+        if (cfg < 0) return fail(c, PNN_E_ARG, "no tapgemm_f32 tile fits a layer with %d-deep taps", p.Cin);
+        bool tune = c->opt_f32_cfg < 0 && (c->opt_autotune == 1 || (c->opt_autotune == 2 && flops >= 4.0e9));
+        if (tune) {                                   // never while the caller's stream is being captured into a hipGraph
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) tune = false;
+        }
+        if (tune) {
+            const void* key = (const void*)((const char*)&L + 8 + (next ? 1 : 0));   // offsets 0-7: the split-precision launches of this layer
+            float best_us = -1.f;
+            const int rule = cfg;
+            const int trc = tuned_cfg(c, key, M, tapgemm_f32_num_cfgs(), rule, legal, launch, s, &cfg, &best_us);
+            if (trc) return trc;
+            if (best_us >= 0.f && debug) {
+                const TileCfg tb = tapgemm_f32_cfg(cfg), th = tapgemm_f32_cfg(rule);
+                fprintf(stderr, "[pnn] f32 autotune M=%ld K=%.0f N=%d ncls=%d: best {%d,%d,%d} %.1f us (rule {%d,%d,%d})\n", M, L.k_total, p.Cout, p.ncls,
+                        tb.rt, tb.nt, tb.kc, best_us, th.rt, th.nt, th.kc);
+            }
+        }
+        if (tiles_out) { const TileCfg t = tapgemm_f32_cfg(cfg); *tiles_out = (int)((p.Cout + 32L * t.nt - 1) / (32L * t.nt)); }
+    } else {
+        cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
+        launch = [&, p](int i) { return launch_tapgemm(p, i, s); };
+    }
+    const TileCfg t = f32k ? tapgemm_f32_cfg(cfg) : tapgemm_cfg(cfg);
+    if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> %s cfg %d {rt %d, nt %d, kc %d}%s\n", M, L.k_total, p.Cout, p.ncls,
+                       f32k ? "f32" : "legacy", cfg, t.rt, t.nt, t.kc, next ? " + fused output layer" : "");
     if (profile || c->opt_time_launches) {
         pnn_ctx::LaunchRec r;
         HIPCHK(c, hipEventCreate(&r.e0));
         HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = tapgemm_cfg(cfg).rt == 0 ? 1 : 0;
-        r.flops = 2.0 * (double)M * L.k_total * p.Cout;
+        r.kind = (!f32k && t.rt == 0) ? 1 : 0;
+        r.flops = flops;
         const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
         g_launch_events = &ev;
-        const hipError_t le = launch_tapgemm(p, cfg, s);
+        const hipError_t le = launch(cfg);
         g_launch_events = nullptr;
         HIPCHK(c, le);
         if (profile) {
             HIPCHK(c, hipEventSynchronize(r.e1));
             float ms = 0.f;
             HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
-            const TileCfg t = tapgemm_cfg(cfg);
-            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
-                    p.Cout, p.ncls, cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+            fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d %s cfg=%d rt=%d nt=%d kc=%d mf=%d us=%.1f tflops=%.1f\n", M, L.k_total,
+                    p.Cout, p.ncls, f32k ? "f32" : "legacy", cfg, t.rt, t.nt, t.kc, t.mf, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
             (void)hipEventDestroy(r.e0);
             (void)hipEventDestroy(r.e1);
         } else {
             c->launch_recs.push_back(r);
         }
     } else {
-        HIPCHK(c, launch_tapgemm(p, cfg, s));
+        HIPCHK(c, launch(cfg));
+    }
+    static const bool diag = getenv("PNN_F32_DIAG") != nullptr;     // diagnostic library only (make diag): per-workgroup cycle stamps
+    if (diag && f32k) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (dev_reserve(c, c->stage_tbs, (size_t)16 << 20)) return PNN_E_NOMEM;
+        TapGemmParams q = p;
+        if (next) { q.W2p = next->d_w; q.Npad2 = next->proto.Npad; q.K2chunks = next->proto.chunk_begin[1]; q.part = part; }
+        q.Xlo = c->stage_tbs.p;
+        HIPCHK(c, hipMemset(c->stage_tbs.p, 0, (size_t)16 << 20));
+        for (int rep = 0; rep < 3; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg, next != nullptr, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls;
+        std::vector<unsigned long long> hbuf(8 * nwg);
+        HIPCHK(c, hipMemcpy(hbuf.data(), c->stage_tbs.p, hbuf.size() * 8, hipMemcpyDeviceToHost));
+        double sum[4] = {0, 0, 0, 0};
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (size_t i = 0; i < nwg; i++) {
+            for (int k = 0; k < 4; k++) sum[k] += (double)hbuf[8 * i + k];
+            r0 = std::min(r0, hbuf[8 * i + 4]); r1 = std::max(r1, hbuf[8 * i + 4] + hbuf[8 * i + 3]);
+        }
+        const double chunks = std::ceil(L.k_total / 16.0 / p.ncls / t.kc) * t.kc;
+        const double cyc = (sum[0] + sum[1] + sum[2]) / nwg, rt_ticks = sum[3] / nwg;
+        fprintf(stderr, "[pnn-f32diag] M=%ld K=%.0f N=%d {%d,%d,%d}%s: %zu WGs; wave 0 mean cycles: prologue %.0f  loop %.0f (MFMA work %.0f = %.3f)  epilogue %.0f;"
+                " lifetime %.1f us, in-kernel clock %.0f MHz; first start -> last end %.1f us\n", M, L.k_total, p.Cout, t.rt, t.nt, t.kc, next ? "+out" : "", nwg,
+                sum[0] / nwg, sum[1] / nwg, chunks * 8 * t.rt * t.nt * 64, chunks * 8 * t.rt * t.nt * 64 / (sum[1] / nwg), sum[2] / nwg, rt_ticks / 100.0,
+                cyc / (rt_ticks / 100.0), (double)(r1 - r0) / 100.0);
     }
     c->stat_gemm_launches++; c->stat_launches++;
-    c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    c->stat_gemm_flops += flops;
     return PNN_OK;
 }
 
@@ -446,6 +513,31 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
     }
     if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
     if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
+    // Output layer of the 4x4 / 8x8 nets (<= 64 outputs) on the exact-f32 path: summed in K segments of 160 hidden units +
+    // fuse_reduce at EVERY batch size -- inside the last hidden layer's launch (big batches: its 1200-wide activations never
+    // leave the registers of the waves that produce them; the 29 us / 14 %-of-peak launch of rounds 1-3 is gone) or from the
+    // stored activations by fc_out_f32_kernel, which repeats the fused kernel's MFMA chain operand for operand.
+    const int n_out = m->fc[3].proto.Cout;
+    if (c->opt_f32_kernel && c->opt_tile_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && (c->opt_canonical || nb >= 1024)) {
+        const int segs = (m->fc[3].proto.Cin + 159) / 160;
+        if ((rc = dev_reserve(c, c->ws[3], (size_t)segs * nb * 64 * 4))) return rc;
+        float* part = (float*)c->ws[3].p;
+        int tiles = 0;
+        if (c->opt_fuse_last && nb >= 1024) {
+            if ((rc = run_gemm(c, m->fc[2], P1, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
+        } else {
+            if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
+            TapGemmParams q = m->fc[3].proto;
+            q.X = P0; q.Wp = m->fc[3].d_w; q.part = part; q.M = (int)nb; q.x_bytes = (unsigned)(4.0 * (double)nb * q.Cin);
+            HIPCHK(c, launch_fc_out_f32(q, s, &tiles));
+            c->stat_gemm_launches++; c->stat_launches++;
+            c->stat_gemm_flops += 2.0 * (double)nb * m->fc[3].k_total * n_out;
+        }
+        if (tiles != segs) return fail(c, PNN_E_ARG, "output layer: %d K segments, expected %d", tiles, segs);
+        HIPCHK(c, launch_fuse_reduce(part, tiles, (int)nb, n_out, m->fc[3].d_bias, 1.f, c->mean, d_out, d_dst, s, take_done_signal(c)));
+        c->stat_launches++;
+        return PNN_OK;
+    }
     if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
     return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
 }

@@ -31,11 +31,15 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
     const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
     const long b = bx;
     const float* xb = p.X + b * p.IH * p.IW;
+    bool in_bad = false;                              // split path: an input element outside the f16 range (leaves_f16, pnn_device_common.h)
     for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
         const int r = idx / PW, c = idx - r * PW;
         const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
-        xs[idx] = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
+        const float v = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
+        in_bad |= leaves_f16(v);
+        xs[idx] = v;
     }
+    if (p.split && in_bad && p.range_flag) *p.range_flag = 1;
     const int npix = p.OH * p.OW;
     if (p.split) {
         // Split-precision path: the contraction over the taps on the matrix cores (FirstConv, pnn_device_common.h).  A wave

@@ -49,6 +49,44 @@ int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_t
     return i < 0 ? 0 : i;
 }
 
+// tapgemm_f32_kernel (32x32x2 MFMA, few waves with big tiles): the tile that finishes first by a list-scheduling estimate.  Every
+// tile runs its loop at 0.95-0.98 of the matrix rate (PNN_F32_DIAG stamps), so a launch costs its padded
+// MFMA work spread over 256 CUs, plus a tail of about half a workgroup unless the workgroups fit the chip exactly (FC 8x8 at batch
+// 4096 on the 128 x 160 tile: 256 workgroups, one per CU), plus the start-up / epilogue of a workgroup -- which co-resident
+// workgroups (R per CU, by LDS and registers) hide behind each other's MFMAs.  Two row tiles per wave measured 20-25 % slower than
+// the same area as one (twice the activation loads per MFMA, one resident workgroup).  Big launches are autotuned on top of this
+// (run_gemm); all tiles give the same bits.  -1: no legal tile.
+int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused)
+{
+    const int cpt = cin / 16;
+    const bool one_tap = (k_total == (double)cin);
+    if (c->opt_f32_cfg >= 0 && c->opt_f32_cfg < tapgemm_f32_num_cfgs()) {
+        const TileCfg t = tapgemm_f32_cfg((int)c->opt_f32_cfg);
+        if ((one_tap || cpt % t.kc == 0) && (!fused || tapgemm_f32_can_fuse((int)c->opt_f32_cfg))) return (int)c->opt_f32_cfg;
+    }
+    int best = -1;
+    double best_cost = 1e300;
+    for (int i = 0; i < tapgemm_f32_num_cfgs(); i++) {
+        const TileCfg t = tapgemm_f32_cfg(i);
+        if (fused && !tapgemm_f32_can_fuse(i)) continue;
+        if (!one_tap && cpt % t.kc) continue;
+        const long bm = 128L * t.rt, bn = 32L * t.nt;
+        const double wgs = (double)((M + bm - 1) / bm) * (double)((cout + bn - 1) / bn) * ncls;
+        const double regs = 16.0 * t.rt * t.nt + 16.0 * t.nt + 16.0 * t.kc * t.rt + 40.0;
+        const int res = (int)std::max(1.0, std::min(std::min(4.0, std::floor(512.0 / regs)), std::floor(160.0 * 1024 / (double)tapgemm_f32_lds_bytes(t, fused))));
+        const double chunks = std::ceil(k_total / 16.0 / ncls / t.kc) * t.kc;
+        const double mfma = chunks * 8.0 * t.rt * t.nt * 64.0;
+        const double fixed = 5000.0 + 2500.0 * t.rt * t.nt;
+        const bool exact = std::fmod(wgs, 256.0) == 0.0 && wgs / 256.0 <= res;
+        double cost = wgs * mfma / 256.0 + (exact ? 0.0 : 0.6 * mfma) + fixed * (res >= 2 && wgs > 256.0 ? 0.4 : 1.0);
+        if (wgs < 256.0) cost = mfma + fixed;                         // under-filled chip: the launch lasts one workgroup
+        if (t.rt == 2) cost *= 1.2;
+        cost *= 1.0 + 0.01 / (t.rt * t.nt) + (t.kc == 2 ? 0.005 : 0.0);   // ties: the bigger wave tile, the longer stage
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
 // convimg_sp_kernel: how many images one workgroup of tile `t` stages for this layer (0 = tile cannot run the layer).
 int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap)
 {

@@ -479,6 +479,43 @@ def test_trained_checkpoints_through_the_split_kernels(pnn, oracle, precision, w
         net2.close()
 
 
+@pytest.mark.parametrize("w,n", [(16, 200), (16, 2), (8, 300), (32, 40)])
+def test_f16_range_guard_on_the_raw_context(pnn, oracle, precision, w, n):
+    """The first convolution of a branch splits the RAW context into f16 pairs in registers (FirstConv): a finite input element
+    of 1e5 would become hi = inf, lo = -inf and a NaN that the output-side guard's fmaxf drops.  The staging loops check the
+    inputs (leaves_f16): host calls repeat the pass on the exact-f32 kernels and still match the oracle, device calls report
+    PNN_E_RANGE -- at batch (image kernel with the fused first convolution) and for a handful (conv_cin1 kernels)."""
+    import torch
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, False, 91, out_gain=util.out_gain(w, False)).copy()
+    specs = wts.tensor_specs(w, False)
+    sizes = [int(np.prod(sh)) for _, sh, _ in specs]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    above, left = util.make_contexts(w, n, 92)
+    above[n // 2, 1, 2] = 1.0e5                                      # one finite, huge element in ONE block's above portion
+    left[n - 1, 3, 1] = -2.0e5                                       # ... and one in another block's left portion
+    params[offs[-3]:offs[-2]] /= 200.0                               # keep that block's prediction finite-sized
+    net = pnn.PredictionNeuralNetwork(n, w, False, params=params)
+    net.set_option("canonical_order", 1)
+    want = oracle.conv_forward(params, w, above, left)
+    got = net.predict(above, left)
+    fallbacks = ctypes.c_long()
+    assert L.pnn_check_range(net.ctx, None, ctypes.byref(fallbacks)) == 0
+    assert fallbacks.value == (1 if precision == "split_f16" else 0)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[..., 0], want, rtol=2e-6, atol=FLOAT_ATOL * 4)
+    ts = [torch.from_numpy(np.ascontiguousarray(a)).cuda()[..., None] for a in (above, left)]
+    out = net.predict(*ts)
+    rc = L.pnn_check_range(net.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None)
+    if precision == "split_f16":
+        assert rc == -6 and b"f16 range" in L.pnn_last_error(net.ctx)
+    else:
+        assert rc == 0
+        np.testing.assert_allclose(out.cpu().numpy()[..., 0], want, rtol=2e-6, atol=FLOAT_ATOL * 4)
+    net.close()
+
+
 @pytest.mark.parametrize("w,is_fc,n,layer", [(8, True, 600, 0), (8, True, 1, 0), (16, False, 90, 0), (16, False, 90, 1), (16, False, 1, 1)])
 def test_f16_range_guard(pnn, oracle, precision, w, is_fc, n, layer):
     """Split precision carries activations as f16 pairs: |v| >= 65504 must never turn into a silent NaN -> 255.  First-layer
@@ -956,9 +993,9 @@ def test_range_fallback_touches_only_the_overflowing_block(pnn, oracle, precisio
 def test_one_summation_order_at_every_batch_size(pnn, precision, w, is_fc, big):
     """canonical_order: a block's float prediction is the same bit pattern whether it is predicted alone (tapgemm_small_kernel,
     one wave per 32 x 32 tile, K-segment output layer), in a handful, in a mid-size pass or in a big batch (ring / sp /
-    convimg kernels, fused output layer) -- what an encoder behind the batching service and a stand-alone decoder need."""
-    if precision != "split_f16":
-        pytest.skip("split-precision kernels only")
+    convimg kernels, fused output layer) -- what an encoder behind the batching service and a stand-alone decoder need.
+    On the exact-f32 arithmetic too: every tile of tapgemm_f32_kernel sums in one order, the FC output layer is summed in the
+    fused kernel's K segments at every batch size (fc_out_f32_kernel below 1024 blocks)."""
     params = util.make_params(w, is_fc, 111, out_gain=util.out_gain(w, is_fc))
     above, left = util.make_contexts(w, big, 112)
     net = pnn.PredictionNeuralNetwork(big, w, is_fc, params=params)
