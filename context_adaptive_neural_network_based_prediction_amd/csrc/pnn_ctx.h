@@ -106,6 +106,7 @@ struct pnn_ctx {
     // exact-f32 passes: 1 (default) = tapgemm_f32_kernel (32x32x2 MFMA, one wave per SIMD; FC nets: output layer fused into the last
     // hidden layer's launch); 0 = the round-1 kernels (tapgemm_kernel on 16x16x4 MFMA, tapgemm_splitk_kernel for small M)
     long opt_f32_kernel = 1;
+    long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel

@@ -32,6 +32,7 @@
 #include "pnn_device_common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace pnn {
@@ -82,11 +83,49 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     unsigned long long dq1 = 0, dq2 = 0;
 #endif
 
+    const int SP = p.SH * p.SW;
+    const int cpt = p.Cin >> 4;                      // 16-deep chunks per tap (a multiple of KC, or one tap)
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    // Position-major tiles (p.pm_groups > 0, convolutions at batch; launch_f32 decides with the ring kernel's planner,
+    // pnn_gemm_ring.hip): the tile's BM rows are BM BLOCKS at ONE position (pmi, pmj) of the SH x SW grid, first block mblk.  A tap
+    // then lies inside the image for every row or for none, and the taps that only meet SAME padding (17 % of the 16x16 net's
+    // multiply-adds) are skipped -- no loads, no MFMAs.  Their products are exact zeros: every output keeps its bits.
+    // tmask = this class's taps that stay (all of them otherwise).
+    const int pmg = p.pm_groups;
+    int pmi = 0, pmj = 0, mblk = 0;
+    unsigned tmask = t1 - t0 >= 32 ? 0xffffffffu : (1u << (t1 - t0)) - 1u;
+    if (pmg) {
+        // launch order: chunks of 8 block groups; within a chunk rank by position rank, the 8 groups side by side -- workgroups
+        // i, i + 8, ... run on one XCD, so each XCD walks the positions of ONE group at a time and its L2 keeps that group's maps
+        const int gc = blockIdx.x / (SP * 8), r = blockIdx.x - gc * (SP * 8);
+        const int c = gc < (pmg >> 3) ? 8 : (pmg & 7);
+        const int pr = r / c;
+        const int pos = SP <= 64 ? (int)((p.pos_order[pr >> 2] >> ((pr & 3) * 8)) & 0xffu) : pr;
+        pmi = pos / p.SW;
+        pmj = pos - pmi * p.SW;
+        mblk = (gc * 8 + r - pr * c) * BM;
+        unsigned m = 0;
+        for (int t = t0; t < t1; t++) {
+            const int tp = p.tap[t];
+            const int iy = pmi * p.a + (tp >> 16), ix = pmj * p.a + (int)(short)(tp & 0xffff);
+            if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) m |= 1u << (t - t0);
+        }
+        tmask = m ? m : 1u;                          // no tap inside: one of them fetches zeros
+    }
+    auto next_tap = [&](int t) {                     // the next tap that stays after t (class-relative), or t itself at the end
+        const unsigned rest = tmask & ~((2u << t) - 1u);
+        return rest ? (int)__builtin_ctz(rest) : t;
+    };
     int pb[RT], pi[RT], pj[RT];
     bool mv[RT];
-    const int SP = p.SH * p.SW;
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
+        const int row = wave * (32 * RT) + rt * 32 + l31;
+        if (pmg) {
+            mv[rt] = mblk + row < p.nblk;
+            pb[rt] = mv[rt] ? mblk + row : 0; pi[rt] = pmi; pj[rt] = pmj;
+            continue;
+        }
         const int mg = m0 + rt * 32 + l31;
         mv[rt] = mg < p.M;
         const int mc = mv[rt] ? mg : 0;
@@ -99,17 +138,23 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
             pj[rt] = r - pi[rt] * p.SW;
         }
     }
-
-    const int cpt = p.Cin >> 4;                      // 16-deep chunks per tap (a multiple of KC, or one tap)
-    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
-    const int nchunks = (t1 - t0) * cpt;
+    const int nchunks = __builtin_popcount(tmask) * cpt;
     const int nstages = (nchunks + KC - 1) / KC;     // the packed weights are zero-padded to whole stages (kChunkPad)
 
     // ---- weights: this lane's pieces of a stage (LDS-DMA: lane-linear destination, per-lane source) ------------------------
     const unsigned wbytes = (unsigned)p.chunk_begin[p.ncls] * 4u * (unsigned)p.Npad * 16u;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, wbytes, 0x00020000);
     const unsigned wcls = (unsigned)p.chunk_begin[cls] * 4u * (unsigned)p.Npad * 16u;
-    const unsigned wstage = (unsigned)(KC * 4) * (unsigned)p.Npad * 16u;      // bytes per stage
+    const unsigned wchunk = 4u * (unsigned)p.Npad * 16u;                      // bytes per packed chunk
+    // cursor of the next stage to be fetched: tap (class-relative) and chunk within it
+    int dt = (int)__builtin_ctz(tmask), dcc = 0;
+    auto advance_d = [&]() {
+        dcc += KC;
+        if (dcc >= cpt) {
+            const int n = next_tap(dt);
+            if (n != dt) { dt = n; dcc = 0; } else dcc -= KC;       // past the end: the last stage again (harmless, no exec-masked code)
+        }
+    };
     unsigned bsrc[NPW];
 #pragma unroll
     for (int ii = 0; ii < NPW; ii++) {
@@ -119,8 +164,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
         const int q = ee / BN, nn = ee - q * BN;
         bsrc[ii] = (unsigned)(((j * 4 + q) * p.Npad + n0 + nn) << 4) + wcls;
     }
-    auto dma_b = [&](int stage, int buf, int ii) {   // instruction ii of this wave
-        dma16(wrsrc, bsrc[ii], (unsigned)stage * wstage, lds + buf * SE + 64 * (wave + 4 * ii));
+    auto dma_b = [&](int buf, int ii) {              // instruction ii of this wave, of the stage under the cursor
+        dma16(wrsrc, bsrc[ii], (unsigned)(dt * cpt + dcc) * wchunk, lds + buf * SE + 64 * (wave + 4 * ii));
     };
 
     // ---- activations: buffer-descriptor loads, out-of-image taps / rows past M read zeros, per-tap byte offsets ------------
@@ -137,8 +182,9 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
         }
     };
     // cursor of the NEXT stage to be loaded
-    int lt = t0, lcc = 0, ltp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
-    tap_setup(p.tap[t0]);
+    int lt = (int)__builtin_ctz(tmask), lcc = 0;
+    tap_setup(p.tap[t0 + lt]);
+    int ltp_next = p.tap[t0 + next_tap(lt)];          // the next tap's word, fetched a whole tap early
     auto load_a_chunk = [&](int j, f32x4 (&dst)[KC][RT][2]) {
         const int cj = lcc + j < cpt ? lcc + j : cpt - 1;          // padding chunk: zero weights, any finite data will do
 #pragma unroll
@@ -149,11 +195,14 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     };
     auto advance_a = [&]() {                         // to the stage after the one just loaded (wave-uniform)
         lcc += KC;
-        if (lcc >= cpt && lt + 1 < t1) {
-            lcc = 0;
-            ++lt;
-            tap_setup(ltp_next);
-            ltp_next = p.tap[lt + 1 < t1 ? lt + 1 : lt];
+        if (lcc >= cpt) {
+            const int n = next_tap(lt);
+            if (n != lt) {
+                lcc = 0;
+                lt = n;
+                tap_setup(ltp_next);
+                ltp_next = p.tap[t0 + next_tap(lt)];
+            }
         }
     };
 
@@ -174,13 +223,14 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     f32x4 a0[KC][RT][2], a1[KC][RT][2];              // activations of the even / odd stages
     f32x4 wf0[NT][2], wf1[NT][2];                    // weight fragments of the even / odd chunks
 #pragma unroll
-    for (int ii = 0; ii < NPW; ii++) dma_b(0, 0, ii);
+    for (int ii = 0; ii < NPW; ii++) dma_b(0, ii);
+    advance_d();
 #pragma unroll
     for (int j = 0; j < KC; j++) load_a_chunk(j, a0);
     advance_a();
-    const int s1 = nstages > 1 ? 1 : 0;
 #pragma unroll
-    for (int ii = 0; ii < NPW; ii++) dma_b(s1, 1, ii);
+    for (int ii = 0; ii < NPW; ii++) dma_b(1, ii);
+    advance_d();
     if (FUSE) {
         // rows n/4 in [n0/4, n0/4 + BN/4) of the output layer's pack [k/4][Npad2][4 floats]: its first 64 columns, 1 KiB per row;
         // rows past its K read zeros (descriptor bound)
@@ -195,9 +245,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     // ---- one stage: KC chunks of 8 k-steps x NT x RT MFMAs; after each MFMA at most ONE memory instruction -------------------
     // chunk j carries: the fragment reads of chunk j+1 (the last chunk: the next stage's first, from its buffer), the
     // activation loads of chunk j of stage s+1, and its share of the LDS-DMA of stage s+2 into buffer (s+2) % 3.
-    auto stage = [&](int s, int buf, f32x4 (&acur)[KC][RT][2], f32x4 (&anxt)[KC][RT][2]) {
+    auto stage = [&](int buf, f32x4 (&acur)[KC][RT][2], f32x4 (&anxt)[KC][RT][2]) {
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;      // (s+1) % 3, (s+2) % 3
-        const int s2 = s + 2 < nstages ? s + 2 : nstages - 1;       // past the end: the last stage again (harmless, no exec-masked code)
 #pragma unroll
         for (int j = 0; j < KC; j++) {
             constexpr int kLast = KC - 1;
@@ -233,25 +282,26 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
                                 const int cj = lcc + j < cpt ? lcc + j : cpt - 1;   // padding chunk: zero weights, any finite data will do
                                 anxt[j][ar][ah] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[ar] + 16u * ah, cj << 6, 0));
                             } else {
-                                dma_b(s2, buf2, d0 + (k - 2 * NT - 2 * RT));
+                                dma_b(buf2, d0 + (k - 2 * NT - 2 * RT));
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
         }
         advance_a();
+        advance_d();
     };
 #ifdef PNN_F32_DIAG
     dq1 = __builtin_amdgcn_s_memtime();
 #endif
     int s = 0, buf = 0;
     for (; s + 1 < nstages; s += 2) {
-        stage(s, buf, a0, a1);
+        stage(buf, a0, a1);
         buf = buf == 2 ? 0 : buf + 1;
-        stage(s + 1, buf, a1, a0);
+        stage(buf, a1, a0);
         buf = buf == 2 ? 0 : buf + 1;
     }
-    if (s < nstages) stage(s, buf, a0, a1);
+    if (s < nstages) stage(buf, a0, a1);
 #ifdef PNN_F32_DIAG
     dq2 = __builtin_amdgcn_s_memtime();
     auto diag_out = [&]() {
@@ -416,10 +466,27 @@ size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse) { return ((size_t)3 * 
 bool tapgemm_f32_can_fuse(int idx) { return kCfgsF32[idx].rt == 1 && kCfgsF32[idx].nt == 5; }
 
 template <int RT, int NT, int KC>
-static hipError_t launch_f32(const TapGemmParams& p, bool fuse, hipStream_t s)
+static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
 {
-    dim3 grid((p.M + 128 * RT - 1) / (128 * RT), (p.Cout + 32 * NT - 1) / (32 * NT), p.ncls);
+    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls);
     const TileCfg t{RT, NT, KC, 32};
+    TapGemmParams p = p0;
+    p.pm_groups = 0;
+    // (not with a last block group that is mostly padding rows: 64 blocks of the 64x64 net in 128-row tiles ran 3 % slower)
+    const long nblk = p0.M / (p0.SH * p0.SW), bm = 128 * RT;
+    if (!fuse && p0.pm_groups >= 0 && p0.SH * p0.SW > 1 && (p0.pm_groups == 1 || (nblk + bm - 1) / bm * bm * 100 <= nblk * 115)) {
+        TapGemmParams q = p0;
+        q.W2p = nullptr;                              // (the planner reads the fused-layer field of the ring kernel's launches)
+        const PmPlan& plan = position_major_plan(q, 128 * RT, 32 * NT, KC, tapgemm_f32_lds_bytes(t, false));
+        if (plan.use) {
+            p.pm_groups = plan.groups;
+            p.nblk = p0.M / (p0.SH * p0.SW);
+            for (int i = 0; i < 16; i++) p.pos_order[i] = plan.order[i];
+            grid.x = (unsigned)(plan.groups * p0.SH * p0.SW);
+            static const bool debug = getenv("PNN_DEBUG") != nullptr;
+            if (debug) fprintf(stderr, "[pnn] f32 %dx%d: position-major tiles, %d block groups x %d positions\n", 128 * RT, 32 * NT, plan.groups, p0.SH * p0.SW);
+        }
+    }
     if constexpr (RT == 1 && NT == 5) {
         if (fuse) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

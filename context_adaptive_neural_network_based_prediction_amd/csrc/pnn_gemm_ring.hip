@@ -789,7 +789,6 @@ hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, cons
 // p.pm_groups on entry: -1 = never (option ring_pm = 0), 1 = whenever possible (ring_pm = 2, tests), 0 = by this model.
 namespace {
 constexpr double kWgFixed = 10.0;
-struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; };
 
 double list_schedule(const std::vector<double>& cost, int slots)
 {
@@ -854,6 +853,8 @@ PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_
     return plan;
 }
 
+}  // namespace
+
 // the plan of a launch shape is computed once per thread (a few microseconds of host time otherwise, per launch)
 const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds)
 {
@@ -869,7 +870,6 @@ const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC
     }
     return it->second;
 }
-}  // namespace
 
 template <int RT, int NT, int KC, int WM, int D, bool FUSE = false>
 static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)

@@ -111,6 +111,12 @@ bool tapgemm_ring_can_fuse(int idx);
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
                               hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)
+// Position-major tiles (a workgroup's BM rows = BM blocks at ONE position of the SH x SW grid: the taps that only meet padding are
+// skipped): whether a launch of tile BM x BN, KC chunks per stage, `lds` bytes per workgroup takes them, in how many block
+// groups, and the position order (pnn_gemm_ring.hip; shared by the ring kernel and tapgemm_f32_kernel).  p.pm_groups on entry:
+// -1 never, 1 whenever possible, 0 by the planner's list-scheduling model.
+struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; };
+const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds);
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
@@ -150,6 +156,10 @@ struct Conv1Params {
     int band_rows;   // output rows per workgroup (set by the launcher)
     int* range_flag; // split output only: raised when a value leaves the f16 range
     const float* Wsp; float out_scale; int npad;   // split output: the taps x channels matrix in the split pack of the GEMM layers, its inverse pre-scale, its Npad
+    // X == NULL: the context gather fused in (extraction_context.cpp:3-208) -- image b's raw context comes straight from the picture
+    // plane through TB descriptor tbs[b] (branch 0: the above portion w x 3w, 1: the left portion 2w x w; unit-pixel availability
+    // units), Pel (pel_bytes) -> float, minus mean: the values gather_f32x4_kernel would have written
+    const void* plane; const TbDev* tbs; int pel_bytes, unit, w, branch; float mean;
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s);   // both branches in one launch (same batch, same kernel size)

@@ -40,6 +40,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     if (next && !f32k) return fail(c, PNN_E_ARG, "the fused output layer needs the tapgemm_f32 kernel");
     int cfg = -1;
     std::function<hipError_t(int)> launch;
+    p.pm_groups = c->opt_ring_pm == 0 ? -1 : c->opt_ring_pm == 2 ? 1 : 0;   // position-major tiles: never / whenever possible / by the planner's model (launch_tapgemm_f32)
     if (f32k) {
         if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
         auto legal = [&](int i) {
@@ -407,7 +408,9 @@ bool branches_overlap_at_batch(const pnn_ctx* c, const Model* m, long nb)
     static const bool profile = getenv("PNN_PROFILE") != nullptr;
     if (!c->opt_branch_streams || m->is_fc || profile || c->opt_time_launches || c->opt_sp_cfg >= 0) return false;
     if (m->branch[0].size() < 2 || m->branch[1].size() < 2) return false;
-    return nb * m->width * m->width >= 65536 && pass_uses_split(c, m, nb);
+    // (exact-f32 passes too, option f32_kernel: their launches end with a tail of big workgroups -- one or two per CU -- that the other
+    // branch's launches fill)
+    return nb * m->width * m->width >= 65536 && (pass_uses_split(c, m, nb) || (c->opt_precision == 0 && c->opt_f32_kernel && c->opt_tile_cfg < 0 && c->opt_f32_overlap));
 }
 
 int ensure_ws(pnn_ctx* c, const Model* m, long nb)
@@ -554,7 +557,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     const bool side_ok = c->side_stream && c->ws[4].bytes >= (size_t)nb * m->pmax * 4 && c->ws[5].bytes >= (size_t)nb * m->pmax * 4;   // ensure_ws sized them for this pass's chunk
     bool par = branches_overlap(c, m, nb) && side_ok;
     const auto shape = std::make_pair((const void*)m, nb);
-    const bool batch_overlap = !par && sp && side_ok && branches_overlap_at_batch(c, m, nb);
+    const bool batch_overlap = !par && side_ok && branches_overlap_at_batch(c, m, nb);
     if (batch_overlap) {                              // see branches_overlap_at_batch: once a one-stream pass of this shape needed no tuning sweep
         auto it = c->overlap_ready.find(shape);
         par = it != c->overlap_ready.end() && it->second == c->tune_gen;
@@ -621,6 +624,10 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         f.B = (int)nb; f.range_flag = c->h_range;
         f.Y = nl == 0 ? F[br] : PB[br][0];
         f.split = (sp && nl > 0) ? 1 : 0;
+        if (!f.X && !sp && c->lazy.plane) {           // exact-f32 pass straight from the picture plane (pnn_predict_tbs_device decided so)
+            f.plane = c->lazy.plane; f.tbs = reinterpret_cast<const TbDev*>(c->lazy.tbs); f.pel_bytes = c->lazy.pel_bytes; f.unit = c->lazy.unit;
+            f.w = m->width; f.branch = br; f.mean = c->mean;
+        }
         const bool delegate = sp && nl > 0;           // run_gemm_sp of the next layer launches or absorbs this convolution
         if (!delegate) {
             HIPCHK(c, launch_conv_cin1(f, st));
@@ -689,9 +696,10 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
 }  // namespace
 
 // Would a pass of nb blocks through convolutional model m fuse BOTH branches' first convolutions into the image kernel (so that
-// the context gather can be fused in too)?  Launches nothing.
+// the context gather can be fused in too)?  Launches nothing.  Exact-f32 passes: conv_cin1_kernel reads the plane itself.
 bool conv_pass_fuses_first(pnn_ctx* c, Model* m, long nb)
 {
+    if (!m->is_fc && c->opt_fuse_gather && !pass_uses_split(c, m, nb)) return true;
     if (m->is_fc || !c->opt_fuse_gather || !pass_uses_split(c, m, nb) || c->opt_time_launches || getenv("PNN_PROFILE")) return false;
     for (int br = 0; br < 2; br++) {
         if (m->branch[br].empty()) return false;

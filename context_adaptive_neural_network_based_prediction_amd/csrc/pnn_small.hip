@@ -30,14 +30,39 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
     const int oy1 = oy0 + p.band_rows < p.OH ? oy0 + p.band_rows : p.OH;
     const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
     const long b = bx;
-    const float* xb = p.X + b * p.IH * p.IW;
     bool in_bad = false;                              // split path: an input element outside the f16 range (leaves_f16, pnn_device_common.h)
+    if (!p.X) {
+        // the gather fused in: straight from the picture plane through this block's TB descriptor
+        const TbDev d = p.tbs[b];
+        const int w0 = p.w;
+        for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+            const int r = idx / PW, c = idx - r * PW;
+            const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+                bool ok;
+                long off;
+                if (p.branch == 0) {
+                    ok = ix < w0 || ((d.above_mask >> ((ix - w0) / p.unit)) & 1u);
+                    off = d.origin + (long)(iy - w0) * d.stride + (ix - w0);
+                } else {
+                    ok = iy < d.left_units * p.unit;
+                    off = d.origin + (long)iy * d.stride + (ix - w0);
+                }
+                if (ok) v = (p.pel_bytes == 4 ? (float)reinterpret_cast<const int32_t*>(p.plane)[off] : (float)reinterpret_cast<const uint8_t*>(p.plane)[off]) - p.mean;
+            }
+            in_bad |= leaves_f16(v);
+            xs[idx] = v;
+        }
+    } else {
+    const float* xb = p.X + b * p.IH * p.IW;
     for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
         const int r = idx / PW, c = idx - r * PW;
         const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
         const float v = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
         in_bad |= leaves_f16(v);
         xs[idx] = v;
+    }
     }
     if (p.split && in_bad && p.range_flag) *p.range_flag = 1;
     const int npix = p.OH * p.OW;

@@ -340,6 +340,35 @@ def test_ring_position_major_tiles_bit_identical(pnn, oracle, precision, w, n):
     net.close()
 
 
+@pytest.mark.parametrize("w,is_fc,n", [(16, False, 384), (16, False, 300), (8, False, 1024), (32, False, 130), (8, True, 1500), (4, True, 2048), (16, False, 3)])
+def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, is_fc, n):
+    """The exact-f32 path (tapgemm_f32_kernel): every tile configuration gives the same float bits (one per-output summation order),
+    with block-major tiles and with position-major ones (which skip the taps that only meet SAME padding: exact zeros) -- whole
+    block groups, ragged ones, stride-2 layers, the four classes of the stride-2 transposed convolutions; FC nets with the
+    output layer fused into the last hidden layer's launch (n >= 1024) or from stored activations."""
+    if precision != "f32":
+        pytest.skip("exact-f32 kernels only")
+    params = util.make_params(w, is_fc, 177, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 178)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    net.set_option("autotune", 0)
+    run = (lambda: net.predict(util.flatten_fc(above, left))) if is_fc else (lambda: net.predict(above, left))
+    net.set_option("ring_pm", 0)
+    want = run()
+    for cfg in range(-1, 14):
+        net.set_option("f32_cfg", cfg)
+        for mode in (0, 2, 1):
+            net.set_option("ring_pm", mode)
+            assert np.array_equal(run(), want), "tapgemm_f32 configuration %d, position-major mode %d changes the result" % (cfg, mode)
+    net.set_option("f32_cfg", -1)
+    net.set_option("fuse_last", 0)                                   # FC: the output layer from stored activations
+    assert np.array_equal(run(), want)
+    m = min(n, 48)
+    ref = oracle.fc_forward(params, w, util.flatten_fc(above[:m], left[:m])) if is_fc else oracle.conv_forward(params, w, above[:m], left[:m])
+    np.testing.assert_allclose(want[:m, ..., 0], ref, rtol=0, atol=FLOAT_ATOL)
+    net.close()
+
+
 @pytest.mark.parametrize("w,is_fc", [(8, True), (16, False)])
 def test_prediction_cache_for_single_block_calls(pnn, w, is_fc):
     """`cache_mb`: a repeated single-block call (HM's RDO re-evaluates the same TB) is answered from the cache with the
