@@ -434,10 +434,12 @@ def self_launch(args):
     raise SystemExit(r.returncode if r.returncode or line else 1)
 
 
-def hm_campaigns(which, devices, quick=False, pictures="synthetic"):
+def hm_campaigns(which, devices, quick=False, pictures="synthetic", cpu_leg=True):
     """BASELINE.json configs[3] / configs[4] at their stated picture counts through the reference's own HM binaries
-    (tools/hm/campaign.py; built by __graft_entry__.build() where /root/reference exists, they travel with the tree).
-    Returns {name: record}; a missing binary or a failed run is recorded, never raised -- the kernel line must survive."""
+    (tools/hm/campaign.py; built by __graft_entry__.build() where /root/reference exists, they travel with the tree), and -- the
+    cpu_baseline leg -- the first pictures of the same campaign with the PNN answered on HOST CORES (the reference's route: inference
+    on the CPU; here the CPU oracle behind the same batching service, tools/hm/cpu_pnn_service.py), beside the same pictures on the GPU.
+    Returns {name: record}; a missing binary or a failed run is recorded, never raised."""
     import shutil
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools", "hm"))
@@ -451,7 +453,22 @@ def hm_campaigns(which, devices, quick=False, pictures="synthetic"):
     for name in which:
         work = tempfile.mkdtemp(prefix="pnn_bench_hm_")
         try:
-            out[name] = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300, picture_set=pictures)   # per codec process: a wedged service must not hold the line for long
+            rec = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300, picture_set=pictures)   # per codec process: a wedged service must not hold the line for long
+            if cpu_leg:
+                k = 2
+                small = campaign.run_campaign(name, os.path.join(work, "gpu_small"), devices[:1], pictures=k, timeout=300, picture_set=pictures, yardstick=False)
+                cpu = campaign.run_campaign(name, os.path.join(work, "cpu"), devices[:1], pictures=k, timeout=900, picture_set=pictures, yardstick=False, backend="cpu")
+                keep = ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "enc_wall_s", "dec_wall_s", "every_decode_equals_its_encoder", "bits_total", "service")
+                rec["cpu_pnn"] = {
+                    "what": "the first %d pictures with the PNN answered on host cores (CPU oracle, OpenMP, behind the same batching service) and, beside it, "
+                            "the same %d pictures on one MI355X; both with %d encodes in flight" % (k, k, k),
+                    "cores": min(8, os.cpu_count() or 8), "host_cores": os.cpu_count(),
+                    "cpu": {kk: cpu.get(kk) for kk in keep}, "gpu_same_sample": {kk: small.get(kk) for kk in keep},
+                    "pictures_per_s": cpu.get("pictures_per_s"), "gpu_same_sample_pictures_per_s": small.get("pictures_per_s"),
+                    "gpu_over_cpu_wall": round(cpu["wall_s_all_encodes_and_decodes"] / small["wall_s_all_encodes_and_decodes"], 2),
+                    "same_bits": cpu.get("bits_total") == small.get("bits_total"),
+                    "sample": "first %d pictures of the campaign, encode + decode" % k}
+            out[name] = rec
         except Exception as e:                        # noqa: BLE001
             out[name] = {"error": repr(e)[:2000]}
         finally:
@@ -566,7 +583,7 @@ def main():
         # configs[3] / configs[4]: whole encodes through the reference's HM binaries, one batching service per device; this
         # process never touches the GPU (the services and the codecs are child processes)
         name = args.workload[3:]
-        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick, args.hm_pictures)
+        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick, args.hm_pictures, cpu_leg=not args.no_cpu_baseline)
         r = rec.get(name, rec)
         ok = "error" not in r
         with open(args.detail_file, "w") as f:
@@ -578,11 +595,13 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[1], "data": "synthetic",
             "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign", "pictures": r.get("pictures"),
                        "picture_set": args.hm_pictures, "parallelism": "independent encodes dealt over one batching service per device, no collective"},
-            "hm": {k: r.get(k) for k in ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular", "every_decode_equals_its_encoder",
-                                         "service_start_s", "error")} if isinstance(r, dict) else None,
+            "hm": {k: r.get(k) for k in ("variant", "pictures", "picture_set", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
+                                         "every_decode_equals_its_encoder", "service_start_s", "bits_total", "error")} if isinstance(r, dict) else None,
             "roofline": None,
             "cpu_baseline": {"value": cpu_pnn.get("pictures_per_s"), "unit": "pictures/s", "cores": cpu_pnn.get("cores"), "kind": "port",
-                             "sample": cpu_pnn.get("sample"), "hm_16_15_regular": r.get("yardstick_hm_16_15_regular")} if ok else None,
+                             "sample": cpu_pnn.get("sample"), "gpu_same_sample": cpu_pnn.get("gpu_same_sample_pictures_per_s"),
+                             "gpu_over_cpu_wall": cpu_pnn.get("gpu_over_cpu_wall"), "same_bits": cpu_pnn.get("same_bits"),
+                             "hm_16_15_regular_pictures_per_s": (r.get("yardstick_hm_16_15_regular") or {}).get("pictures_per_s")} if ok else None,
             "detail_file": os.path.basename(args.detail_file)}, separators=(",", ":")))
         raise SystemExit(0 if ok else 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -69,6 +69,7 @@ SIGNATURES = {
 }
 
 _lib = None
+SKIP_TORCH = False      # set by processes that never touch torch (the batching service): skips its import, seconds on a cold box
 
 
 def lib():
@@ -80,10 +81,11 @@ def lib():
         # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both own
         # the GPU. Importing torch first makes the loader resolve our DT_NEEDED libamdhip64.so.7 to the
         # copy already mapped, so the library and torch share one runtime (streams, device pointers).
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        if not SKIP_TORCH:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(SERVICE_SIGNATURES.items()):
             fn = getattr(L, name)

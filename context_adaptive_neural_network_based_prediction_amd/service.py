@@ -125,7 +125,10 @@ def main():
                          "while a batch is on the GPU form the next one by themselves")
     args = ap.parse_args()
     import signal
+    import sys
     import time
+    t_main = time.time()
+    _lib.SKIP_TORCH = True                            # this process owns a GPU context through libpnn_hip.so alone
     # five contexts (one per width, each with its own worker thread and stream) inside the C server; a block gets the same
     # prediction whatever batch it travels in (one summation order at every batch size is the library's default)
     import os
@@ -147,6 +150,8 @@ def main():
     if srv.rc is not None or not os.path.exists(args.socket):
         raise SystemExit("pnn service: cannot start (%s): %s" % (srv.rc, (_lib.lib().pnn_last_error(None) or b"").decode()))
     print("pnn service: listening on %s" % args.socket, flush=True)
+    if os.environ.get("PNN_SERVICE_DEBUG"):
+        sys.stderr.write("[pnn-service] start-up: %.2f s from main() to listening (five contexts created, five models loaded)\n" % (time.time() - t_main))
     while not done.is_set() and srv.rc is None:
         time.sleep(0.05)
     st = srv.stop()

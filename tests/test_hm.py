@@ -338,22 +338,68 @@ def test_hm_encodes_dealt_over_one_service_per_device(hm_built, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,picture_set", [("kodak", "synthetic"), ("kodak", "natural"), ("bsds", "synthetic"), ("bsds", "natural")])
+def test_hm_campaign_at_stated_counts(hm_built, oracle, tmp_path, config, picture_set):
+    """BASELINE.json configs[3] / configs[4] AS STATED: 24 pictures of 768 x 512 through hm_16_15_substitution, 100 pictures of
+    480 x 320 through hm_16_15_switch (all widths 4-64), every encode in flight behind one batching service per device -- on the
+    engineered synthetic pictures and on windows of the natural fixtures (widths 4 / 8 then run the reference's trained checkpoints).
+    Every decoded picture must equal its encoder's reconstruction, and the service that served the campaign must answer seeded
+    contexts of every width like the oracle (within 1 LSB: .5 ties) -- asked through the same socket before it stops."""
+    import campaign
+    from tests import util
+    r = campaign.run_campaign(config, str(tmp_path / "work"), [0], picture_set=picture_set, yardstick=False, spot_check=True, timeout=600)
+    assert r["pictures"] == campaign.CONFIGS[config]["pictures"] == (24 if config == "kodak" else 100)
+    assert r["picture_size"] == ("768x512 4:0:0" if config == "kodak" else "480x320 4:0:0")
+    assert r["variant"] == ("hm_16_15_substitution" if config == "kodak" else "hm_16_15_switch")
+    assert r["every_decode_equals_its_encoder"] is True
+    assert r["service"]["requests"] > 10000 and r["service"]["backend_calls"] <= r["service"]["requests"]
+    served = {w: v["session_run_calls"] for w, v in r["pnn_calls"]["enc_pnn"].items()}
+    assert all(served[w] > 0 for w in (4, 8, 16, 32)), served        # every TU width reached the PNN (64: only in the switch variant's fast search)
+    spot = r["_spot_check"]
+    assert sorted(w for (_, w) in spot) == [4, 8, 16, 32, 64]
+    for (_, w), rec in spot.items():
+        flat, is_fc = run_hm.model_params(w, trained_small=(picture_set == "natural"))
+        assert is_fc == rec["is_fc"]
+        a, l = rec["above"], rec["left"]
+        want = oracle.fc_forward(flat, w, util.flatten_fc(a, l)) if is_fc else oracle.conv_forward(flat, w, a, l)
+        want = oracle.epilogue(want, run_hm.MEAN)
+        got = np.stack(rec["pel"])
+        assert np.abs(got.astype(np.int64) - want).max() <= 1, "width %d: the campaign's service differs from the oracle" % w
+        assert (got != want).mean() < 0.01
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("config", ["kodak", "bsds"])
 def test_bench_hm_campaign_in_small(hm_built, config):
     """BASELINE.json configs[3] / configs[4] through bench.py (`--workload hm_kodak` / `hm_bsds`, here with 4 pictures instead of
-    24 / 100): one batching service per device, all encodes in flight, hm_16_15_regular beside it; ONE JSON line whose `hm`
-    record says that every decoded picture equals its encoder's reconstruction.  The default bench line runs the same code at
-    the stated picture counts."""
+    24 / 100): one batching service per device, all encodes in flight, hm_16_15_regular beside it; ONE JSON line (< 4 KB) whose `hm`
+    record says that every decoded picture equals its encoder's reconstruction, everything else in the detail file.  The Kodak case
+    also runs the cpu_baseline leg: the first two pictures with the PNN answered on host cores (CPU oracle behind the same service)
+    beside the same two on the GPU."""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "hm_" + config, "--hm-quick"], capture_output=True, text=True,
-                       timeout=900, cwd=ROOT)
+    detail = os.path.join(ROOT, "gpurun_out", "test_hm_detail_%s.json" % config)
+    os.makedirs(os.path.dirname(detail), exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "hm_" + config, "--hm-quick", "--detail-file", detail]
+    if config == "bsds":
+        cmd.append("--no-cpu-baseline")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(lines[0]) < 4096
     d = json.loads(lines[0])
     h = d["hm"]
     assert h["pictures"] == 4 and h["every_decode_equals_its_encoder"] is True
     assert h["variant"] == ("hm_16_15_substitution" if config == "kodak" else "hm_16_15_switch")
-    assert h["service"]["requests"] > 1000 and h["service"]["backend_calls"] <= h["service"]["requests"]
-    assert d["value"] == h["service"]["pnn_blocks_per_s_over_the_wall"] and d["cpu_baseline"]["every_decode_equals_its_encoder"] is True
-    assert sum(v["session_run_calls"] for v in h["pnn_calls"]["enc_pnn"].values()) > h["service"]["requests"]     # the rest were cache hits
+    full = json.load(open(detail))["hm"][config]
+    assert full["service"]["requests"] > 1000 and full["service"]["backend_calls"] <= full["service"]["requests"]
+    assert d["value"] == pytest.approx(full["service"]["pnn_blocks_per_s_over_the_wall"], rel=1e-5)
+    assert sum(v["session_run_calls"] for v in full["pnn_calls"]["enc_pnn"].values()) > full["service"]["requests"]     # the rest were cache hits
+    assert full["yardstick_hm_16_15_regular"]["every_decode_equals_its_encoder"] is True
+    if config == "kodak":
+        cb = d["cpu_baseline"]
+        assert cb["unit"] == "pictures/s" and cb["kind"] == "port" and cb["value"] > 0 and cb["gpu_same_sample"] > 0
+        cp = full["cpu_pnn"]
+        assert cp["cpu"]["every_decode_equals_its_encoder"] is True and cp["gpu_same_sample"]["every_decode_equals_its_encoder"] is True
+        assert cp["cpu"]["service"]["requests"] == cp["gpu_same_sample"]["service"]["requests"] or not cp["same_bits"]
+    else:
+        assert d["cpu_baseline"]["value"] is None

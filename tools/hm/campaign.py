@@ -52,6 +52,11 @@ def binaries_present(variants=("substitution", "switch", "regular")):
         return False
 
 
+def np_cat(above, left):
+    import numpy as np
+    return np.concatenate([above.reshape(-1), left.reshape(-1)])       # sets/common.py:466-473: [above | left], both row-major
+
+
 def _service_stats(stdout_text, stderr_text):
     out = {}
     m = re.search(r"(\d+) requests in (\d+) batched calls \(largest batch (\d+)\), (\d+) clients", stdout_text)
@@ -68,29 +73,57 @@ def _service_stats(stdout_text, stderr_text):
     return out
 
 
-def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800, picture_set="synthetic"):
+def spot_check_contexts(width, k=6, seed=31):
+    """k seeded uint8-valued contexts of one width, mean-subtracted (what HM hands to Session::Run)."""
+    import numpy as np
+    rng = np.random.RandomState(seed + width)
+    above = rng.randint(0, 256, (k, width, 3 * width)).astype(np.float32) - np.float32(run_hm.MEAN)
+    left = rng.randint(0, 256, (k, 2 * width, width)).astype(np.float32) - np.float32(run_hm.MEAN)
+    above[1, :, 2 * width:] = 0.0                      # an unavailable above-right unit row / below-left rows, as the gather leaves them
+    left[2, width:, :] = 0.0
+    return above, left
+
+
+def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800, picture_set="synthetic",
+                 backend="gpu", spot_check=False, cpu_threads=None):
+    """backend "gpu": one batching service per device (the product).  backend "cpu": ONE service whose backend answers from the CPU
+    oracle (tools/hm/cpu_pnn_service.py) -- the reference's route, PNN inference on host cores, as bench.py's cpu_baseline leg.
+    picture_set "natural": windows of the natural fixtures, widths 4 / 8 on the reference's trained (convolutional) checkpoints.
+    spot_check: before the services stop, a client asks each of them for the predictions of seeded contexts of every width; they come
+    back under "_spot_check" (numpy arrays, popped by the callers that serialise the record) for the tests to hold against the oracle."""
     cfg = CONFIGS[config]
     n = int(pictures or cfg["pictures"])
     h, w, variant = cfg["height"], cfg["width"], cfg["variant"]
+    if backend == "cpu":
+        devices = [0]
     in_flight = int(in_flight or min(n, max(1, (os.cpu_count() or 8) - 2 * len(devices))))
     os.makedirs(work, exist_ok=True)
-    table, mean_path = run_hm.make_models(os.path.join(work, "models"))
-    frames = [run_hm.make_frame(h, w, seed + j) for j in range(n)]
-    servers, socks = [], []
+    natural = picture_set == "natural"
+    table, mean_path = run_hm.make_models(os.path.join(work, "models"), trained_small=natural)
+    frames = run_hm.natural_frames(h, w, n, seed) if natural else [run_hm.make_frame(h, w, seed + j) for j in range(n)]
+    servers, socks, logs = [], [], []
     t_start = time.time()
     for k, dev in enumerate(devices):
         sock = os.path.join(work, "pnn%d.sock" % k)
         env = dict(os.environ, PNN_SERVICE_DEBUG="1")
-        servers.append(subprocess.Popen([sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
-                                         "--table", table, "--device", str(dev), "--max-batch", "256", "--window-us", "0"], cwd=ROOT, env=env,
-                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        log = open(os.path.join(work, "service%d.err" % k), "w+")      # a file, not a pipe: a chatty service must never block on a full pipe
+        logs.append(log)
+        if backend == "cpu":
+            cmd = [sys.executable, os.path.join(HERE, "cpu_pnn_service.py"), "--socket", sock, "--table", table, "--threads", str(cpu_threads or 0)]
+        else:
+            cmd = [sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
+                   "--table", table, "--device", str(dev), "--max-batch", "256", "--window-us", "0"]
+        servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True))
         socks.append(sock)
-    results, stats = [], []
+    results, stats, spot = [], [], {}
     try:
-        for srv in servers:
-            line = srv.stdout.readline()
+        import select
+        for srv, log in zip(servers, logs):            # the start-up line, with a deadline
+            ready, _, _ = select.select([srv.stdout], [], [], 300.0)
+            line = srv.stdout.readline() if ready else ""
             if "listening" not in line:
-                raise RuntimeError("batching service did not start: %s %s" % (line, srv.stderr.read()[-2000:]))
+                log.seek(0)
+                raise RuntimeError("batching service did not start: %r %s" % (line, log.read()[-2000:]))
         t_up = time.time() - t_start
 
         def job(j):
@@ -100,15 +133,34 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         with ThreadPoolExecutor(in_flight) as ex:
             results = list(ex.map(job, range(n)))
         wall = time.time() - t0
+        if spot_check:
+            from context_adaptive_neural_network_based_prediction_amd import service as svc
+            for k, sock in enumerate(socks):
+                cl = svc.Client(sock)
+                for wd in (4, 8, 16, 32, 64):
+                    above, left = spot_check_contexts(wd)
+                    fc = run_hm.model_params(wd, trained_small=natural)[1]
+                    pel = [cl.predict_pel(wd, np_cat(above[i], left[i]) if fc else above[i], None if fc else left[i]) for i in range(above.shape[0])]
+                    spot[(k, wd)] = {"above": above, "left": left, "pel": pel, "is_fc": fc}
+                cl.close()
     finally:
         for srv in servers:
-            srv.terminate()
-        for srv in servers:
             try:
-                so, se = srv.communicate(timeout=30)
+                os.killpg(srv.pid, 15)                 # the service and anything it started (its own session: see Popen above)
+            except OSError:
+                pass
+        for srv, log in zip(servers, logs):
+            try:
+                so, _ = srv.communicate(timeout=30)
             except subprocess.TimeoutExpired:
-                srv.kill()
-                so, se = srv.communicate()
+                try:
+                    os.killpg(srv.pid, 9)
+                except OSError:
+                    pass
+                so, _ = srv.communicate()
+            log.seek(0)
+            se = log.read()
+            log.close()
             stats.append(_service_stats(so or "", se or ""))
     calls = {}
     for side in ("enc_pnn", "dec_pnn"):
@@ -129,7 +181,10 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         b["backend_busy_s"] = round(b["backend_busy_s"], 3)
     out = {
         "config": cfg["baseline"], "variant": "hm_16_15_" + variant, "pictures": n, "picture_size": "%dx%d 4:0:0" % (w, h), "qp": qp,
-        "data": "seeded synthetic pictures + seeded random-init models (Kodak / BSDS and the trained production models are not in the reference checkout)",
+        "picture_set": picture_set, "pnn_backend": backend,
+        "data": ("windows of the natural fixtures (tests/golden/natural_luma.npz); widths 4 / 8 on the reference's trained convolutional checkpoints, 16 / 32 / 64 "
+                 "seeded random init" if natural else "seeded synthetic pictures + seeded random-init models") + " (Kodak / BSDS and the trained production models "
+                "are not in the reference checkout)",
         "devices": list(devices), "services": len(devices), "encodes_in_flight": in_flight, "host_cores": os.cpu_count(),
         "wall_s_all_encodes_and_decodes": round(wall, 3), "service_start_s": round(t_up, 3),
         "pictures_per_s": round(n / wall, 3),
@@ -159,6 +214,8 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
             "enc_wall_s_mean": round(sum(r["enc_wall_s"] for r in reg) / n, 3), "bits_total": int(sum(r["bits"] for r in reg)),
             "every_decode_equals_its_encoder": bool(all(r["decoder_equals_encoder"] for r in reg))}
         out["wall_vs_regular"] = round(wall / rw, 3)
+    if spot_check:
+        out["_spot_check"] = spot
     return out
 
 
@@ -169,13 +226,16 @@ def main():
     ap.add_argument("--pictures", type=int, default=0)
     ap.add_argument("--in-flight", type=int, default=0)
     ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--picture-set", default="synthetic", choices=["synthetic", "natural"])
+    ap.add_argument("--backend", default="gpu", choices=["gpu", "cpu"])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hm_campaign"))
     args = ap.parse_args()
     import shutil
     import tempfile
     work = tempfile.mkdtemp(prefix="hm_campaign_")
     try:
-        res = run_campaign(args.config, work, [int(d) for d in args.devices.split(",")], args.pictures or None, args.in_flight or None, args.qp)
+        res = run_campaign(args.config, work, [int(d) for d in args.devices.split(",")], args.pictures or None, args.in_flight or None, args.qp,
+                           picture_set=args.picture_set, backend=args.backend)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(res))

@@ -1,0 +1,70 @@
+"""The batching service with a CPU backend: the reference's route for the PNN -- inference on host cores -- behind the same socket
+the HM binaries talk to (include/pnn_service.h: pnn_service_run_backend).  bench.py's `cpu_baseline` leg for the HM campaigns and
+nothing else: the answers come from the CPU ORACLE (oracle/pnn_oracle.c, OpenMP), which is test infrastructure, never the product.
+
+    python tools/hm/cpu_pnn_service.py --socket /tmp/pnn.sock --table models/single.txt [--threads T]
+
+What HM's TComPrediction.cpp:572-579,601-608 does per transform block is one Session::Run at batch 1 on the host; here the requests of
+one width that are pending together reach the backend as one batch (with two encodes in flight: almost always one request) and the
+oracle walks it with its OpenMP team of T threads -- default 8, the fastest count of bench.py's batch-1 CPU legs on the 256-core GPU
+boxes (a single 8x8 block on 64 threads is slower than on 8: the fork / join costs more than the 6.7 MFLOP).
+"""
+import argparse
+import os
+import signal
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--socket", required=True)
+    ap.add_argument("--table", required=True)
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+    threads = args.threads or min(8, os.cpu_count() or 8)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import numpy as np
+    from context_adaptive_neural_network_based_prediction_amd import _lib, service, weights as wts
+    _lib.SKIP_TORCH = True
+    from oracle import pnn_oracle as O
+    mean = np.float32(wts.MEAN_TRAINING_LUMINANCE)
+    models = {}
+    for line in open(args.table):
+        width, _, _, path = line.strip().split(",", 3)
+        flat, w, is_fc = wts.load_pnnw(path)
+        models[int(width)] = (flat, bool(is_fc))
+
+    def backend(width, above, left):
+        flat, is_fc = models[width]
+        n = above.shape[0]
+        if is_fc:
+            f32 = O.fc_forward(flat, width, above.reshape(n, 5 * width * width))
+        else:
+            f32 = O.conv_forward(flat, width, above.reshape(n, width, 3 * width), left.reshape(n, 2 * width, width))
+        return O.epilogue(f32, float(mean)), f32
+
+    try:
+        os.unlink(args.socket)
+    except OSError:
+        pass
+    srv = service.Server(args.socket, backend=backend, max_batch=256, window_us=0)
+    done = threading.Event()
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, lambda *_: done.set())
+    t0 = time.time()
+    while srv.rc is None and not os.path.exists(args.socket) and time.time() - t0 < 120:
+        time.sleep(0.02)
+    print("pnn service (CPU oracle backend, %d OpenMP threads): listening on %s" % (threads, args.socket), flush=True)
+    while not done.is_set() and srv.rc is None:
+        time.sleep(0.05)
+    st = srv.stop()
+    print("pnn service: %(requests)d requests in %(backend_calls)d batched calls (largest batch %(largest_batch)d), %(clients)d clients" % st, flush=True)
+
+
+if __name__ == "__main__":
+    main()

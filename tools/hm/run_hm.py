@@ -73,6 +73,39 @@ def make_frame(h, w, seed):
     return np.clip(np.round(img), 0, 255).astype(np.uint8)
 
 
+def natural_frames(h, w, n, seed=1):
+    """n uint8 luminance pictures of h x w cut from the natural fixtures (tests/golden/natural_luma.npz: windows of three HEVC class-B
+    first frames and two photographs of the reference checkout, tests/golden/make_natural.py): windows on a 64-pixel grid, every second one
+    mirrored -- distinct pictures with natural statistics, since Kodak / BSDS themselves are not in the checkout."""
+    pics = np.load(os.path.join(ROOT, "tests", "golden", "natural_luma.npz"))
+    names = sorted(pics.files)
+    rng = np.random.RandomState(seed)
+    out, seen = [], set()
+    while len(out) < n:
+        k = len(out) % len(names)
+        img = pics[names[k]]
+        H, W = img.shape
+        y = 64 * rng.randint(0, (H - h) // 64 + 1) if H > h else 0
+        x = 64 * rng.randint(0, (W - w) // 64 + 1) if W > w else 0
+        flip = (len(out) // len(names)) % 2 == 1
+        key = (k, y, x, flip)
+        if key in seen and len(seen) < 200:
+            continue
+        seen.add(key)
+        win = img[y:y + h, x:x + w]
+        out.append(np.ascontiguousarray(win[:, ::-1] if flip else win))
+    return out
+
+
+def model_params(w, seed=11, trained_small=False):
+    """(flat parameters, is_fc) of the model make_models writes for width w."""
+    from context_adaptive_neural_network_based_prediction_amd import weights as wts
+    if trained_small and w <= 8:
+        flat, _, _ = wts.load_pnnw(os.path.join(ROOT, "tests", "golden", "conv%d_single.pnnw" % w))
+        return flat, False
+    return wts.init_params(w, w <= 8, seed + w, bias_std=0.02), w <= 8
+
+
 def make_models(out_dir, seed=11, trained_small=False, only_widths=(4, 8, 16, 32, 64)):
     """Seeded random-init models in the reference's architecture per width (FC for 4, 8; conv for 16, 32, 64;
     PredictionNeuralNetwork.py:119-137) as .pnnw files + the `width,is_pair,channel,path` table + the mean file
