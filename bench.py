@@ -52,7 +52,7 @@ WORKLOADS = {                      # name -> (width, is_fc, default batch per GP
     "conv4": (4, False, 4096, "4x4 convolutional PNN, batch 4096"),
 }
 PER_WIDTH = ("fc4", "fc8", "conv16", "conv32", "conv64")   # the nets HM uses per width (pnn/PredictionNeuralNetwork.py:119-137, TComPrediction.cpp:130-171)
-KERNELS = ((0, "tapgemm_kernel (exact f32 MFMA, LDS-staged weights)"),
+KERNELS = ((0, "tapgemm_f32_kernel (exact f32 on v_mfma_f32_32x32x2_f32, one wave per SIMD, LDS-DMA weight ring; FC nets: output layer fused in)"),
            (1, "tapgemm_splitk_kernel (f32 MFMA, small M)"),
            (2, "tapgemm_sp_kernel (split products on 3 x f16 MFMA 32x32x16, register-staged operands)"),
            (3, "convimg_sp_kernel (split-product MFMAs, feature maps resident in LDS)"),
@@ -298,7 +298,7 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
                       "blocks_per_s_spread": [per_call / float(np.max(ts)), per_call / float(np.min(ts))]}))   # slowest / fastest run of this leg
 
 
-def cpu_legs(workload, budget_s=1.0, full=False):
+def cpu_legs(workload, budget_s=2.0, full=False):
     """the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
     an independent PyTorch-CPU formulation (oneDNN / MKL), each batched (the GPU batch where the oracle finishes it in seconds)
     and at batch 1 sequential (what HM does per TB).  Bounded samples: every leg runs for about `budget_s` in its own process.

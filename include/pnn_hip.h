@@ -111,6 +111,13 @@ float pnn_mean(const pnn_ctx* ctx);
  * AND their reduction as one launch, fc_out_small_kernel -- bit-identical, one launch less, measured no faster) and
  * "spin_wait" (0, default; 1: synchronous host calls poll the stream with hipStreamQuery instead of blocking in
  * hipStreamSynchronize -- measured no faster): two round-3 experiments on the single-block call kept as switches,
+ * "f32_kernel" (1, default: exact-f32 passes -- "precision" 0, the range fallback of host calls -- run their tap GEMMs on
+ * tapgemm_f32_kernel: v_mfma_f32_32x32x2_f32, one wave per SIMD, one per-output summation order for every tile and batch size;
+ * fully-connected nets with <= 64 outputs sum the output layer in K segments of 160 hidden units at every batch size, inside the
+ * last hidden layer's launch from 1024 blocks on ("fuse_last"); "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
+ * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
+ * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
+ * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs
@@ -120,14 +127,14 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
- * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG. */
+ * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG, PNN_F32_DIAG (diagnostic library of `make diag` only). */
 /* Input-range contract of the default arithmetic ("precision" = 1): operands travel as pairs of f16 values, so every
  * intermediate activation must satisfy |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude
  * below that; arbitrary float inputs or models may not.  The kernels detect a violation (they never emit
- * a silent NaN): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then recompute, on the exact-f32 kernels and
+ * a silent NaN; the raw context a convolutional net's first layer splits in registers is checked where it is staged): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then recompute, on the exact-f32 kernels and
  * by themselves, exactly the blocks that overflow when predicted alone (batches of <= 256; the other blocks of the batch keep
  * the bits they get in any batch), and they refuse non-finite inputs (PNN_E_ARG) -- the guard's max would drop a NaN; models
  * with a non-finite parameter are refused at load (PNN_E_MODEL).  Device entry points are asynchronous, so the NEXT call on the context fails with PNN_E_RANGE, and

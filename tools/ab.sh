@@ -16,7 +16,7 @@ else
   for i in 1 2 3; do
     for lib in build_tmp/libpnn_hip_prev.so context_adaptive_neural_network_based_prediction_amd/libpnn_hip.so; do
       for wl in $wls; do
-        v=$(PNN_LIB_PATH=$PWD/$lib python3 bench.py --workload $wl --no-cpu-baseline --no-extras --no-sustained 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4g blocks/s  %.4f ms' % (d['value'], d['ms_per_step']))")
+        v=$(PNN_LIB_PATH=$PWD/$lib python3 bench.py --workload $wl --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4g blocks/s  %.4f ms' % (d['value'], d['ms_per_step']))")
         echo "$(basename $lib) $wl: $v"
       done
     done

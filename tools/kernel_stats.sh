@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 wl=${1:-conv16}; shift
 mkdir -p gpurun_out/ks
 rm -rf /tmp/ks
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 bench.py --workload $wl --no-cpu-baseline --no-sustained --steps 20 --warmup 3 "$@" > gpurun_out/ks/$wl.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 bench.py --workload $wl --no-cpu-baseline --no-extras --steps 20 --warmup 3 "$@" > gpurun_out/ks/$wl.log 2>&1
 f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -5,9 +5,9 @@ units of a 128-byte-wide read path: x2; both counters are in KiB).  Writes profi
 reports as roofline.traffic.   usage: tools/pmc_traffic.py <out.json> <workload> [<workload> ...]"""
 import collections, csv, glob, json, sys
 GEMM_SPLIT = ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")
-GEMM_F32 = ("tapgemm_kernel", "tapgemm32_kernel", "tapgemm_splitk_kernel")
+GEMM_F32 = ("tapgemm_f32_kernel", "tapgemm_kernel", "tapgemm32_kernel", "tapgemm_splitk_kernel")
 out = {}
-for wl in sys.argv[2:]:                      # "<workload>" = default (split) arithmetic, "<workload>_f32" = PNN_PRECISION=0 passes
+for wl in sys.argv[2:]:                      # "<workload>_split" = split-f16 arithmetic, "<workload>_f32" = exact-f32 passes (tools/profile_round.sh)
     GEMM = GEMM_F32 if wl.endswith("_f32") else GEMM_SPLIT
     per = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
     names = collections.Counter()
@@ -26,7 +26,7 @@ for wl in sys.argv[2:]:                      # "<workload>" = default (split) ar
     out[wl] = {"bytes_per_launch": (2.0 * fetch + write) * 1024.0, "fetch_kb_raw_mean": fetch, "write_kb_mean": write,
                "launches": nf, "kernels": dict(names),
                "precision": 0 if wl.endswith("_f32") else 1,
-               "source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload %s` with the rule-based tile choice "
+               "source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py on `%s` (workload_arithmetic) with the rule-based tile choice "
                          "(PNN_AUTOTUNE=0, so that tuning launches do not enter the mean); mean over the GEMM dispatches of that arithmetic of "
                          "2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes" % wl}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
