@@ -304,7 +304,14 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
         const void* key = (const void*)((const char*)&L + (next ? 1 : 0) + (first ? 2 : 0) + (lastp ? 4 : 0));
         const int rule = cfg;
         float best_us = -1.f;
+        // The sweep launches every configuration several times; a last layer that carries the completion signal of a host call
+        // (`lastp->done`) must not raise it from there -- the flag would already stand at this call's sequence number while the
+        // final launch below is still writing its results.  The sweep runs with an unsignalled copy; only the final launch signals.
+        TConv1Params quiet;
+        const TConv1Params* const signalled = lastp;
+        if (lastp && lastp->done.host_flag) { quiet = *lastp; quiet.done = DoneSignal{nullptr, nullptr, 0, 0}; lastp = &quiet; }
         const int trc = tuned_cfg(c, key, M, nsp + nci + nrg, rule, legal, launch, s, &cfg, &best_us);
+        lastp = signalled;
         if (trc) return trc;
         if (best_us >= 0.f && getenv("PNN_DEBUG")) {
             const TileCfg tb = cfg_of(cfg), th = cfg_of(rule);

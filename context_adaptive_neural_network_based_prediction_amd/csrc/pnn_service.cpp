@@ -174,7 +174,7 @@ struct Server {
     static constexpr int kMaxIo = 8;
     int nio = 1;
     std::vector<Reply> done[kMaxIo];
-    std::vector<int> fresh[kMaxIo];  // accepted descriptors dealt to I/O thread t by the listener (thread 0), under `mu`
+    std::vector<int> fresh[kMaxIo];  // accepted descriptors dealt to I/O thread t by the listener (thread 0), under dmu[t]
     std::atomic<int> n_peers{0}, n_waiting_peers{0};   // distinct peer processes connected / with a request in flight (window_us > 0 only; written under `mu`)
     std::atomic<bool> quit_flag{false};
     struct Peer { int conns = 0, in_flight = 0; };

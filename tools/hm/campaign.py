@@ -52,6 +52,17 @@ def binaries_present(variants=("substitution", "switch", "regular")):
         return False
 
 
+def _die_with_parent():
+    """preexec_fn of the service processes: SIGTERM when the parent dies (PR_SET_PDEATHSIG), so a campaign killed from outside -- a
+    `timeout` around bench.py sends SIGTERM, which skips `finally` -- leaves no service alive on the GPU."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
+    except OSError:
+        pass
+
+
 def np_cat(above, left):
     import numpy as np
     return np.concatenate([above.reshape(-1), left.reshape(-1)])       # sets/common.py:466-473: [above | left], both row-major
@@ -113,7 +124,7 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         else:
             cmd = [sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
                    "--table", table, "--device", str(dev), "--max-batch", "256", "--window-us", "0"]
-        servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True))
+        servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True, preexec_fn=_die_with_parent))
         socks.append(sock)
     results, stats, spot = [], [], {}
     try:
