@@ -624,7 +624,12 @@ def main():
     dist = sharding.init_ranks("gloo" if share else "nccl", None if share else torch.device("cuda", local_rank))   # "nccl" = RCCL on ROCm; None at N = 1
     ranks_seen = None
     if dist is not None:
-        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": sharding.count_distinct_devices(dist, local_rank, share)}
+        try:
+            ndev = sharding.count_distinct_devices(dist, local_rank, share)
+        except Exception as e:                        # noqa: BLE001 -- an extra of the line must never cost the measurement
+            sys.stderr.write("bench.py: count_distinct_devices failed: %r\n" % (e,))
+            ndev = None
+        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": ndev}
 
     t_start = time.perf_counter()
     wl = Workload(args.workload, args.batch, rank, local_rank)
