@@ -337,6 +337,30 @@ def test_hm_encodes_dealt_over_one_service_per_device(hm_built, tmp_path):
     assert clients == [20, 20], clients                              # 2 encoders + 2 decoders per service, 5 sessions each
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_hm_with_the_pnn_on_host_cores_needs_no_gpu(hm_built, oracle, tmp_path, variant):
+    """The reference's route in small, on a box without a GPU (BASELINE.json configs[0]: the CPU-runnable plumbing case): the unchanged HM
+    binaries talk to the batching service through the client stub of libpnn_hip.so, and the service's backend answers from the CPU oracle
+    (tools/hm/cpu_pnn_service.py -- bench.py's cpu_baseline leg of the HM campaigns).  One 64 x 64 picture: encode, decode, decoder ==
+    encoder; the service answers seeded contexts of every width like the oracle called directly (Pel epilogue, socket framing, FC and
+    conv request shapes)."""
+    import campaign
+    from tests import util
+    name = "tiny_" + variant
+    campaign.CONFIGS[name] = {"variant": variant, "pictures": 1, "width": 64, "height": 64, "baseline": "one 64 x 64 picture, PNN on host cores"}
+    try:
+        r = campaign.run_campaign(name, str(tmp_path / "work"), [0], backend="cpu", yardstick=False, spot_check=True, timeout=600, cpu_threads=2)
+    finally:
+        del campaign.CONFIGS[name]
+    assert r["pnn_backend"] == "cpu" and r["pictures"] == 1 and r["every_decode_equals_its_encoder"] is True
+    assert r["service"]["requests"] > 50
+    for (_, w), rec in r["_spot_check"].items():
+        flat, is_fc = run_hm.model_params(w)
+        a, l = rec["above"], rec["left"]
+        want = oracle.epilogue(oracle.fc_forward(flat, w, util.flatten_fc(a, l)) if is_fc else oracle.conv_forward(flat, w, a, l), run_hm.MEAN)
+        assert np.array_equal(np.stack(rec["pel"]), want), "width %d" % w
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("config,picture_set", [("kodak", "synthetic"), ("kodak", "natural"), ("bsds", "synthetic"), ("bsds", "natural")])
 def test_hm_campaign_at_stated_counts(hm_built, oracle, tmp_path, config, picture_set):
