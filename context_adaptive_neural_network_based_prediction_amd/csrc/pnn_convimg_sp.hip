@@ -464,6 +464,30 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         __syncthreads();
         f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Yhi);
         const int cq = p.Cout >> 2;
+        // A forward convolution's output grid IS its row grid (one class, os = 1): output pixel = first image's first pixel + row, no
+        // divisions -- the general mapping below cost ~40 VALU instructions per 16-byte piece (two run-time divisions), a third of
+        // this kernel's epilogue instructions on the layers with K = 576 (profiles/r03_conv16_pmc_summary.txt: 9.6 VALU per MFMA)
+        const bool linear = p.ncls == 1 && p.os == 1 && p.OH == p.SH && p.OW == p.SW;      // launch-uniform
+        if (linear) {
+            f32x4* __restrict__ ybase = yo + (size_t)img0 * SP * cq + (n0 >> 2);
+            const int rows_here = nimg * SP;
+            const bool cols_whole = n0 + BN <= p.Cout;
+            for (int i0 = tid; i0 < BM * (BN / 4); i0 += 2 * 256) {
+                f32x4 v[2];
+                f32x4* dst[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = i0 + u * 256;
+                    const int ic = i < BM * (BN / 4) ? i : tid;
+                    const int row = ic / (BN / 4), q = ic - row * (BN / 4);
+                    v[u] = lds[row * OPP + q];
+                    dst[u] = (i < BM * (BN / 4) && row < rows_here && (cols_whole || (n0 >> 2) + q < cq)) ? ybase + ((size_t)row * cq + q) : nullptr;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (dst[u]) store16_through(dst[u], v[u]);
+            }
+        } else
         for (int i0 = tid; i0 < BM * (BN / 4); i0 += 2 * 256) {   // two pieces per thread in flight (the store is an asm statement)
             f32x4 v[2];
             f32x4* dst[2];

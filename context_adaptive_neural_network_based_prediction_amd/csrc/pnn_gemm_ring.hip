@@ -171,6 +171,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
     // (Handing the tile to the loader waves one 32-column block at a time, so that the copy-out runs under the conversion,
     // was built and measured: epilogue 8.8k -> 7.9k cycles in tools/ring_prof.hip, but FC-8 and conv-16 passes 1 % SLOWER
     // -- five more workgroup-wide barriers and a third copy of the unrolled group loop in the instruction cache.)
+    const bool lin_out = p.ncls == 1 && p.os == 1 && p.OH == p.SH && p.OW == p.SW;   // launch-uniform
     auto copy_out = [&]() {
         if (!p.Yhi) return;
         const int cpy = p.py[cls], cpx = p.px[cls];
@@ -192,7 +193,7 @@ __device__ __forceinline__ void ring_layer(CParams& p, const int tid)
                 if (pmg) {
                     rowok = mg < p.nblk;
                     opix = ((size_t)mg * p.OH + pmi * p.os + cpy) * p.OW + pmj * p.os + cpx;
-                } else if (SP != 1 || p.os != 1) {
+                } else if (!lin_out && (SP != 1 || p.os != 1)) {   // (a forward convolution's output grid is its row grid: pixel = row, no divisions)
                     const int pbq = mg / SP;
                     const int rq = mg - pbq * SP;
                     const int piq = rq / p.SW, pjq = rq - piq * p.SW;
