@@ -128,13 +128,14 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
                 for (int g = 0; g < 4; g++) bv0[ct][g] = *reinterpret_cast<const f32x4*>(p.B0 + (ct < nct ? ct * 32 + 8 * g + 4 * h : 0));
             }
             const int total = nimg * NPIN;
+            FirstConv<K> fc;
+            fc.setup(PW, h);
             for (int rt0 = wave; rt0 * 32 < total; rt0 += 4) {
                 const int pix = rt0 * 32 + l31;
                 const bool valid = pix < total;
                 const int li = valid ? pix / NPIN : 0, q = valid ? pix - li * NPIN : 0;
                 const int oy = q / p.IW, ox = q - oy * p.IW;
-                FirstConv<K> fc;
-                fc.load(raw + li * PH * PW + (oy * S0) * PW + ox * S0, PW, h, valid);
+                fc.load(raw + li * PH * PW + (oy * S0) * PW + ox * S0);   // (an idle row reads image 0, pixel 0: its outputs are not stored)
 #pragma unroll
                 for (int ct = 0; ct < 2; ct++) {
                     if (ct >= nct) break;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
 
-    int abase[RT];                                    // slot index of this lane's source pixel for the current tap
+    const f32x4* arow[RT];                            // this lane's source pixel for the current tap: its hi piece of chunk 0, k-half h
     auto tap_setup = [&](int tp) {
         const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
 #pragma unroll
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             const int iy = pi[rt] * p.a + dy, ix = pj[rt] * p.a + dx;
             const bool ok = mv[rt] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
             const int nat = (pg[rt] * NPIN + iy * p.IW + ix) * PITCH;          // where the pixel is -- or would be
-            abase[rt] = ok ? nat : G * NPIN * PITCH + ((nat - G * NPIN * PITCH) & 15);
+            // (a pointer with the lane's k-half folded in, set once per tap: a fragment read is then base + a wave-uniform chunk
+            // offset -- the index form cost three VALU instructions per read, 18 per stage of 18 MFMAs)
+            arow[rt] = Ai + (ok ? nat : G * NPIN * PITCH + ((nat - G * NPIN * PITCH) & 15)) + h;
         }
     };
     unsigned bsrc[NLD];                              // byte offsets into the packed weights (buffer loads: a 32-bit offset per lane
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
         }
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-            af[rt][0] = Ai[abase[rt] + cj * 4 + 0 + h];
-            af[rt][1] = Ai[abase[rt] + cj * 4 + 2 + h];
+            af[rt][0] = arow[rt][cj * 4 + 0];
+            af[rt][1] = arow[rt][cj * 4 + 2];
         }
     };
     auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2]) {

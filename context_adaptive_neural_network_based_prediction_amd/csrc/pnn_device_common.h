@@ -152,21 +152,31 @@ template <int K>
 struct FirstConv {
     static constexpr int NCH = (K * K + 15) / 16;
     f16x8 xhi[NCH], xlo[NCH];
+    // Per-lane tap offsets into the zero-padded plane (row pitch PW): lane half h supplies taps 16 c + 8 h + j of chunk c.  Set once
+    // per kernel; taps past K * K (the K padding of the last chunk) point at the pixel's own first tap -- their WEIGHTS are zero, so
+    // any finite value will do, and the read needs no select.  (Until round 4 every load() recomputed the offsets and masked the
+    // values: ~100 of the fused first convolution's ~280 VALU instructions per 32-pixel tile.)
+    int off[NCH][8];
+    __device__ __forceinline__ void setup(int PW, int h)
+    {
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int t0 = 16 * c + j, t1 = t0 + 8;             // the tap of k-half 0 / 1
+                const int o0 = t0 < K * K ? (t0 / K) * PW + t0 % K : 0, o1 = t1 < K * K ? (t1 / K) * PW + t1 % K : 0;
+                off[c][j] = h ? o1 : o0;
+            }
+    }
     // This lane's operand: 8 taps (k-half h = lane >> 5) of each chunk for ITS pixel.  xr = the pixel's top-left tap in the
-    // zero-padded f32 plane (LDS or global), PW = the plane's row pitch; !valid (idle row of the tile) -> zeros.
-    __device__ __forceinline__ void load(const float* xr, int PW, int h, bool valid)
+    // zero-padded f32 plane (LDS or global); an idle row of the tile passes any readable pixel (its outputs are not stored).
+    __device__ __forceinline__ void load(const float* xr)
     {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             f32x4 v[2];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int t0 = 16 * c + j, t1 = t0 + 8;             // the tap of k-half 0 / 1
-                const int o0 = t0 < K * K ? (t0 / K) * PW + t0 % K : 0, o1 = t1 < K * K ? (t1 / K) * PW + t1 % K : 0;
-                const bool in = valid && (h ? t1 < K * K : t0 < K * K);
-                const float x = xr[h ? o1 : o0];
-                v[j >> 2][j & 3] = in ? x : 0.f;
-            }
+            for (int j = 0; j < 8; j++) v[j >> 2][j & 3] = xr[off[c][j]];
             f16x4 h0, l0, h1, l1;
             split4(v[0], h0, l0);
             split4(v[1], h1, l1);

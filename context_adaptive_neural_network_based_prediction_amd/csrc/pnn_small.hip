@@ -87,12 +87,13 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
         const int band_pix = (oy1 - oy0) * p.OW;
         float amax = 0.f;                            // range guard of the split output (pnn_device_common.h)
         f32x4* yo = reinterpret_cast<f32x4*>(p.Y) + ((size_t)b * npix + (size_t)oy0 * p.OW) * cq;
+        FirstConv<K> fc;
+        fc.setup(PW, h);
         for (int rt = wave; rt * 32 < band_pix; rt += 4) {
             const int lp = rt * 32 + l31;
             const bool valid = lp < band_pix;
             const int ly = valid ? lp / p.OW : 0, lx = valid ? lp - ly * p.OW : 0;
-            FirstConv<K> fc;
-            fc.load(xs + (ly * p.s) * PW + lx * p.s, PW, h, valid);
+            fc.load(xs + (ly * p.s) * PW + lx * p.s);      // (an idle row reads pixel 0: its outputs are not stored)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
                 if (ct >= nct) break;
