@@ -10,12 +10,16 @@
 //
 //   workgroup = 256 threads = 4 waves as WM x WN; wave tile (32*RT) x (32*NT); workgroup rows = G images x SH*SW
 //   output pixels (rows past G*SH*SW idle), all of them taken from the G staged input images.
-//   LDS: weights [2][KC][4 planes][BN] slots | images [(G*IH*IW + 1)][Cin/4 + 1] slots (16-B slots; the +1 slot of
-//   pitch keeps the 64-lane fragment reads conflict-free; the extra pixel is all zeros = SAME padding / idle rows).
+//   LDS: weights [3][KC][4 planes][BN] slots (round 4: an LDS-DMA ring, see the K loop) | images [(G*IH*IW + 1)][Cin/4 + 1] slots
+//   (16-B slots; the +1 slot of pitch keeps the 64-lane fragment reads conflict-free; the extra pixel is all zeros = SAME
+//   padding / idle rows).
 // Measured (tools/convimg_prof.hip, 3x3 conv 64 -> 64 on 1024 images of 8x24, tile 192 x 64): per workgroup ~9.5k cycles
 // to stage its 52 KB image, ~30k in the tap loop (1650 per 32-deep stage for 576 MFMA cycles, two workgroups per CU), ~10k in
 // the epilogue.  Staging by LDS-DMA with an XOR-swizzled layout was tried: same 9.3k cycles -- the 50 MB of activations of
 // all resident workgroups arrive as one burst at ~5.8 TB/s, it is memory bandwidth, not the copy loop.
+// Round 4 (same tool, same layer): weights by LDS-DMA into three stage buffers, the stage barrier between its two chunks, the next
+// stage's first fragments and the refill issued between MFMA groups, and a copy-out without divisions: 57.9 -> 48.3 us, tap loop
+// 1620 -> 1346 cycles per stage (two co-resident workgroups: 1152 MFMA cycles), epilogue 10.5k -> 7.6k cycles.
 // Round 3: the ring kernel's issue order inside a chunk (one MFMA, then two of the next chunk's fragment reads, pinned with
 // sched_group_barrier) was tried here too: conv 16x16 pass 0.3830 -> 0.3849 ms same-box, i.e. nothing -- with two workgroups
 // per CU the other workgroup's wave fills the SIMD while this one issues its read burst.
@@ -27,6 +31,16 @@ namespace pnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kCiRing = 3;       // weight stage buffers (round 4: LDS-DMA ring, see the K loop)
+
+// 16 bytes per lane, global -> LDS without passing registers (lane-linear destination).  In a __device__ helper on purpose: called
+// straight from a lambda inside the __global__ template, the builtin made hipcc emit the host object WITHOUT its device code
+// (no error, no .hip_fatbin section: the library then loads and every launch of this file's kernels fails).
+__device__ __forceinline__ void ci_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4* l)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
 
 template <int RT, int NT, int KC, int WM>
 __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, const int G)
@@ -40,8 +54,8 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
     constexpr int E = 4 * BN;
     constexpr int NLD = (E + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
-    f32x4* Bs = lds;                                  // [2][KC][E]
-    f32x4* Ai = lds + 2 * KC * E;                     // [G*NPIN][PITCH] | zero region [ZP]
+    f32x4* Bs = lds;                                  // [kCiRing][KC][E]
+    f32x4* Ai = lds + kCiRing * KC * E;               // [G*NPIN][PITCH] | zero region [ZP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -224,29 +238,27 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             arow[rt] = Ai + (ok ? nat : G * NPIN * PITCH + ((nat - G * NPIN * PITCH) & 15)) + h;
         }
     };
-    unsigned bsrc[NLD];                              // byte offsets into the packed weights (buffer loads: a 32-bit offset per lane
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffffu, 0x00020000);   // issues faster than a 64-bit flat address, see pnn_gemm_ring.hip)
-    int bdst[NLD];
+    // Weights: global -> LDS by LDS-DMA (round 4; until then global -> registers -> ds_write, one barrier per stage with the stage's
+    // first fragment reads exposed behind it: 1650 cycles per stage for the 2 x 576 MFMA cycles of two co-resident workgroups).
+    // Three stage buffers: the one barrier of a stage sits between its two chunks, stage s+2 is fetched behind it into the buffer
+    // stage s-1 left, and the next stage's first fragments are read under the second chunk's MFMAs -- tapgemm_f32_kernel's scheme.
+    static_assert(KC == 2, "the loop below is written for two chunks per stage");
+    constexpr int NDMA = KC * E / 64, NPW = NDMA / 4;   // LDS-DMA wave-instructions per stage, per wave
+    static_assert((KC * E) % 256 == 0, "a stage is the same whole number of wave instructions for every wave");
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffffu, 0x00020000);
+    unsigned bsrc[NPW];
 #pragma unroll
-    for (int r = 0; r < NLD; r++) {
-        int e = tid + 256 * r;
-        if (E % 256 != 0) e = e < E ? e : E - 1;
-        const int qq = e / BN, nn = e - qq * BN;
-        bsrc[r] = (unsigned)((qq * p.Npad + n0 + nn) << 4);
-        bdst[r] = e;
+    for (int ii = 0; ii < NPW; ii++) {
+        const int e = 64 * (wave + 4 * ii) + lane;
+        const int j = e / E, ee = e - j * E;
+        const int qq = ee / BN, nn = ee - qq * BN;
+        bsrc[ii] = (unsigned)(((j * 4 + qq) * p.Npad + n0 + nn) << 4);
     }
-    const unsigned bstride = (unsigned)(4 * p.Npad) << 4;   // bytes per packed chunk
-    auto load_b = [&](int stage, f32x4 (&dst)[KC][NLD]) {
+    const unsigned wstage = (unsigned)(KC * 4 * p.Npad) << 4;   // bytes per stage
+    auto dma_stage = [&](int stage, int buf) {
 #pragma unroll
-        for (int j = 0; j < KC; j++)
-#pragma unroll
-            for (int r = 0; r < NLD; r++) dst[j][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, bsrc[r] + (unsigned)(stage * KC + j) * bstride, 0, 0));
-    };
-    auto store_b = [&](int buf, const f32x4 (&src)[KC][NLD]) {
-#pragma unroll
-        for (int j = 0; j < KC; j++)
-#pragma unroll
-            for (int r = 0; r < NLD; r++) Bs[(buf * KC + j) * E + bdst[r]] = src[j][r];
+        for (int ii = 0; ii < NPW; ii++)
+            ci_dma16(wrsrc, bsrc[ii], (unsigned)stage * wstage, Bs + buf * (KC * E) + 64 * (wave + 4 * ii));
     };
     auto read_frags = [&](int buf, int j, int cj, f32x4 (&wf)[NT][2], f32x4 (&af)[RT][2]) {   // [..][0] = hi, [..][1] = lo
 #pragma unroll
@@ -260,61 +272,81 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
             af[rt][1] = arow[rt][cj * 4 + 2];
         }
     };
-    auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2]) {
+    // one chunk's MFMAs in three groups -- 0: w_hi * a_hi of every tile; 1 / 2: (w_hi * a_lo, w_lo * a_hi) of the first / second half of the
+    // tiles -- so that the K loop can place memory instructions between them; per accumulator the order is always hi*hi, hi*lo, lo*hi
+    auto mfma_group = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2], int grp) {
+        constexpr int T = NT * RT, H = (T + 1) / 2;
 #pragma unroll
-        for (int part = 0; part < 2; part++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    const f16x8 whi = __builtin_bit_cast(f16x8, wf[nt][0]), wlo = __builtin_bit_cast(f16x8, wf[nt][1]);
-                    const f16x8 ahi = __builtin_bit_cast(f16x8, a[rt][0]), alo = __builtin_bit_cast(f16x8, a[rt][1]);
-                    if (part == 0) {
-                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[rt][nt], 0, 0, 0);
-                    } else {
-                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[rt][nt], 0, 0, 0);
-                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc[rt][nt], 0, 0, 0);
-                    }
+            for (int rt = 0; rt < RT; rt++) {
+                const int i = nt * RT + rt;
+                if (grp == 1 && i >= H) continue;
+                if (grp == 2 && i < H) continue;
+                const f16x8 whi = __builtin_bit_cast(f16x8, wf[nt][0]), wlo = __builtin_bit_cast(f16x8, wf[nt][1]);
+                const f16x8 ahi = __builtin_bit_cast(f16x8, a[rt][0]), alo = __builtin_bit_cast(f16x8, a[rt][1]);
+                if (grp == 0) {
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc[rt][nt], 0, 0, 0);
+                } else {
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc[rt][nt], 0, 0, 0);
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc[rt][nt], 0, 0, 0);
                 }
+            }
+    };
+    auto mfma_chunk = [&](const f32x4 (&wf)[NT][2], const f32x4 (&a)[RT][2]) {
+        mfma_group(wf, a, 0);
+        mfma_group(wf, a, 1);
+        mfma_group(wf, a, 2);
     };
 
-    // ---- K loop: (tap, chunk group) stages; only the weights are fetched per stage -------------------------
-    f32x4 b_stage[KC][NLD];
+    // ---- K loop: (tap, chunk pair) stages; only the weights are fetched per stage ---------------------------
     int t = t0, cc = 0;
     tap_setup(p.tap[t0]);
     int tp_next = p.tap[t0 + 1 < t1 ? t0 + 1 : t0];
-    load_b(0, b_stage);
-    store_b(0, b_stage);
-    __syncthreads();                                  // images + first weight stage visible
+    dma_stage(0, 0);
+    dma_stage(nstages > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // images + the first two weight stages visible
 #ifdef PNN_CI_DIAG
     const unsigned long long dq1 = __builtin_amdgcn_s_memtime();
 #endif
+    f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
+    read_frags(0, 0, 0, wf0, af0);
+    int buf = 0;
     for (int s = 0; s < nstages; s++) {
-        const int buf = s & 1;
-        const bool more = s + 1 < nstages;
-        load_b(more ? s + 1 : s, b_stage);
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;    // (s+1) % 3, (s+2) % 3
+        mfma_group(wf0, af0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 wf0[NT][2], wf1[NT][2], af0[RT][2], af1[RT][2];
-        read_frags(buf, 0, cc < cpt ? cc : cpt - 1, wf0, af0);
-#pragma unroll
-        for (int j = 0; j < KC; j++) {
-            const int cn = cc + j + 1 < cpt ? cc + j + 1 : cpt - 1;   // tail stage of a one-tap layer: zero weights, any data
-            if (j + 1 < KC) { if (j & 1) read_frags(buf, j + 1, cn, wf0, af0); else read_frags(buf, j + 1, cn, wf1, af1); }
-            if (j & 1) mfma_chunk(wf1, af1); else mfma_chunk(wf0, af0);
-        }
+        read_frags(buf, 1, cc + 1 < cpt ? cc + 1 : cpt - 1, wf1, af1);           // second chunk's fragments under the first chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        store_b(buf ^ 1, b_stage);
-        if (more) {
-            cc += KC;
-            if (cc >= cpt) {                          // wave-uniform: next stage starts the next tap
-                cc = 0;
-                ++t;
-                tap_setup(tp_next);
-                tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
-            }
+        mfma_group(wf0, af0, 1);
+        mfma_group(wf0, af0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave's LDS-DMA of stage s+1 has landed (issued a stage ago), and nobody reads buffer (s-1) % 3 any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cc += KC;
+        if (cc >= cpt && t + 1 < t1) {                // wave-uniform: the next stage starts the next tap
+            cc = 0;
+            ++t;
+            tap_setup(tp_next);
+            tp_next = p.tap[t + 1 < t1 ? t + 1 : t];
         }
-        __syncthreads();
+        // the second chunk's MFMAs with the stage's memory work BETWEEN them: the next stage's first fragments, then the LDS-DMA of
+        // stage s+2 (a wave is held while it issues a 1-KiB vector-memory instruction; with one workgroup per CU nobody else feeds the SIMD)
+        mfma_group(wf1, af1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(buf1, 0, cc < cpt ? cc : cpt - 1, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(wf1, af1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_stage(s + 2 < nstages ? s + 2 : nstages - 1, buf2);                     // (past the end: the last stage again, harmless)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(wf1, af1, 2);
+        buf = buf1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // the epilogue reuses the LDS: every wave done reading, no DMA in flight
 
 #ifdef PNN_CI_DIAG
     __builtin_amdgcn_sched_barrier(0);
@@ -380,7 +412,7 @@ __global__ __launch_bounds__(256) void convimg_sp_kernel(const TapGemmParams p, 
 #ifdef PNN_CI_DIRECT_EPILOGUE   // A/B build: the stores from the accumulator layout
     const bool tile_fits = false;
 #else
-    const bool tile_fits = (size_t)BM * OPP <= (size_t)2 * KC * E + (size_t)G * NPIN * PITCH + ZP;
+    const bool tile_fits = (size_t)BM * OPP <= (size_t)kCiRing * KC * E + (size_t)G * NPIN * PITCH + ZP;
 #endif
     if constexpr (WN == 1 && NT == 2) {
     if (p.k1) {
@@ -543,7 +575,7 @@ TileCfg convimg_sp_cfg(int idx) { return kCfgsCi[idx]; }
 bool convimg_sp_can_fuse_first(const TapGemmParams& p, const TileCfg& t, int G, int s0, int k0)
 {
     const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
-    const size_t scratch_floats = 2 * (size_t)t.kc * 4 * bn * 4;               // the weight staging area
+    const size_t scratch_floats = kCiRing * (size_t)t.kc * 4 * bn * 4;         // the weight staging area
     const size_t ph = (size_t)(p.IH - 1) * s0 + k0, pw = (size_t)(p.IW - 1) * s0 + k0;
     return (k0 == 3 || k0 == 5) && (p.Cin == 32 || p.Cin == 64) && (size_t)G * ph * pw <= scratch_floats;
 }
@@ -563,7 +595,7 @@ bool convimg_sp_can_fuse_last(const TapGemmParams& p, const TileCfg& t, int G, c
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G)
 {
     const size_t bn = 32 * (size_t)t.nt * (4 / t.wm);
-    const size_t slots = 2 * (size_t)t.kc * 4 * bn + (size_t)G * p.IH * p.IW * ((size_t)(p.Cin >> 2) + 1) + (size_t)(p.Cin >> 2) + 16;   // weights | images | zero region
+    const size_t slots = kCiRing * (size_t)t.kc * 4 * bn + (size_t)G * p.IH * p.IW * ((size_t)(p.Cin >> 2) + 1) + (size_t)(p.Cin >> 2) + 16;   // weights | images | zero region
     return slots * 16;
 }
 

@@ -49,6 +49,7 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
     assert starts, "no offload bundle in .hip_fatbin"
     n_objects = n_mfma = 0
+    kernels_seen = set()
     for i, a in enumerate(starts):
         piece = str(tmp_path / ("bundle%d.bin" % i))
         open(piece, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
@@ -62,7 +63,13 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         n_mfma += len(re.findall(r"\bv_mfma_", asm))
         bad = sorted(set(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", asm)))
         assert not bad, "code object %d contains %s" % (i, bad)
+        kernels_seen.update(re.findall(r"<_ZN3pnn\d+([a-z_0-9]+?)(?:I|E)", asm))
     assert n_objects >= 5 and n_mfma > 1000           # really looked at the kernels
+    # every kernel family has device code in the shipped library: hipcc once emitted a host object WITHOUT its .hip_fatbin section,
+    # with exit code 0 (an LDS-DMA builtin called straight from a lambda inside a __global__ template, pnn_convimg_sp.hip)
+    for family in ("tapgemm_f32_kernel", "tapgemm_ring_kernel", "convimg_sp_kernel", "tapgemm_sp_kernel", "tapgemm_small_kernel", "tapgemm_kernel",
+                   "conv_cin1_kernel", "merger_mfma_kernel", "tconv_cout1_mfma_kernel", "fuse_reduce_kernel", "fc_out_f32_kernel", "block_cost_kernel"):
+        assert any(k.startswith(family) for k in kernels_seen), "no device code for %s in %s" % (family, _lib.LIB_PATH)
 
 
 def test_every_option_is_documented_in_the_header():
