@@ -476,6 +476,32 @@ def hm_campaigns(which, devices, quick=False, pictures="synthetic", cpu_leg=True
     return out
 
 
+def natural_pred_psnr(device):
+    """BASELINE.json's "pred-PSNR delta vs ref" where it means something: the reference's two TRAINED checkpoints (convolutional 4x4 / 8x8,
+    tests/golden/conv{4,8}_single.pnnw) on 2500 natural contexts per width (tests/golden/natural_luma.npz), prediction PSNR
+    (tools/tools.py:364-401) against the blocks they predict -- the HIP path on both arithmetics beside the oracle."""
+    from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork, weights as wts
+    from oracle import pnn_oracle as O
+    from tests import test_natural as tn, util
+    out = {}
+    for w in (4, 8):
+        flat, _, _ = wts.load_pnnw(os.path.join(ROOT, "tests", "golden", "conv%d_single.pnnw" % w))
+        a8, l8, tgt = tn.natural_contexts(w, tn.N_CONTEXTS)
+        above = a8.astype(np.float32) - np.float32(util.MEAN)
+        left = l8.astype(np.float32) - np.float32(util.MEAN)
+        want = O.epilogue(O.conv_forward(flat, w, above, left), util.MEAN)
+        rec = {"contexts": int(tn.N_CONTEXTS), "oracle_db": tn.psnr(want, tgt)}
+        for arith, precision in (("f32", 0), ("split", 1)):
+            net = PredictionNeuralNetwork(tn.N_CONTEXTS, w, False, params=flat, device=device)
+            net.set_option("precision", precision)
+            got = net.predict_pel(above, left)
+            net.close()
+            rec[arith + "_db"] = tn.psnr(got, tgt)
+            rec[arith + "_max_abs_lsb_vs_oracle"] = int(np.abs(got.astype(np.int64) - want).max())
+        out[str(w)] = rec
+    return out
+
+
 def _r(x, nd=4):
     """Rounded to `nd` significant digits (the line is read by people and by a 4 KB tail buffer)."""
     if x is None or isinstance(x, (str, bool, int)):
@@ -491,7 +517,7 @@ def compact(res):
 
 
 def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=None, cpu=None, cpu_conv16=None, detail_file=None, extra_config=None,
-               rccl_ranks_seen=None):
+               rccl_ranks_seen=None, natural=None):
     """The ONE JSON line of rank 0 (< LINE_LIMIT bytes).  `main_res` / `fast` / `per_width[name][arith]` are measure() results."""
     rf = main_res["roofline"]
     out = {
@@ -533,6 +559,8 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
             tab[str(w)] = row
         out["per_width"] = tab
         out["per_width_note"] = "f32 frac vs 157.3, split frac vs 2500/3 TFLOP/s; frac = dominant GEMM kernel, pass_frac = whole step; conv FLOPs count padding taps"
+    if natural:
+        out["natural_pred_psnr_db"] = {w: {"gpu_f32": _r(v.get("f32_db"), 5), "gpu_split": _r(v.get("split_db"), 5), "oracle": _r(v.get("oracle_db"), 5)} for w, v in natural.items()}
     if rccl_ranks_seen is not None:
         out["rccl_ranks_seen"] = rccl_ranks_seen
     if detail_file:
@@ -659,6 +687,14 @@ def main():
                 torch.cuda.empty_cache()
         detail["per_width"] = per_width
         detail["fast_arithmetic"] = fast
+    natural = None
+    if rank == 0 and single and not args.no_extras:
+        try:
+            natural = natural_pred_psnr(local_rank)
+        except Exception as e:                        # noqa: BLE001 -- fixtures absent / anything else: the kernel line must survive
+            natural = None
+            detail["natural_pred_psnr_error"] = repr(e)[:500]
+        detail["natural_pred_psnr"] = natural
     if rank == 0 and single and not args.no_extras and not args.no_live_traffic:
         lt = live_traffic(args.workload, wl.batch, precision)
         detail["live_traffic"] = lt
@@ -680,7 +716,7 @@ def main():
             sys.stderr.write("bench.py: cannot write %s: %s\n" % (args.detail_file, e))
             dfile = None
         print(build_line(main_res, world, args.steps, args.warmup, wl.cfg_name, fast, per_width, cpu, cpu16, dfile,
-                         {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"} if share else None, ranks_seen))
+                         {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"} if share else None, ranks_seen, natural))
         sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()

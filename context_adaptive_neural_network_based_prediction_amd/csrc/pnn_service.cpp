@@ -148,7 +148,9 @@ namespace {
 // Requests and replies carry a client ID, never a file descriptor (a dropped client's descriptor may be reused at once).
 struct Server {
     pnn_service_backend backend;
-    void* users[5];
+    static constexpr int kMaxRep = 4;
+    void* users[5][kMaxRep];       // backend handle of worker k, replica r
+    int nrep = 1;                    // replicas per worker queue (pnn_service_run_table: contexts per width, PNN_SERVICE_REPLICAS)
     int nworkers;                    // 1: one worker serves every width (a single context is not shared between threads); 5: one per width
     int max_batch, window_us;
     volatile int* stop;
@@ -189,7 +191,7 @@ struct Server {
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
     int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
 
-    void worker(int k)
+    void worker(int k, int r)
     {
         std::vector<Req> batch;
         std::vector<float> above, left, out;
@@ -235,9 +237,9 @@ struct Server {
             if (any_pel) dst.resize(n * w2);
             if (any_f32) out.resize(n * w2);
             const auto tb0 = Clock::now();
-            const int rc = backend(users[nworkers == 1 ? 0 : k], w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
+            const int rc = backend(users[nworkers == 1 ? 0 : k][r], w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
                                    any_f32 ? out.data() : nullptr);
-            busy_s[k] += std::chrono::duration<double>(Clock::now() - tb0).count();
+            const double busy = std::chrono::duration<double>(Clock::now() - tb0).count();
             std::vector<Reply> replies(n);
             for (size_t i = 0; i < n; i++) {
                 const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
@@ -261,7 +263,7 @@ struct Server {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
-                ++calls_w[k]; served_w[k] += (long)n;
+                ++calls_w[k]; served_w[k] += (long)n; busy_s[k] += busy;
             }
             const char one = 1;
             for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t][1], &one, 1);
@@ -519,7 +521,8 @@ struct Server {
             epoll_ctl(eps[0], EPOLL_CTL_ADD, lfd, &ev);
         }
         std::vector<std::thread> threads;
-        for (int k = 0; k < nworkers; k++) threads.emplace_back([this, k] { worker(k); });
+        for (int k = 0; k < nworkers; k++)
+            for (int r = 0; r < nrep; r++) threads.emplace_back([this, k, r] { worker(k, r); });
         std::vector<std::thread> io;
         for (int t = 1; t < nio; t++) io.emplace_back([this, t, lfd, &eps] { io_loop(t, lfd, eps[t]); });
         io_loop(0, lfd, eps[0]);                     // the calling thread: listener + its share of the connections
@@ -550,7 +553,7 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     if (!backend || !stop || max_batch < 1 || window_us < 0) return PNN_E_ARG;
     Server sv;
     sv.backend = backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
-    for (void*& u : sv.users) u = user;
+    for (auto& ur : sv.users) for (void*& u : ur) u = user;
     sv.nio = 2;
     return sv.run(socket_path, stats);
 }
@@ -562,7 +565,7 @@ int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int wi
     if (!ctx || !stop || max_batch < 1 || window_us < 0) return PNN_E_ARG;
     Server sv;
     sv.backend = ctx_backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
-    for (void*& u : sv.users) u = ctx;
+    for (auto& ur : sv.users) for (void*& u : ur) u = ctx;
     for (int k = 0; k < 5; k++) {
         int is_fc = 0;
         sv.kind[k] = pnn_model_info(ctx, kServiceWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
@@ -574,7 +577,12 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
                           int window_us, volatile int* stop, long* stats)
 {
     if (!stop || max_batch < 1 || window_us < 0 || !model_table_path) return PNN_E_ARG;
-    // one context per width, each with that width's model only: five worker threads, five streams on one GPU
+    // One context per width, each with that width's model only: five worker threads, five streams on one GPU.
+    // PNN_SERVICE_REPLICAS = R (1 .. 4) makes it R contexts and workers per width taking alternate batches -- built in round 4 because
+    // the 4x4 / 8x8 workers are busy 4.2 s of a 4.9 s Kodak-size campaign (a single-block call is a chain of dependent launches of
+    // ~45 us whatever its batch), measured, and left OFF: with 2 / 3 replicas a call takes 61 / 81 us instead of 43 (ten or fifteen host
+    // threads launching tiny kernels contend in the runtime and on the device's queues) and the campaign 5.68 / 6.22 s instead of 5.12
+    // (configs[4]: 6.97 / 8.07 instead of 5.69); same bitstreams in every case (a block's prediction does not depend on its batch).
     int widths[64], pairs[64], chans[64];
     const char* paths[64];
     const int n = pnn_parse_model_table(model_table_path, widths, pairs, chans, paths, 64);
@@ -585,7 +593,9 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     std::string dir(model_table_path);
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    pnn_ctx* ctxs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int nrep = 1;
+    if (const char* e = getenv("PNN_SERVICE_REPLICAS")) nrep = std::max(1, std::min(Server::kMaxRep, atoi(e)));
+    pnn_ctx* ctxs[5][Server::kMaxRep] = {};
     static const int kWidths[5] = {4, 8, 16, 32, 64};
     int rc = PNN_OK;
     for (int k = 0; k < 5 && rc == PNN_OK; k++) {
@@ -597,23 +607,25 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             FILE* f = fopen((dir + "/" + p).c_str(), "rb");
             if (f) { fclose(f); p = dir + "/" + p; }
         }
-        rc = pnn_create_empty(&ctxs[k], mean, device);
-        if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k], p.c_str());
-        // the file must hold a model of the width its table row names (pnn_create's check)
-        if (rc == PNN_OK && pnn_model_info(ctxs[k], kWidths[k], nullptr, nullptr, nullptr) != PNN_OK) rc = PNN_E_MODEL;
+        for (int r = 0; r < nrep && rc == PNN_OK; r++) {
+            rc = pnn_create_empty(&ctxs[k][r], mean, device);
+            if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
+            // the file must hold a model of the width its table row names (pnn_create's check)
+            if (rc == PNN_OK && pnn_model_info(ctxs[k][r], kWidths[k], nullptr, nullptr, nullptr) != PNN_OK) rc = PNN_E_MODEL;
+        }
     }
     if (rc == PNN_OK) {
         Server sv;
-        sv.backend = ctx_backend; sv.nworkers = 5; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+        sv.backend = ctx_backend; sv.nworkers = 5; sv.nrep = nrep; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
         sv.nio = 4;                                  // socket threads (PNN_SERVICE_IO_THREADS overrides)
         for (int k = 0; k < 5; k++) {
-            sv.users[k] = ctxs[k];
+            for (int r = 0; r < sv.nrep; r++) sv.users[k][r] = ctxs[k][r];
             int is_fc = 0;
-            sv.kind[k] = pnn_model_info(ctxs[k], kWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
+            sv.kind[k] = pnn_model_info(ctxs[k][0], kWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
         }
         rc = sv.run(socket_path, stats);
     }
-    for (pnn_ctx* c : ctxs) if (c) pnn_destroy(c);
+    for (auto& cr : ctxs) for (pnn_ctx* c : cr) if (c) pnn_destroy(c);
     return rc;
 }
 

@@ -644,12 +644,13 @@ def test_bench_line_fits_the_driver_tail_buffer():
     per_width = {n: {"f32": _canned_measurement(n, 0), "split": _canned_measurement(n, 1)} for n in bench.PER_WIDTH}
     cpu = {"value": 12345.678901, "unit": "blocks/s", "cores": 64, "host_cores": 256, "kind": "port", "value_leg": "torch_cpu_batched",
            "batch1_value": 234.5678901, "batch1_leg": "torch_cpu_batch1", "batch1_cores": 8, "sample": "x" * 600, "legs": {"bulk": "y" * 5000}}
+    natural = {w: {"contexts": 2500, "oracle_db": 24.9501234567, "f32_db": 24.9501234567, "split_db": 24.9498765432, "f32_max_abs_lsb_vs_oracle": 1} for w in ("4", "8")}
     line = bench.build_line(main, 8, 20, 5, bench.WORKLOADS["fc8"][3], fast, per_width, cpu, dict(cpu), "bench_detail.json",
-                            {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"}, {"backend": "nccl", "world_size": 8, "devices": 8})
+                            {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"}, {"backend": "nccl", "world_size": 8, "devices": 8}, natural)
     assert len(line) < bench.LINE_LIMIT and "\n" not in line, len(line)
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "fast_arithmetic", "per_width", "rccl_ranks_seen"):
+              "roofline", "cpu_baseline", "fast_arithmetic", "per_width", "rccl_ranks_seen", "natural_pred_psnr_db"):
         assert k in d, k
     assert d["dtype"] == "f32" and d["n_gpus"] == 8 and d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "flops_per_launch", "avg_launch_us"):
