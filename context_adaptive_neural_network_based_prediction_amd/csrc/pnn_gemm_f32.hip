@@ -477,7 +477,12 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     if (!fuse && p0.pm_groups >= 0 && p0.SH * p0.SW > 1 && (p0.pm_groups == 1 || (nblk + bm - 1) / bm * bm * 100 <= nblk * 115)) {
         TapGemmParams q = p0;
         q.W2p = nullptr;                              // (the planner reads the fused-layer field of the ring kernel's launches)
-        const PmPlan& plan = position_major_plan(q, 128 * RT, 32 * NT, KC, tapgemm_f32_lds_bytes(t, false));
+        // a block group's input maps may exceed an XCD's 4 MB L2 here (the split kernels' planner stops at 4.5 MB): at a third of their
+        // matrix rate the taps' re-reads that spill to the MALL are covered.  Same-box sweep, conv 16x16 f32 at batch 1024: limit 4.5 MB
+        // 0.778 ms, 7 MB (lets the 8x24x64 maps of the two biggest layers in: 6.3 MB per group) 0.742-0.746, 12 MB 0.737-0.749;
+        // conv 32x32 at batch 256: 1.089 / 1.077-1.083 / 1.128-1.130 ms
+        static const double l2_mb = getenv("PNN_F32_PM_L2_MB") ? atof(getenv("PNN_F32_PM_L2_MB")) : 7.0;
+        const PmPlan& plan = position_major_plan(q, 128 * RT, 32 * NT, KC, tapgemm_f32_lds_bytes(t, false), l2_mb);
         if (plan.use) {
             p.pm_groups = plan.groups;
             p.nblk = p0.M / (p0.SH * p0.SW);

@@ -806,7 +806,7 @@ double list_schedule(const std::vector<double>& cost, int slots)
     return end;
 }
 
-PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_t lds)
+PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_t lds, double l2_mb)
 {
     PmPlan plan;
     const int SP = p.SH * p.SW, ntaps = p.tap_begin[p.ncls];
@@ -839,7 +839,7 @@ PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_
     }
     plan.groups = (int)groups;
     if (p.pm_groups == 1) { plan.use = true; return plan; }
-    if ((double)BM * p.IH * p.IW * p.Cin * 4.0 > 4.5 * 1048576.0) return plan;   // a block group's input against the 4 MB L2 of an XCD
+    if ((double)BM * p.IH * p.IW * p.Cin * 4.0 > l2_mb * 1048576.0) return plan;   // a block group's input against the 4 MB L2 of an XCD (l2_mb: 4.5 for the split kernels; the f32 kernel, a third of their matrix rate, tolerates maps that spill to the MALL)
     const int slots = 256 * (lds <= 80 * 1024 ? 2 : 1);
     const int spt = p.Cin / 16 / KC, gy = (p.Cout + BN - 1) / BN;
     std::vector<double> bm, pm;
@@ -857,17 +857,17 @@ PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_
 }  // namespace
 
 // the plan of a launch shape is computed once per thread (a few microseconds of host time otherwise, per launch)
-const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds)
+const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds, double l2_mb)
 {
     typedef std::array<int, 14> Key;
     thread_local std::map<Key, PmPlan> plans;
     int taps_hash = 0;
     for (int t = 0; t < p.tap_begin[p.ncls]; t++) taps_hash = taps_hash * 31 + p.tap[t];
-    const Key key = {p.M, p.SH, p.SW, p.IH, p.IW, p.Cin, p.Cout, p.a, p.ncls, taps_hash, BM, BN, KC * 4 + (p.pm_groups + 1), (int)(lds >> 10)};
+    const Key key = {p.M, p.SH, p.SW, p.IH, p.IW, p.Cin, p.Cout, p.a, p.ncls, taps_hash, BM, BN, KC * 4 + (p.pm_groups + 1), (int)(lds >> 10) + 1024 * (int)(l2_mb * 8.0)};
     auto it = plans.find(key);
     if (it == plans.end()) {
         if (plans.size() >= 4096) plans.clear();     // a caller that never repeats a batch size: start over rather than grow
-        it = plans.emplace(key, plan_position_major(p, BM, BN, KC, lds)).first;
+        it = plans.emplace(key, plan_position_major(p, BM, BN, KC, lds, l2_mb)).first;
     }
     return it->second;
 }

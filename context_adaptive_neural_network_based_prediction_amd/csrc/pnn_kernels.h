@@ -116,7 +116,7 @@ hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s); 
 // groups, and the position order (pnn_gemm_ring.hip; shared by the ring kernel and tapgemm_f32_kernel).  p.pm_groups on entry:
 // -1 never, 1 whenever possible, 0 by the planner's list-scheduling model.
 struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; };
-const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds);
+const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds, double l2_mb = 4.5);
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);
 size_t convimg_sp_lds_bytes(const TapGemmParams& p, const TileCfg& t, int G);
