@@ -888,7 +888,8 @@ static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
     TapGemmParams q = p;
     q.pm_groups = 0;
     if (!FUSE && p.pm_groups >= 0 && p.SH * p.SW > 1) {
-        const PmPlan& plan = position_major_plan(p, BM, BN, KC, lds);
+        static const double l2_mb = getenv("PNN_RING_PM_L2_MB") ? atof(getenv("PNN_RING_PM_L2_MB")) : 4.5;   // (round 4 re-check at 7 MB, which the f32 kernel takes: see NOTES.md)
+        const PmPlan& plan = position_major_plan(p, BM, BN, KC, lds, l2_mb);
         if (plan.use) {
             q.pm_groups = plan.groups;
             q.nblk = p.M / (p.SH * p.SW);
