@@ -48,6 +48,7 @@ SIGNATURES = {
     "pnn_mean": (ctypes.c_float, [vp]),
     "pnn_set_option": (ci, [vp, ctypes.c_char_p, ctypes.c_long]),
     "pnn_num_split_configs": (ci, []),
+    "pnn_num_f32_configs": (ci, []),
     "pnn_check_range": (ci, [vp, vp, ctypes.POINTER(ctypes.c_long)]),
     "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),

@@ -318,6 +318,7 @@ int pnn_model_info(const pnn_ctx* c, int width, int* is_fc, int* n_layers, long*
 }
 
 int pnn_num_split_configs(void) { return tapgemm_sp_num_cfgs() + convimg_sp_num_cfgs() + tapgemm_ring_num_cfgs(); }
+int pnn_num_f32_configs(void) { return tapgemm_f32_num_cfgs(); }
 
 int pnn_set_option(pnn_ctx* c, const char* name, long value)
 {

@@ -144,6 +144,8 @@ int pnn_check_range(pnn_ctx* ctx, void* stream, long* host_fallbacks);
 
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
 int pnn_num_split_configs(void);
+/* Number of configuration codes "f32_cfg" accepts (tiles of tapgemm_f32_kernel; all of them give the same bits). */
+int pnn_num_f32_configs(void);
 /* Hits / misses of the "cache_mb" prediction cache since the option was last set. */
 int pnn_cache_stats(pnn_ctx* ctx, long* hits, long* misses);
 

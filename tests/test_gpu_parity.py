@@ -355,7 +355,8 @@ def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, i
     run = (lambda: net.predict(util.flatten_fc(above, left))) if is_fc else (lambda: net.predict(above, left))
     net.set_option("ring_pm", 0)
     want = run()
-    for cfg in range(-1, 14):
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    for cfg in range(-1, _lib.lib().pnn_num_f32_configs()):
         net.set_option("f32_cfg", cfg)
         for mode in (0, 2, 1):
             net.set_option("ring_pm", mode)

@@ -25,7 +25,7 @@ def step():
     if rc: raise RuntimeError(wl.L.pnn_last_error(net.ctx))
 ref = None
 cases = [("round-1 kernels", {"f32_kernel": 0}), ("rule", {"f32_kernel": 1, "autotune": 0, "f32_cfg": -1}), ("autotuned", {"autotune": 1})]
-cases += [("f32_cfg %%d" %% i, {"autotune": 0, "f32_cfg": i}) for i in range(int(os.environ.get("F32_NCFG", "14")))]
+cases += [("f32_cfg %%d" %% i, {"autotune": 0, "f32_cfg": i}) for i in range(wl.L.pnn_num_f32_configs())]
 for label, opts in cases:
     for k, v in opts.items():
         net.set_option(k, v)
