@@ -298,7 +298,7 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
                       "blocks_per_s_spread": [per_call / float(np.max(ts)), per_call / float(np.min(ts))]}))   # slowest / fastest run of this leg
 
 
-def cpu_legs(workload, budget_s=2.0, full=False):
+def cpu_legs(workload, budget_s=1.5, full=False):
     """the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
     an independent PyTorch-CPU formulation (oneDNN / MKL), each batched (the GPU batch where the oracle finishes it in seconds)
     and at batch 1 sequential (what HM does per TB).  Bounded samples: every leg runs for about `budget_s` in its own process.
