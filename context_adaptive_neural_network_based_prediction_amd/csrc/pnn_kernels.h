@@ -142,7 +142,7 @@ hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
 // fuse: apply the output layer p.W2p (f32 pack, <= 64 outputs) to the activated tile, partial sums to p.part[column tile][M][64]
 int tapgemm_f32_num_cfgs();
 TileCfg tapgemm_f32_cfg(int idx);
-size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse);
+size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse, bool row_out = false);   // row_out: an FC layer's f32 output leaves through an LDS tile
 bool tapgemm_f32_can_fuse(int idx);
 hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStream_t s);
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
