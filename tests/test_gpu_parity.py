@@ -1049,6 +1049,31 @@ def test_one_summation_order_at_every_batch_size(pnn, precision, w, is_fc, big):
                           net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))[2])
 
 
+@pytest.mark.parametrize("w,is_fc,big", [(4, True, 2600), (8, True, 2300), (4, False, 1500), (8, False, 1300), (16, False, 520), (32, False, 150), (64, False, 36)])
+def test_random_batch_sizes_keep_the_bits(pnn, oracle, precision, w, is_fc, big):
+    """A seeded walk over batch sizes and offsets -- ragged row tiles, ragged position-major block groups, the FC output layer fused
+    (>= 1024 blocks) and from stored activations, chunked passes (max_chunk) -- on both arithmetics: every sub-batch must reproduce,
+    bit for bit, the rows it has inside the big batch, and the big batch must match the oracle."""
+    params = util.make_params(w, is_fc, 211, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, big, 212)
+    net = pnn.PredictionNeuralNetwork(big, w, is_fc, params=params)
+    net.set_option("canonical_order", 1)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    full = run(above, left)
+    m = min(big, 64 if w <= 16 else 12)
+    ref = oracle.fc_forward(params, w, util.flatten_fc(above[:m], left[:m])) if is_fc else oracle.conv_forward(params, w, above[:m], left[:m])
+    np.testing.assert_allclose(full[:m, ..., 0], ref, rtol=0, atol=FLOAT_ATOL)
+    rng = np.random.RandomState(213 + w)
+    sizes = sorted(set([1, 2, 31, 32, 33, 127, 128, 129, big - 1] + [int(x) for x in rng.randint(1, big, 8)]))
+    for n in [x for x in sizes if 0 < x <= big]:
+        lo = int(rng.randint(0, big - n + 1))
+        got = run(above[lo:lo + n], left[lo:lo + n])
+        assert np.array_equal(got, full[lo:lo + n]), "%d blocks at offset %d differ from the same rows of the batch of %d" % (n, lo, big)
+    net.set_option("max_chunk", max(1, big // 3 + 1))                # three passes per call
+    assert np.array_equal(run(above, left), full)
+    net.close()
+
+
 def test_tf_compat_session_run(pnn, oracle, tmp_path):
     """The TensorFlow-look-alike session API of include/pnn_tf_compat.h (what HM's C++ calls) against the oracle."""
     import subprocess
