@@ -317,6 +317,9 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
 #endif
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // (the last stages' refills -- re-fetches of the last stage, never read -- must have landed before this wave may end: an LDS-DMA
+    // still in flight would write into LDS that the next workgroup on this CU already owns; issued a chunk or more ago, so no wait in practice)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int py = p.py[cls], px = p.px[cls];
     f32x4 bvs[NT][4];                                // all bias loads before the first store (see pnn_gemm_sp.hip)
 #pragma unroll
