@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
         const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2p, 0, (unsigned)p.K2chunks * 4u * (unsigned)p.Npad2 * 16u, 0x00020000);
         for (int r = wave; r < W2R; r += 4) dma16(w2rsrc, (unsigned)(((n0 >> 2) + r) * p.Npad2 + lane) << 4, 0, W2s + r * 64);
     }
-    wait_vm_le<0>();
+    static_assert(!FUSE || W2R % 4 == 0, "every wave fetches the same number of rows of the output layer's tile");
+    wait_vm_le<NPW + (FUSE ? W2R / 4 : 0)>();        // stage 0 and its activations; stage 1 (and the tile behind it) is waited for where stage 0 ends
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) read_wf(0, 0, nt, wf0);
@@ -295,14 +296,45 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
 #ifdef PNN_F32_DIAG
     dq1 = __builtin_amdgcn_s_memtime();
 #endif
+    // the LAST stage: nothing left to fetch, and only its live chunks run -- the zero-padded chunks that fill the stage (K = 1200:
+    // chunk 76 of 75) would add exact zeros for 2560 cycles each
+    auto tail = [&](int buf, f32x4 (&acur)[KC][RT][2], int nlive) {
+#pragma unroll
+        for (int j = 0; j < KC; j++) {
+            if (j >= nlive) break;
+            f32x4 (&wc)[NT][2] = (j & 1) ? wf1 : wf0;
+            f32x4 (&wn)[NT][2] = (j & 1) ? wf0 : wf1;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nt][e >> 2][e & 3], acur[j][rt][e >> 2][e & 3], acc[rt][nt], 0, 0, 0);
+                        const int sl = (e * NT + nt) * RT + rt;
+                        constexpr int nops = 2 * NT;
+                        const int k = (sl * nops + SLOTS - 1) / SLOTS;
+                        if (j + 1 < KC && k < nops && k * SLOTS / nops == sl)
+                            wn[k >> 1][k & 1] = lds[buf * SE + (j + 1) * E + (2 * h + (k & 1)) * BN + (k >> 1) * 32 + l31];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+    };
+    const int nlive = nchunks - (nstages - 1) * KC;
     int s = 0, buf = 0;
-    for (; s + 1 < nstages; s += 2) {
+    for (; s + 2 < nstages; s += 2) {
         stage(buf, a0, a1);
         buf = buf == 2 ? 0 : buf + 1;
         stage(buf, a1, a0);
         buf = buf == 2 ? 0 : buf + 1;
     }
-    if (s < nstages) stage(buf, a0, a1);
+    if (s + 1 < nstages) {
+        stage(buf, a0, a1);
+        buf = buf == 2 ? 0 : buf + 1;
+        tail(buf, a1, nlive);
+    } else {
+        tail(buf, a0, nlive);
+    }
 #ifdef PNN_F32_DIAG
     dq2 = __builtin_amdgcn_s_memtime();
     auto diag_out = [&]() {
@@ -320,6 +352,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     // (the last stages' refills -- re-fetches of the last stage, never read -- must have landed before this wave may end: an LDS-DMA
     // still in flight would write into LDS that the next workgroup on this CU already owns; issued a chunk or more ago, so no wait in practice)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FUSE && nstages < 2) __builtin_amdgcn_s_barrier();   // no stage ran its barrier behind the prologue's fetches: the output layer's tile is whole only now
     const int py = p.py[cls], px = p.px[cls];
     f32x4 bvs[NT][4];                                // all bias loads before the first store (see pnn_gemm_sp.hip)
 #pragma unroll
@@ -375,7 +408,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     // point at the same moment (20 MB through the write path at once); transposed through a wave-private LDS tile (the ring is dead)
     // consecutive lanes store consecutive pieces of a row.  Same-box A/B: FC 8x8 f32 at batch 4096 0.2312 -> 0.2295 ms, FC 4x4
     // 0.2114 -> 0.2107; convolution layers (several co-resident workgroups, epilogues already staggered) lost 0.7 % and keep the
-    // direct stores.
+    // direct stores.  The stores go THROUGH L2 (store16_through, pnn_device_common.h: the next layer's workgroups run on other XCDs, and
+    // what is written through early is not left for the end-of-kernel write-back): FC 8x8 0.2277 -> 0.2256 ms, FC 4x4 0.2074 -> 0.2051.
     constexpr int TP = BN / 4 + 1;                   // tile row pitch in 16-byte pieces (+1: conflict-free for both accesses)
     if (kCoalescedOut && p.Y && !p.Yi && SP == 1) {      // launch-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -398,7 +432,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
 #pragma unroll 4
         for (int i = lane; i < 32 * RT * (BN / 4); i += 64) {
             const int row = i / (BN / 4), col = i - row * (BN / 4);
-            if (row < rows && nq0 + col < cq) yo[(size_t)row * cq + col] = tile[row * TP + col];
+            if (row < rows && nq0 + col < cq) store16_through(yo + (size_t)row * cq + col, tile[row * TP + col]);
         }
         diag_out();
         return;
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
                 if (n < p.Cout) {
                     f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} + bvs[nt][g];
                     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;
+                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;    // (through L2 like the FC rows: conv 16x16 pass 0.7215 -> 0.7330 ms)
                     if (p.Yi) {
                         int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
                         *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;

@@ -108,7 +108,8 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         if (next) { q.W2p = next->d_w; q.Npad2 = next->proto.Npad; q.K2chunks = next->proto.chunk_begin[1]; q.part = part; }
         q.Xlo = c->stage_tbs.p;
         HIPCHK(c, hipMemset(c->stage_tbs.p, 0, (size_t)16 << 20));
-        for (int rep = 0; rep < 3; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg, next != nullptr, s));
+        for (int rep = 0; rep < 400; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg, next != nullptr, s));   // back to back: the stamps that
+                                                                                           // stay are the last launch's, at the steady-state clock
         HIPCHK(c, hipStreamSynchronize(s));
         const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls;
         std::vector<unsigned long long> hbuf(8 * nwg);
