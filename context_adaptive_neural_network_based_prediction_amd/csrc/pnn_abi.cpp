@@ -293,6 +293,7 @@ void pnn_destroy(pnn_ctx* c)
     for (DevBuf& b : c->stage_in) if (b.p) (void)hipFree(b.p);
     for (DevBuf& b : c->stage_out) if (b.p) (void)hipFree(b.p);
     if (c->stage_tbs.p) (void)hipFree(c->stage_tbs.p);
+    for (auto& b : c->seg_part) if (b.p) (void)hipFree(b.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_done) (void)hipFree(c->d_done);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }

@@ -50,6 +50,10 @@ struct GemmLayer {                                    // one tap-GEMM launch (al
     float sp_inv_scale = 1.f;
     float* d_bias = nullptr;
     double k_total = 0;                               // sum over classes of taps * Cin
+    // Exact-f32 path: the canonical per-output summation order of a DEEP convolution layer is a sum of nseg K segments (each
+    // class's taps dealt in order over the segments; within a segment the sequential chain of tapgemm_f32_kernel), added in
+    // order, then bias and activation.  A property of the layer (pnn_model.cpp), the same at every batch size and tile.
+    int nseg = 1;
     long out_per_block = 0;                           // output floats per block
 };
 struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_w_sp = nullptr; float sp_inv_scale = 1.f; int npad = 0; float* d_bias = nullptr; long out_per_block = 0; };
@@ -87,6 +91,7 @@ struct pnn_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     pnn::DevBuf stage_in[2], stage_out[2], stage_tbs;
+    pnn::DevBuf seg_part[2];                               // K-segment partial sums of the exact-f32 conv layers: main stream / side stream
     // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
     // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.
     struct CacheEntry { uint64_t hash = 0; bool valid = false; std::vector<float> in, out; std::vector<int32_t> pel; };

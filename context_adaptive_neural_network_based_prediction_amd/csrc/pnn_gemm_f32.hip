@@ -5,7 +5,16 @@
 // i.e. the FC layers, convolutions and transposed convolutions of pnn/components.py:10-261 in the REFERENCE's arithmetic
 // (IEEE float32 products, float32 accumulation: pnn/tfutils.py:107-139, components.py:169-176).  Same per-output summation order
 // as tapgemm32_kernel (16-deep chunks in K order; MFMA step e of a chunk adds x[8h + e] * w[8h + e] for the two k-halves h),
-// so every tile of either kernel gives the same bits: this is the canonical f32 order of the library.
+// so every tile of either kernel gives the same bits: this is the canonical f32 order of the library -- for a layer whose deepest
+// class stays under kSegMinDepth.  A DEEPER convolution layer is summed in K segments (GemmLayer::nseg, pnn_model.cpp: whole taps, at
+// most kSegDepth deep): grid z = class * nseg + segment, a workgroup walks its segment's taps only and leaves its raw sums in plane
+// `segment` of a partial buffer; seg_reduce_kernel adds the planes in order, then bias and LeakyReLU.  That is the layer's order at
+// EVERY batch size and tile (the bit-identity tests cover the 32x32 and 64x64 nets, which have such layers).  Why: a chain of K / 2
+// dependent 64-cycle MFMAs per output is a latency no tiling hides -- the 6400-deep third layer of the 64x64 net took 185 us at batch
+// 64 on 192 workgroups (1536 wave tiles on 1024 SIMDs: two rounds for one and a half) and 171 us at batch 1; in four segments 145
+// and 45.  conv 64x64 at batch 64: 46.0 k -> 52.7 k blocks/s, a single-block call 538 -> 347 us; conv 32x32 +2 % / 333 -> 275 us.
+// (tapgemm32_kernel and the other round-1 kernels -- option f32_kernel = 0 -- know no segments: on those layers their sums differ
+// in the last bits.)
 //
 // Why another kernel (tools/mfma_peak.hip, tools/f32_sweep.py; profiles/r04_f32_tile_sweep.txt): the 32x32x2 instruction sustains
 // 154.5 TFLOP/s (0.98 of the 157.3 peak) with one or two waves per SIMD and 124 with four, the 16x16x4 instruction 124-139 with
@@ -76,7 +85,10 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int cls = blockIdx.z;
+    // K segments (p.nseg > 1, never with the fused output layer): z = class * nseg + segment
+    const int nseg = (!FUSE && p.nseg > 1) ? p.nseg : 1;
+    const int cls = nseg > 1 ? (int)blockIdx.z / nseg : (int)blockIdx.z;
+    const int seg = (int)blockIdx.z - cls * nseg;
     const int n0 = blockIdx.y * BN;
     const int m0 = blockIdx.x * BM + wave * (32 * RT);
 #ifdef PNN_F32_DIAG             // diagnostic library only (make diag): cycle stamps of wave 0 -> p.Xlo[workgroup][8]
@@ -95,6 +107,12 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     const int pmg = p.pm_groups;
     int pmi = 0, pmj = 0, mblk = 0;
     unsigned tmask = t1 - t0 >= 32 ? 0xffffffffu : (1u << (t1 - t0)) - 1u;
+    unsigned smask = 0xffffffffu;                    // this segment's taps: the class's taps dealt in order, the first (taps % nseg) segments one more
+    if (nseg > 1) {
+        const int base = (t1 - t0) / nseg, rem = (t1 - t0) - base * nseg;
+        smask = ((1u << (base + (seg < rem ? 1 : 0))) - 1u) << (seg * base + (seg < rem ? seg : rem));
+        tmask &= smask;
+    }
     if (pmg) {
         // launch order: chunks of 8 block groups; within a chunk rank by position rank, the 8 groups side by side -- workgroups
         // i, i + 8, ... run on one XCD, so each XCD walks the positions of ONE group at a time and its L2 keeps that group's maps
@@ -111,7 +129,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
             const int iy = pmi * p.a + (tp >> 16), ix = pmj * p.a + (int)(short)(tp & 0xffff);
             if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) m |= 1u << (t - t0);
         }
-        tmask = m ? m : 1u;                          // no tap inside: one of them fetches zeros
+        m &= smask;
+        tmask = m ? m : (smask & (0u - smask));      // no tap inside: one of them fetches zeros
     }
     auto next_tap = [&](int t) {                     // the next tap that stays after t (class-relative), or t itself at the end
         const unsigned rest = tmask & ~((2u << t) - 1u);
@@ -411,6 +430,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     // direct stores.  The stores go THROUGH L2 (store16_through, pnn_device_common.h: the next layer's workgroups run on other XCDs, and
     // what is written through early is not left for the end-of-kernel write-back): FC 8x8 0.2277 -> 0.2256 ms, FC 4x4 0.2074 -> 0.2051.
     constexpr int TP = BN / 4 + 1;                   // tile row pitch in 16-byte pieces (+1: conflict-free for both accesses)
+    float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     if (kCoalescedOut && p.Y && !p.Yi && SP == 1) {      // launch-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                              // nobody reads the ring any more, no LDS-DMA in flight
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
         __builtin_amdgcn_wave_barrier();              // the tile is this wave's own: LDS keeps a wave's accesses in order
         const int cq = p.Cout >> 2, nq0 = n0 >> 2;
         const int rows = p.M - m0 < 32 * RT ? p.M - m0 : 32 * RT;          // rows of this wave that exist (<= 0: none)
-        f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(p.Y) + (size_t)m0 * cq + nq0;
+        f32x4* __restrict__ yo = reinterpret_cast<f32x4*>(Yo) + (size_t)m0 * cq + nq0;
 #pragma unroll 4
         for (int i = lane; i < 32 * RT * (BN / 4); i += 64) {
             const int row = i / (BN / 4), col = i - row * (BN / 4);
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
                 if (n < p.Cout) {
                     f32x4 v = (f32x4){acc[rt][nt][4 * g], acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]} + bvs[nt][g];
                     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-                    if (p.Y) *reinterpret_cast<f32x4*>(p.Y + obase + n) = v;    // (through L2 like the FC rows: conv 16x16 pass 0.7215 -> 0.7330 ms)
+                    if (p.Y) *reinterpret_cast<f32x4*>(Yo + obase + n) = v;    // (through L2 like the FC rows: conv 16x16 pass 0.7215 -> 0.7330 ms)
                     if (p.Yi) {
                         int4 iv = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
                         *reinterpret_cast<int4*>(p.Yi + obase + n) = iv;
@@ -520,6 +540,29 @@ hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segment
     return hipGetLastError();
 }
 
+// The K segments of a layer, summed in order: Y = act(bias + ((part[0] + part[1]) + ...)), one thread per 4 consecutive channels.
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const float* __restrict__ part, int nseg, size_t n4, size_t stride4, int cq, const float* __restrict__ bias,
+                                                         int act, float* __restrict__ Y)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(part) + i;
+    f32x4 acc = src[0];
+    for (int sgm = 1; sgm < nseg; sgm++) acc += src[(size_t)sgm * stride4];
+    f32x4 v = acc + reinterpret_cast<const f32x4*>(bias)[i % (size_t)cq];
+    if (act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+    reinterpret_cast<f32x4*>(Y)[i] = v;
+}
+
+hipError_t launch_seg_reduce(const float* part, int nseg, size_t n, int Cout, const float* bias, int act, float* Y, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (nseg < 1 || n % 4 || Cout % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    pnn_launch(seg_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, nseg, n4, n4, Cout / 4, bias, act, Y);
+    return hipGetLastError();
+}
+
 // {rt, nt, kc, fuse-capable}
 #define PNN_F32_CFGS(X) \
     X(1, 5, 4) X(1, 5, 2) X(1, 4, 4) X(1, 4, 2) X(1, 3, 4) X(1, 2, 4) X(1, 2, 2) X(1, 1, 4) X(1, 1, 2) \
@@ -543,7 +586,7 @@ bool tapgemm_f32_can_fuse(int idx) { return kCfgsF32[idx].rt == 1 && kCfgsF32[id
 template <int RT, int NT, int KC>
 static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
 {
-    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls);
+    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls * (!fuse && p0.nseg > 1 ? p0.nseg : 1));
     const TileCfg t{RT, NT, KC, 32};
     TapGemmParams p = p0;
     p.pm_groups = 0;

@@ -91,12 +91,17 @@ struct TapGemmParams {
     int pm_groups, nblk;
     // image kernel, fused last layer (Cout == 64 -> 1 transposed convolution, kernel k1, stride s1, pad1 before, bias1): k1 != 0
     float bias1; int k1, s1, pad1;
+    // tapgemm_f32_kernel, K segments (nseg > 1, see GemmLayer::nseg): grid z = class * nseg + segment; a workgroup walks only its
+    // segment's share of the class's taps and stores its sums at Y + segment * seg_stride (floats) -- the caller passes a zero
+    // bias and act = 0 and finishes with launch_seg_reduce
+    int nseg; unsigned seg_stride;
 };
 static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 
 // Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
 constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
+constexpr int kSegDepth = 1600, kSegMinDepth = 2304;   // K segments of the exact-f32 summation order, see finish_gemm_layer (pnn_model.cpp)
 struct TileCfg { int rt, nt, kc, mf, wm = 4, d = 2; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
 int tapgemm32_num_cfgs();
 TileCfg tapgemm32_cfg(int idx);
@@ -108,6 +113,9 @@ int tapgemm_ring_num_cfgs();
 TileCfg tapgemm_ring_cfg(int idx);
 size_t tapgemm_ring_lds_bytes(const TileCfg& t);
 bool tapgemm_ring_can_fuse(int idx);
+// Y[i] = act(bias[i % Cout] + ((part[0][i] + part[1][i]) + ... + part[nseg - 1][i])), i < n (n and Cout multiples of 4): the K segments of
+// a tapgemm_f32 layer in their canonical order
+hipError_t launch_seg_reduce(const float* part, int nseg, size_t n, int Cout, const float* bias, int act, float* Y, hipStream_t s);
 hipError_t launch_fuse_reduce(const float* part, int ntiles, int M, int N2, const float* bias, float scale, float mean, float* Y, int32_t* Yi,
                               hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s);     // LDS-DMA ring pipeline (pnn_gemm_ring.hip)

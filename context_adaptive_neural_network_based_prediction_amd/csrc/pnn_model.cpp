@@ -122,6 +122,23 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
     if (rc) return rc;
     p.Cout = Cout; p.Npad = npad;
     L->k_total = k_real;
+    // K segments of the exact-f32 order (GemmLayer::nseg): a class deeper than kSegMinDepth is summed in segments of at most
+    // kSegDepth (a 1600-deep chain of v_mfma_f32_32x32x2_f32 is 51 k cycles = 21 us; the 6400-deep third layer of the 64x64 net
+    // as ONE chain left a quarter of the chip idle at batch 64 and took 171 us at batch 1), whole taps, never more segments than
+    // the shallowest class has taps.  One-tap layers (FC) are never segmented.
+    {
+        static const int seg_depth = getenv("PNN_F32_SEG_DEPTH") ? atoi(getenv("PNN_F32_SEG_DEPTH")) : kSegDepth;
+        static const int seg_min = getenv("PNN_F32_SEG_MIN") ? atoi(getenv("PNN_F32_SEG_MIN")) : kSegMinDepth;
+        int tmax = 0, tmin = 1 << 30;
+        for (int cls = 0; cls < p.ncls; cls++) {
+            const int t = p.tap_begin[cls + 1] - p.tap_begin[cls];
+            tmax = std::max(tmax, t); tmin = std::min(tmin, t);
+        }
+        L->nseg = 1;
+        if (seg_depth > 0 && tmax > 1 && (long)tmax * p.Cin >= seg_min)
+            L->nseg = (int)std::min<long>(std::min(tmin, 8), ((long)tmax * p.Cin + seg_depth - 1) / seg_depth);
+        if (L->nseg < 1) L->nseg = 1;
+    }
     return PNN_OK;
 }
 

@@ -41,6 +41,18 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     int cfg = -1;
     std::function<hipError_t(int)> launch;
     p.pm_groups = c->opt_ring_pm == 0 ? -1 : c->opt_ring_pm == 2 ? 1 : 0;   // position-major tiles: never / whenever possible / by the planner's model (launch_tapgemm_f32)
+    // K segments (GemmLayer::nseg, the canonical order of the deep conv layers): the launch leaves nseg planes of partial sums, a
+    // second launch adds them in order, + bias, activation
+    const int nseg = (f32k && !next && !Yi && L.nseg > 1) ? L.nseg : 1;
+    const size_t out_floats = (size_t)nblocks * (size_t)L.out_per_block;
+    if (f32k && L.nseg > 1 && nseg == 1) return fail(c, PNN_E_ARG, "a K-segmented layer cannot carry the HM epilogue or a fused output layer");
+    if (nseg > 1) {
+        DevBuf& sb = c->seg_part[(c->side_stream && s == c->side_stream) ? 1 : 0];
+        int rrc;
+        if ((rrc = dev_reserve(c, sb, (size_t)nseg * out_floats * 4))) return rrc;
+        if (out_floats >= 0xffffffffull) return fail(c, PNN_E_ARG, "batch too large for one pass");
+        p.Y = (float*)sb.p; p.bias = (const float*)c->d_zero; p.act = 0; p.nseg = nseg; p.seg_stride = (unsigned)out_floats;
+    }
     if (f32k) {
         if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
         auto legal = [&](int i) {
@@ -48,7 +60,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             return (one_tap || cpt % t.kc == 0) && (!next || tapgemm_f32_can_fuse(i));
         };
         launch = [&, p](int i) { return launch_tapgemm_f32(p, i, next != nullptr, s); };
-        cfg = choose_cfg_f32(c, M, p.Cout, p.ncls, p.Cin, L.k_total, next != nullptr);
+        cfg = choose_cfg_f32(c, M, p.Cout, p.ncls * nseg, p.Cin, L.k_total, next != nullptr);
         if (cfg < 0) return fail(c, PNN_E_ARG, "no tapgemm_f32 tile fits a layer with %d-deep taps", p.Cin);
         bool tune = c->opt_f32_cfg < 0 && (c->opt_autotune == 1 || (c->opt_autotune == 2 && flops >= 4.0e9));
         if (tune) {                                   // never while the caller's stream is being captured into a hipGraph
@@ -100,6 +112,10 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     } else {
         HIPCHK(c, launch(cfg));
     }
+    if (nseg > 1) {
+        HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
+        c->stat_launches++;
+    }
     static const bool diag = getenv("PNN_F32_DIAG") != nullptr;     // diagnostic library only (make diag): per-workgroup cycle stamps
     if (diag && f32k) {
         HIPCHK(c, hipStreamSynchronize(s));
@@ -111,7 +127,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         for (int rep = 0; rep < 400; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg, next != nullptr, s));   // back to back: the stamps that
                                                                                            // stay are the last launch's, at the steady-state clock
         HIPCHK(c, hipStreamSynchronize(s));
-        const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls;
+        const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls * nseg;
         std::vector<unsigned long long> hbuf(8 * nwg);
         HIPCHK(c, hipMemcpy(hbuf.data(), c->stage_tbs.p, hbuf.size() * 8, hipMemcpyDeviceToHost));
         double sum[4] = {0, 0, 0, 0};
@@ -120,12 +136,14 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             for (int k = 0; k < 4; k++) sum[k] += (double)hbuf[8 * i + k];
             r0 = std::min(r0, hbuf[8 * i + 4]); r1 = std::max(r1, hbuf[8 * i + 4] + hbuf[8 * i + 3]);
         }
+        size_t late = 0; unsigned long long life_max = 0;     // workgroups that start > 5 us behind the first; the longest lifetime
+        for (size_t i = 0; i < nwg; i++) { late += hbuf[8 * i + 4] > r0 + 500; life_max = std::max(life_max, hbuf[8 * i + 3]); }
         const double chunks = std::ceil(L.k_total / 16.0 / p.ncls / t.kc) * t.kc;
         const double cyc = (sum[0] + sum[1] + sum[2]) / nwg, rt_ticks = sum[3] / nwg;
         fprintf(stderr, "[pnn-f32diag] M=%ld K=%.0f N=%d {%d,%d,%d}%s: %zu WGs; wave 0 mean cycles: prologue %.0f  loop %.0f (MFMA work %.0f = %.3f)  epilogue %.0f;"
-                " lifetime %.1f us, in-kernel clock %.0f MHz; first start -> last end %.1f us\n", M, L.k_total, p.Cout, t.rt, t.nt, t.kc, next ? "+out" : "", nwg,
-                sum[0] / nwg, sum[1] / nwg, chunks * 8 * t.rt * t.nt * 64, chunks * 8 * t.rt * t.nt * 64 / (sum[1] / nwg), sum[2] / nwg, rt_ticks / 100.0,
-                cyc / (rt_ticks / 100.0), (double)(r1 - r0) / 100.0);
+                " lifetime %.1f us (max %.1f), in-kernel clock %.0f MHz; first start -> last end %.1f us, %zu workgroups start > 5 us late\n", M, L.k_total, p.Cout, t.rt, t.nt, t.kc, next ? "+out" : "", nwg,
+                sum[0] / nwg, sum[1] / nwg, chunks * 8 * t.rt * t.nt * 64, chunks * 8 * t.rt * t.nt * 64 / (sum[1] / nwg), sum[2] / nwg, rt_ticks / 100.0, (double)life_max / 100.0,
+                cyc / (rt_ticks / 100.0), (double)(r1 - r0) / 100.0, late);
     }
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += flops;

@@ -114,7 +114,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * "f32_kernel" (1, default: exact-f32 passes -- "precision" 0, the range fallback of host calls -- run their tap GEMMs on
  * tapgemm_f32_kernel: v_mfma_f32_32x32x2_f32, one wave per SIMD, one per-output summation order for every tile and batch size;
  * fully-connected nets with <= 64 outputs sum the output layer in K segments of 160 hidden units at every batch size, inside the
- * last hidden layer's launch from 1024 blocks on ("fuse_last"); "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
+ * last hidden layer's launch from 1024 blocks on ("fuse_last"); convolution layers deeper than 2304 per output are summed in K
+ * segments of at most 1600 -- whole taps, added in order by a second launch -- at every batch size; "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
  * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
  * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
  * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
