@@ -574,6 +574,13 @@ static const TileCfg kCfgsF32[] = {
 #undef X
 };
 
+// Registers per lane (arch + acc) of the non-fused instantiations, in the order of PNN_F32_CFGS, as the compiler allocated them
+// (llvm-readelf --notes on the code object, .vgpr_count): what bounds the waves per SIMD -- 512 / this, whole waves -- in
+// choose_cfg_f32's residency estimate.  Re-read after a change of the kernel.
+static const int kRegsF32[] = {360, 360, 296, 296, 224, 176, 152, 116, 92, 492, 288, 252, 208, 360};
+static_assert(sizeof(kRegsF32) / sizeof(kRegsF32[0]) == sizeof(kCfgsF32) / sizeof(kCfgsF32[0]), "one register count per tile");
+int tapgemm_f32_regs(int idx) { return kRegsF32[idx]; }
+
 int tapgemm_f32_num_cfgs() { return (int)(sizeof(kCfgsF32) / sizeof(kCfgsF32[0])); }
 TileCfg tapgemm_f32_cfg(int idx) { return kCfgsF32[idx]; }
 size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse, bool row_out)

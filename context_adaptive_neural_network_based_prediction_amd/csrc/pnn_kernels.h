@@ -152,6 +152,7 @@ int tapgemm_f32_num_cfgs();
 TileCfg tapgemm_f32_cfg(int idx);
 size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse, bool row_out = false);   // row_out: an FC layer's f32 output leaves through an LDS tile
 bool tapgemm_f32_can_fuse(int idx);
+int tapgemm_f32_regs(int idx);   // registers per lane of tile idx (residency estimate of choose_cfg_f32)
 hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStream_t s);
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
 hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);

@@ -72,13 +72,18 @@ int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double
         if (!one_tap && cpt % t.kc) continue;
         const long bm = 128L * t.rt, bn = 32L * t.nt;
         const double wgs = (double)((M + bm - 1) / bm) * (double)((cout + bn - 1) / bn) * ncls;
-        const double regs = 16.0 * t.rt * t.nt + 16.0 * t.nt + 16.0 * t.kc * t.rt + 40.0;
+        const double regs = tapgemm_f32_regs(i);
         const int res = (int)std::max(1.0, std::min(std::min(4.0, std::floor(512.0 / regs)), std::floor(160.0 * 1024 / (double)tapgemm_f32_lds_bytes(t, fused))));
         const double chunks = std::ceil(k_total / 16.0 / ncls / t.kc) * t.kc;
         const double mfma = chunks * 8.0 * t.rt * t.nt * 64.0;
         const double fixed = 5000.0 + 2500.0 * t.rt * t.nt;
         const bool exact = std::fmod(wgs, 256.0) == 0.0 && wgs / 256.0 <= res;
-        double cost = wgs * mfma / 256.0 + (exact ? 0.0 : 0.6 * mfma) + fixed * (res >= 2 && wgs > 256.0 ? 0.4 : 1.0);
+        // start-up and epilogue hide behind OTHER workgroups' loops only when a CU's slots turn over (>= 2 rounds); workgroups that are all
+        // resident from the start go through them together, and the more of them share a CU the longer those phases last (FC 8x8 first
+        // layer, K = 320, 32-column tiles: 4.75 workgroups per CU, 14 k + 10 k cycles of prologue + epilogue around 10 k of MFMAs)
+        const double per_cu = wgs / 256.0, rounds = per_cu / res;
+        const double fixed_eff = rounds >= 2.0 ? 0.4 * fixed : fixed * std::max(1.0, std::min((double)res, per_cu));
+        double cost = wgs * mfma / 256.0 + (exact ? 0.0 : 0.6 * mfma) + fixed_eff;
         if (wgs < 256.0) cost = mfma + fixed;                         // under-filled chip: the launch lasts one workgroup
         if (t.rt == 2) cost *= 1.2;
         cost *= 1.0 + 0.01 / (t.rt * t.nt) + (t.kc == 2 ? 0.005 : 0.0);   // ties: the bigger wave tile, the longer stage

@@ -3,6 +3,7 @@
 // bit-identical -- and the fastest is remembered for the context.
 #include "pnn_ctx.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -18,32 +19,59 @@ int tuned_cfg(pnn_ctx* c, const void* key_ptr, long M, int ncodes, int rule, con
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
-    float best_ms = 1e30f, rule_ms = 1e30f;
-    int best = rule;
     static const bool debug_tune = getenv("PNN_DEBUG_TUNE") != nullptr;
-    for (int i = 0; i < ncodes; i++) {
-        if (!legal(i)) continue;
-        HIPCHK(c, launch(i));                 // warm
+    auto timed = [&](int code, int reps, float* ms) -> int {
         HIPCHK(c, hipEventRecord(e0, s));
-        for (int r = 0; r < 3; r++) HIPCHK(c, launch(i));
+        for (int r = 0; r < reps; r++) HIPCHK(c, launch(code));
         HIPCHK(c, hipEventRecord(e1, s));
         HIPCHK(c, hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        if (debug_tune) fprintf(stderr, "[pnn]   code %d: %.1f us\n", i, ms * 1e3 / 3);
-        if (i == rule) rule_ms = ms;
-        if (ms < best_ms) { best_ms = ms; best = i; }
+        HIPCHK(c, hipEventElapsedTime(ms, e0, e1));
+        *ms /= (float)reps;
+        return PNN_OK;
+    };
+    // Pass 1: every legal configuration, one warm launch + three timed ones.  A noisy yardstick (no producer in front, caches warm
+    // from the same launch, and in a fresh process the first configurations run while the clock still ramps -- seen: the FC 8x8
+    // f32 pass of one bench run 3.5 % slower than the rule-based tiles run it, with tiles this pass had "measured" faster).
+    float ms1[256];
+    int best = rule, second = -1;
+    float best_ms = 1e30f, second_ms = 1e30f;
+    int rc;
+    for (int i = 0; i < ncodes && i < 256; i++) {
+        ms1[i] = 1e30f;
+        if (!legal(i)) continue;
+        HIPCHK(c, launch(i));                 // warm
+        if ((rc = timed(i, 3, &ms1[i]))) return rc;
+        if (debug_tune) fprintf(stderr, "[pnn]   code %d: %.1f us\n", i, ms1[i] * 1e3);
+        if (ms1[i] < best_ms) { second = best; second_ms = best_ms; best = i; best_ms = ms1[i]; }
+        else if (ms1[i] < second_ms) { second = i; second_ms = ms1[i]; }
     }
-    // Three back-to-back launches of one configuration are a noisy yardstick (no producer in front, caches warm from
-    // the same launch): a configuration has to beat the rule-based choice by more than 3 % to replace it.  (Seen on the
-    // K = 320 layer of the 8x8 FC net: the tuner took the 3-deep ring for "14.6 vs 14.7 us" where the 4-deep ring of
-    // the rule runs the layer in 13.4 us inside the real pass.)
-    if (best != rule && rule_ms < 1e29f && rule_ms <= best_ms * 1.03f) { best = rule; best_ms = rule_ms; }
+    // Pass 2: the finalists -- the two fastest of pass 1 and the rule-based choice -- again, interleaved, three rounds of eight
+    // launches each, by their best round; the rule-based choice stays unless beaten by more than 1 %.
+    int fin[3] = {best, second, (rule >= 0 && rule < ncodes && rule < 256 && legal(rule)) ? rule : -1};
+    float fin_ms[3] = {1e30f, 1e30f, 1e30f};
+    for (int round = 0; round < 3; round++)
+        for (int k = 0; k < 3; k++) {
+            if (fin[k] < 0 || ms1[fin[k]] > 1e29f) continue;
+            bool dup = false;
+            for (int j = 0; j < k; j++) dup |= fin[j] == fin[k];
+            if (dup) continue;
+            float ms = 0.f;
+            if ((rc = timed(fin[k], 8, &ms))) return rc;
+            fin_ms[k] = std::min(fin_ms[k], ms);
+        }
+    best_ms = 1e30f;
+    for (int k = 0; k < 3; k++) if (fin_ms[k] < best_ms) { best_ms = fin_ms[k]; best = fin[k]; }
+    if (fin[2] >= 0) {
+        float rule_ms = 1e30f;
+        for (int k = 0; k < 3; k++) if (fin[k] == rule) rule_ms = std::min(rule_ms, fin_ms[k]);
+        if (best != rule && rule_ms <= best_ms * 1.01f) { best = rule; best_ms = rule_ms; }
+    }
+    if (debug_tune) fprintf(stderr, "[pnn]   finalists %d %d %d: %.1f %.1f %.1f us -> %d\n", fin[0], fin[1], fin[2], fin_ms[0] * 1e3, fin_ms[1] * 1e3, fin_ms[2] * 1e3, best);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     c->tuned.emplace(key, best);
     *cfg = best;
-    if (best_us) *best_us = best_ms * 1e3f / 3;
+    if (best_us) *best_us = best_ms * 1e3f;
     return PNN_OK;
 }
 
