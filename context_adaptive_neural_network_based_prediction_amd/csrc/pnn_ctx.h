@@ -115,6 +115,7 @@ struct pnn_ctx {
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
+    long opt_f32_seg_mode = 0;                        // K-segmented exact-f32 layers: 0 (default) parallel segments + reduce, 1 in sequence inside the workgroups, -1 by cost model / tuner (same bits)
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
     long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)
@@ -183,7 +184,7 @@ int choose_cfg_convimg(const TapGemmParams& p, bool one_tap);
 bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total);
 int choose_cfg_ring(const TapGemmParams& p, long M, bool one_tap, double k_total, bool fused = false);
 int choose_cfg_sp(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total);
-int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused);
+int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused, double* cost_out = nullptr);
 // pnn_tuner.cpp
 // First sighting of (key, M): every legal configuration code in [0, ncodes) runs the real launch (idempotent) on stream
 // `s`, the fastest is remembered in c->tuned and returned in *cfg; later sightings return the remembered code.  `rule` =

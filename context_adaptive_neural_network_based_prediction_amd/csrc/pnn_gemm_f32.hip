@@ -63,9 +63,13 @@ __device__ __forceinline__ void wait_vm_le()
 
 }  // namespace
 
-template <int RT, int NT, int KC, bool FUSE>
+// SEQ: K segments one after the other inside the workgroup (p.seg_seq; big launches, where more workgroups buy nothing): the
+// stages of all segments run as ONE pipeline, and where a segment ends the accumulators are folded into a running total --
+// total = (p0 + p1) + ..., the order seg_reduce_kernel adds the planes in -- so both forms give the same bits.
+template <int RT, int NT, int KC, bool FUSE, bool SEQ = false>
 __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
 {
+    static_assert(!(FUSE && SEQ), "the fused output layer belongs to FC layers, which are never segmented");
     touch_kernargs<sizeof(TapGemmParams)>();
     static_assert(KC >= 2 && KC % 2 == 0, "fragment sets alternate by chunk parity");
     constexpr int BM = 128 * RT, BN = 32 * NT;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     // K segments (p.nseg > 1, never with the fused output layer): z = class * nseg + segment
-    const int nseg = (!FUSE && p.nseg > 1) ? p.nseg : 1;
+    const int nseg = (!FUSE && !SEQ && p.nseg > 1) ? p.nseg : 1;
     const int cls = nseg > 1 ? (int)blockIdx.z / nseg : (int)blockIdx.z;
     const int seg = (int)blockIdx.z - cls * nseg;
     const int n0 = blockIdx.y * BN;
@@ -160,6 +164,14 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     }
     const int nchunks = __builtin_popcount(tmask) * cpt;
     const int nstages = (nchunks + KC - 1) / KC;     // the packed weights are zero-padded to whole stages (kChunkPad)
+    // SEQ: stages of segment k = its live taps x (cpt / KC) (a segmented layer has whole stages per tap); fold_at = the stage count at
+    // which the running segment ends (segments without a live tap end where they begin and fold nothing)
+    const int sq_n = SEQ ? p.nseg : 1, sq_base = (t1 - t0) / sq_n, sq_rem = (t1 - t0) - sq_base * sq_n;
+    auto seg_stages = [&](int k) {
+        const unsigned mk = ((1u << (sq_base + (k < sq_rem ? 1 : 0))) - 1u) << (k * sq_base + (k < sq_rem ? k : sq_rem));
+        return __builtin_popcount(tmask & mk) * (cpt / KC);
+    };
+    int sq_k = 0, fold_at = SEQ ? seg_stages(0) : 0, sq_done = 0;
 
     // ---- weights: this lane's pieces of a stage (LDS-DMA: lane-linear destination, per-lane source) ------------------------
     const unsigned wbytes = (unsigned)p.chunk_begin[p.ncls] * 4u * (unsigned)p.Npad * 16u;
@@ -227,12 +239,31 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     };
 
     f32x16 acc[RT][NT];
+    f32x16 total[SEQ ? RT : 1][SEQ ? NT : 1];        // SEQ: the sum of the finished segments
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[rt][nt][i] = 0.f;
+            for (int i = 0; i < 16; i++) {
+                acc[rt][nt][i] = 0.f;
+                if (SEQ) total[SEQ ? rt : 0][SEQ ? nt : 0][i] = 0.f;
+            }
+    auto after_stage = [&]() {                       // SEQ: a full stage is done; where its segment ends, fold (wave-uniform)
+        if (!SEQ) return;
+        ++sq_done;
+        if (sq_done != fold_at || sq_k >= sq_n - 1) return;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    total[SEQ ? rt : 0][SEQ ? nt : 0][i] += acc[rt][nt][i];
+                    acc[rt][nt][i] = 0.f;
+                }
+        do { ++sq_k; fold_at += seg_stages(sq_k); } while (fold_at == sq_done && sq_k < sq_n - 1);
+    };
 
     auto read_wf = [&](int buf, int j, int nt, f32x4 (&wf)[NT][2]) {
         wf[nt][0] = lds[buf * SE + j * E + (2 * h) * BN + nt * 32 + l31];
@@ -341,18 +372,30 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     };
     const int nlive = nchunks - (nstages - 1) * KC;
     int s = 0, buf = 0;
+    if (SEQ) while (fold_at == 0 && sq_k < sq_n - 1) { ++sq_k; fold_at += seg_stages(sq_k); }   // leading segments without a live tap
     for (; s + 2 < nstages; s += 2) {
         stage(buf, a0, a1);
         buf = buf == 2 ? 0 : buf + 1;
+        after_stage();
         stage(buf, a1, a0);
         buf = buf == 2 ? 0 : buf + 1;
+        after_stage();
     }
     if (s + 1 < nstages) {
         stage(buf, a0, a1);
         buf = buf == 2 ? 0 : buf + 1;
+        after_stage();
         tail(buf, a1, nlive);
     } else {
         tail(buf, a0, nlive);
+    }
+    if (SEQ) {                                       // the last segment's sum joins the others': acc = total + acc
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[rt][nt][i] = total[SEQ ? rt : 0][SEQ ? nt : 0][i] + acc[rt][nt][i];
     }
 #ifdef PNN_F32_DIAG
     dq2 = __builtin_amdgcn_s_memtime();
@@ -559,7 +602,7 @@ hipError_t launch_seg_reduce(const float* part, int nseg, size_t n, int Cout, co
     if (n == 0) return hipSuccess;
     if (nseg < 1 || n % 4 || Cout % 4) return hipErrorInvalidValue;
     const size_t n4 = n / 4;
-    pnn_launch(seg_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, nseg, n4, n4, Cout / 4, bias, act, Y);
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, nseg, n4, n4, Cout / 4, bias, act, Y);   // (not pnn_launch: never the timed GEMM)
     return hipGetLastError();
 }
 
@@ -593,7 +636,8 @@ bool tapgemm_f32_can_fuse(int idx) { return kCfgsF32[idx].rt == 1 && kCfgsF32[id
 template <int RT, int NT, int KC>
 static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
 {
-    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls * (!fuse && p0.nseg > 1 ? p0.nseg : 1));
+    const bool seq = !fuse && p0.nseg > 1 && p0.seg_seq;
+    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls * (!fuse && !seq && p0.nseg > 1 ? p0.nseg : 1));
     const TileCfg t{RT, NT, KC, 32};
     TapGemmParams p = p0;
     p.pm_groups = 0;
@@ -626,6 +670,13 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
         }
     }
     if (fuse) return hipErrorInvalidValue;
+    if (seq) {
+        if ((p0.Cin / 16) % KC) return hipErrorInvalidValue;      // whole stages per tap
+        static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr;
+        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, true>, grid, dim3(256), tapgemm_f32_lds_bytes(t, false, p0.SH * p0.SW == 1), s, p);
+        return hipGetLastError();
+    }
     static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
     pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false>, grid, dim3(256), tapgemm_f32_lds_bytes(t, false, p0.SH * p0.SW == 1), s, p);

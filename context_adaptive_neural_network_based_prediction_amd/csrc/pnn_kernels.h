@@ -95,6 +95,9 @@ struct TapGemmParams {
     // segment's share of the class's taps and stores its sums at Y + segment * seg_stride (floats) -- the caller passes a zero
     // bias and act = 0 and finishes with launch_seg_reduce
     int nseg; unsigned seg_stride;
+    // seg_seq = 1: the segments one after the other inside each workgroup instead (grid z = class), folded into a running total in
+    // the same order -- same bits, no partial planes, no second launch; the caller passes the real Y, bias and act
+    int seg_seq;
 };
 static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }

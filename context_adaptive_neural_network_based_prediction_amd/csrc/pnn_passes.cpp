@@ -46,22 +46,46 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     const int nseg = (f32k && !next && !Yi && L.nseg > 1) ? L.nseg : 1;
     const size_t out_floats = (size_t)nblocks * (size_t)L.out_per_block;
     if (f32k && L.nseg > 1 && nseg == 1) return fail(c, PNN_E_ARG, "a K-segmented layer cannot carry the HM epilogue or a fused output layer");
+    // Two forms with the same bits: PARALLEL segments (grid z = class x segment, planes of partial sums + seg_reduce_kernel: more,
+    // shorter workgroups -- what a launch that does not fill the chip needs) and SEQUENTIAL ones (each workgroup runs its segments
+    // one after the other and folds them into a running total: no planes, no second launch -- what a big launch wants).
+    // Configuration codes of a segmented layer: [0, ntile) = parallel on tile code, [ntile, 2 ntile) = sequential on tile code - ntile.
+    const int ntile = tapgemm_f32_num_cfgs();
+    TapGemmParams pseq = p;                           // the sequential form: the real Y, bias and activation
     if (nseg > 1) {
+        pseq.nseg = nseg; pseq.seg_seq = 1;
         DevBuf& sb = c->seg_part[(c->side_stream && s == c->side_stream) ? 1 : 0];
         int rrc;
         if ((rrc = dev_reserve(c, sb, (size_t)nseg * out_floats * 4))) return rrc;
         if (out_floats >= 0xffffffffull) return fail(c, PNN_E_ARG, "batch too large for one pass");
-        p.Y = (float*)sb.p; p.bias = (const float*)c->d_zero; p.act = 0; p.nseg = nseg; p.seg_stride = (unsigned)out_floats;
+        p.Y = (float*)sb.p; p.bias = (const float*)c->d_zero; p.act = 0; p.nseg = nseg; p.seg_stride = (unsigned)out_floats; p.seg_seq = 0;
     }
     if (f32k) {
         if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
-        auto legal = [&](int i) {
-            const TileCfg t = tapgemm_f32_cfg(i);
-            return (one_tap || cpt % t.kc == 0) && (!next || tapgemm_f32_can_fuse(i));
+        auto legal = [&](int code) {
+            if (code >= ntile && (nseg == 1 || c->opt_f32_seg_mode == 0)) return false;
+            if (code < ntile && nseg > 1 && c->opt_f32_seg_mode == 1) return false;
+            const TileCfg t = tapgemm_f32_cfg(code % ntile);
+            return (one_tap || cpt % t.kc == 0) && (!next || tapgemm_f32_can_fuse(code % ntile));
         };
-        launch = [&, p](int i) { return launch_tapgemm_f32(p, i, next != nullptr, s); };
-        cfg = choose_cfg_f32(c, M, p.Cout, p.ncls * nseg, p.Cin, L.k_total, next != nullptr);
+        float* const Yreal = Y;
+        const float* const bias_real = L.d_bias;
+        const int act_real = L.proto.act;
+        launch = [&, p, pseq, Yreal, bias_real, act_real](int code) {
+            if (code >= ntile) return launch_tapgemm_f32(pseq, code - ntile, false, s);
+            const hipError_t e = launch_tapgemm_f32(p, code, next != nullptr, s);
+            if (e != hipSuccess || p.nseg <= 1) return e;
+            return launch_seg_reduce(p.Y, p.nseg, out_floats, p.Cout, bias_real, act_real, Yreal, s);
+        };
+        double cost_par = 0, cost_seq = 0;
+        cfg = choose_cfg_f32(c, M, p.Cout, p.ncls * nseg, p.Cin, L.k_total, next != nullptr, &cost_par);
         if (cfg < 0) return fail(c, PNN_E_ARG, "no tapgemm_f32 tile fits a layer with %d-deep taps", p.Cin);
+        if (nseg > 1) {
+            // the planes cost a write and a read of nseg x the output and a launch (in cycles at 2.4 GHz, ~4 TB/s through L2 / MALL)
+            cost_par += (double)(nseg + 1) * (double)out_floats * 4.0 / 4.0e12 * 2.4e9 + 9000.0;
+            const int cs = choose_cfg_f32(c, M, p.Cout, p.ncls, p.Cin, L.k_total, false, &cost_seq);
+            if (c->opt_f32_seg_mode == 1 || (c->opt_f32_seg_mode < 0 && cs >= 0 && cost_seq < cost_par)) cfg = ntile + cs;
+        }
         bool tune = c->opt_f32_cfg < 0 && (c->opt_autotune == 1 || (c->opt_autotune == 2 && flops >= 4.0e9));
         if (tune) {                                   // never while the caller's stream is being captured into a hipGraph
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -71,22 +95,24 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             const void* key = (const void*)((const char*)&L + 8 + (next ? 1 : 0));   // offsets 0-7: the split-precision launches of this layer
             float best_us = -1.f;
             const int rule = cfg;
-            const int trc = tuned_cfg(c, key, M, tapgemm_f32_num_cfgs(), rule, legal, launch, s, &cfg, &best_us);
+            const int trc = tuned_cfg(c, key, M, nseg > 1 ? 2 * ntile : ntile, rule, legal, launch, s, &cfg, &best_us);
             if (trc) return trc;
             if (best_us >= 0.f && debug) {
-                const TileCfg tb = tapgemm_f32_cfg(cfg), th = tapgemm_f32_cfg(rule);
-                fprintf(stderr, "[pnn] f32 autotune M=%ld K=%.0f N=%d ncls=%d: best {%d,%d,%d} %.1f us (rule {%d,%d,%d})\n", M, L.k_total, p.Cout, p.ncls,
-                        tb.rt, tb.nt, tb.kc, best_us, th.rt, th.nt, th.kc);
+                const TileCfg tb = tapgemm_f32_cfg(cfg % ntile), th = tapgemm_f32_cfg(rule % ntile);
+                fprintf(stderr, "[pnn] f32 autotune M=%ld K=%.0f N=%d ncls=%d nseg=%d: best {%d,%d,%d}%s %.1f us (rule {%d,%d,%d}%s)\n", M, L.k_total, p.Cout, p.ncls, nseg,
+                        tb.rt, tb.nt, tb.kc, cfg >= ntile ? " seq" : "", best_us, th.rt, th.nt, th.kc, rule >= ntile ? " seq" : "");
             }
         }
-        if (tiles_out) { const TileCfg t = tapgemm_f32_cfg(cfg); *tiles_out = (int)((p.Cout + 32L * t.nt - 1) / (32L * t.nt)); }
+        if (tiles_out) { const TileCfg t = tapgemm_f32_cfg(cfg % ntile); *tiles_out = (int)((p.Cout + 32L * t.nt - 1) / (32L * t.nt)); }
     } else {
         cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
         launch = [&, p](int i) { return launch_tapgemm(p, i, s); };
     }
-    const TileCfg t = f32k ? tapgemm_f32_cfg(cfg) : tapgemm_cfg(cfg);
-    if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> %s cfg %d {rt %d, nt %d, kc %d}%s\n", M, L.k_total, p.Cout, p.ncls,
-                       f32k ? "f32" : "legacy", cfg, t.rt, t.nt, t.kc, next ? " + fused output layer" : "");
+    const bool seq = f32k && nseg > 1 && cfg >= ntile;
+    const TileCfg t = f32k ? tapgemm_f32_cfg(cfg % ntile) : tapgemm_cfg(cfg);
+    if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> %s cfg %d {rt %d, nt %d, kc %d}%s%s\n", M, L.k_total, p.Cout, p.ncls,
+                       f32k ? "f32" : "legacy", cfg, t.rt, t.nt, t.kc, next ? " + fused output layer" : "",
+                       nseg > 1 ? (seq ? ", K segments in sequence" : ", K segments in parallel + reduce") : "");
     if (profile || c->opt_time_launches) {
         pnn_ctx::LaunchRec r;
         HIPCHK(c, hipEventCreate(&r.e0));
@@ -112,22 +138,19 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     } else {
         HIPCHK(c, launch(cfg));
     }
-    if (nseg > 1) {
-        HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
-        c->stat_launches++;
-    }
+    if (nseg > 1 && !seq) c->stat_launches++;          // the reduction of the parallel form (launched by `launch`)
     static const bool diag = getenv("PNN_F32_DIAG") != nullptr;     // diagnostic library only (make diag): per-workgroup cycle stamps
     if (diag && f32k) {
         HIPCHK(c, hipStreamSynchronize(s));
         if (dev_reserve(c, c->stage_tbs, (size_t)16 << 20)) return PNN_E_NOMEM;
-        TapGemmParams q = p;
+        TapGemmParams q = seq ? pseq : p;
         if (next) { q.W2p = next->d_w; q.Npad2 = next->proto.Npad; q.K2chunks = next->proto.chunk_begin[1]; q.part = part; }
         q.Xlo = c->stage_tbs.p;
         HIPCHK(c, hipMemset(c->stage_tbs.p, 0, (size_t)16 << 20));
-        for (int rep = 0; rep < 400; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg, next != nullptr, s));   // back to back: the stamps that
+        for (int rep = 0; rep < 400; rep++) HIPCHK(c, launch_tapgemm_f32(q, cfg % ntile, next != nullptr, s));   // back to back: the stamps that
                                                                                            // stay are the last launch's, at the steady-state clock
         HIPCHK(c, hipStreamSynchronize(s));
-        const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls * nseg;
+        const size_t nwg = (size_t)((M + 128L * t.rt - 1) / (128L * t.rt)) * ((p.Cout + 32L * t.nt - 1) / (32L * t.nt)) * p.ncls * (seq ? 1 : nseg);
         std::vector<unsigned long long> hbuf(8 * nwg);
         HIPCHK(c, hipMemcpy(hbuf.data(), c->stage_tbs.p, hbuf.size() * 8, hipMemcpyDeviceToHost));
         double sum[4] = {0, 0, 0, 0};
@@ -138,7 +161,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         }
         size_t late = 0; unsigned long long life_max = 0;     // workgroups that start > 5 us behind the first; the longest lifetime
         for (size_t i = 0; i < nwg; i++) { late += hbuf[8 * i + 4] > r0 + 500; life_max = std::max(life_max, hbuf[8 * i + 3]); }
-        const double chunks = std::ceil(L.k_total / 16.0 / p.ncls / t.kc) * t.kc;
+        const double chunks = std::ceil(L.k_total / 16.0 / p.ncls / (seq ? 1 : nseg) / t.kc) * t.kc;
         const double cyc = (sum[0] + sum[1] + sum[2]) / nwg, rt_ticks = sum[3] / nwg;
         fprintf(stderr, "[pnn-f32diag] M=%ld K=%.0f N=%d {%d,%d,%d}%s: %zu WGs; wave 0 mean cycles: prologue %.0f  loop %.0f (MFMA work %.0f = %.3f)  epilogue %.0f;"
                 " lifetime %.1f us (max %.1f), in-kernel clock %.0f MHz; first start -> last end %.1f us, %zu workgroups start > 5 us late\n", M, L.k_total, p.Cout, t.rt, t.nt, t.kc, next ? "+out" : "", nwg,

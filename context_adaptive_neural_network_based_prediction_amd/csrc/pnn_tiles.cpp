@@ -56,13 +56,13 @@ int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_t
 // workgroups (R per CU, by LDS and registers) hide behind each other's MFMAs.  Two row tiles per wave measured 20-25 % slower than
 // the same area as one (twice the activation loads per MFMA, one resident workgroup).  Big launches are autotuned on top of this
 // (run_gemm); all tiles give the same bits.  -1: no legal tile.
-int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused)
+int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total, bool fused, double* cost_out)
 {
     const int cpt = cin / 16;
     const bool one_tap = (k_total == (double)cin);
     if (c->opt_f32_cfg >= 0 && c->opt_f32_cfg < tapgemm_f32_num_cfgs()) {
         const TileCfg t = tapgemm_f32_cfg((int)c->opt_f32_cfg);
-        if ((one_tap || cpt % t.kc == 0) && (!fused || tapgemm_f32_can_fuse((int)c->opt_f32_cfg))) return (int)c->opt_f32_cfg;
+        if ((one_tap || cpt % t.kc == 0) && (!fused || tapgemm_f32_can_fuse((int)c->opt_f32_cfg))) { if (cost_out) *cost_out = 0.0; return (int)c->opt_f32_cfg; }
     }
     int best = -1;
     double best_cost = 1e300;
@@ -89,6 +89,7 @@ int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double
         cost *= 1.0 + 0.01 / (t.rt * t.nt) + (t.kc == 2 ? 0.005 : 0.0);   // ties: the bigger wave tile, the longer stage
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
+    if (cost_out) *cost_out = best_cost;              // cycles, for the caller's choice between the two forms of a K-segmented layer
     return best;
 }
 

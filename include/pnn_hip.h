@@ -115,7 +115,9 @@ float pnn_mean(const pnn_ctx* ctx);
  * tapgemm_f32_kernel: v_mfma_f32_32x32x2_f32, one wave per SIMD, one per-output summation order for every tile and batch size;
  * fully-connected nets with <= 64 outputs sum the output layer in K segments of 160 hidden units at every batch size, inside the
  * last hidden layer's launch from 1024 blocks on ("fuse_last"); convolution layers deeper than 2304 per output are summed in K
- * segments of at most 1600 -- whole taps, added in order by a second launch -- at every batch size; "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
+ * segments of at most 1600 -- whole taps, added in order: by a second launch over planes of partial sums where the segments run as
+ * separate workgroups ("f32_seg_mode" 0, default), inside the workgroups where they run in sequence (1: no planes, no second launch;
+ * measured no faster at any batch size; -1: by cost model / tuner); same bits -- at every batch size; "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
  * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
  * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
  * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
@@ -128,10 +130,12 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
- * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG, PNN_F32_DIAG (diagnostic library of `make diag` only). */
+ * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG, PNN_F32_DIAG (diagnostic library of `make diag` only),
+ * PNN_F32_SEG_DEPTH / PNN_F32_SEG_MIN (the K segments of the exact-f32 summation order, read when a model is loaded; 0 = none. They
+ * DEFINE that order: an encoder and its decoder must run with the same values -- leave them alone outside A/B measurements). */
 /* Input-range contract of the default arithmetic ("precision" = 1): operands travel as pairs of f16 values, so every
  * intermediate activation must satisfy |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude
  * below that; arbitrary float inputs or models may not.  The kernels detect a violation (they never emit

@@ -340,7 +340,7 @@ def test_ring_position_major_tiles_bit_identical(pnn, oracle, precision, w, n):
     net.close()
 
 
-@pytest.mark.parametrize("w,is_fc,n", [(16, False, 384), (16, False, 300), (8, False, 1024), (32, False, 130), (8, True, 1500), (4, True, 2048), (16, False, 3)])
+@pytest.mark.parametrize("w,is_fc,n", [(16, False, 384), (16, False, 300), (8, False, 1024), (32, False, 130), (64, False, 9), (8, True, 1500), (4, True, 2048), (16, False, 3)])
 def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, is_fc, n):
     """The exact-f32 path (tapgemm_f32_kernel): every tile configuration gives the same float bits (one per-output summation order),
     with block-major tiles and with position-major ones (which skip the taps that only meet SAME padding: exact zeros) -- whole
@@ -364,6 +364,17 @@ def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, i
     net.set_option("f32_cfg", -1)
     net.set_option("fuse_last", 0)                                   # FC: the output layer from stored activations
     assert np.array_equal(run(), want)
+    if not is_fc:
+        # the deep layers' K segments (32x32 / 64x64 nets): as separate workgroups + seg_reduce_kernel, and in sequence inside the
+        # workgroups with a running total -- the same order of additions, the same bits, on every tile
+        for seg_mode in (0, 1):
+            net.set_option("f32_seg_mode", seg_mode)
+            for cfg in range(-1, _lib.lib().pnn_num_f32_configs()):
+                net.set_option("f32_cfg", cfg)
+                for mode in (0, 2):
+                    net.set_option("ring_pm", mode)
+                    assert np.array_equal(run(), want), "K segments in form %d on tile %d, position-major mode %d change the result" % (seg_mode, cfg, mode)
+        net.set_option("f32_seg_mode", -1); net.set_option("f32_cfg", -1); net.set_option("ring_pm", 1)
     m = min(n, 48)
     ref = oracle.fc_forward(params, w, util.flatten_fc(above[:m], left[:m])) if is_fc else oracle.conv_forward(params, w, above[:m], left[:m])
     np.testing.assert_allclose(want[:m, ..., 0], ref, rtol=0, atol=FLOAT_ATOL)
