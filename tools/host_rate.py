@@ -1,0 +1,42 @@
+"""Host-buffer (PCIe-inclusive) rate of the C ABI's batched entry points, beside bench.py's device-resident figure.
+
+pnn_predict_fc / pnn_predict_conv / pnn_predict_pel take HOST arrays (what the reference's Session::Run takes) and return host
+arrays: every call stages its contexts to the device and its predictions back.  bench.py's `value` is measured with the inputs
+already in HBM (pnn_predict_tbs_device, the gather reads the picture plane on the device); this prints what the host-array form
+of the same batch sustains -- never the bench value, noted in DESIGN.md section 5.   usage: python tools/host_rate.py [fc8 conv16 ...]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork
+
+
+def main():
+    names = sys.argv[1:] or ["fc8", "conv16"]
+    for name in names:
+        wl = bench.Workload(name, 0, 0, 0)
+        w, n = wl.width, wl.batch
+        rng = np.random.RandomState(5)
+        if wl.is_fc:
+            ins = [rng.uniform(-120, 120, (n, 5 * w * w)).astype(np.float32)]
+        else:
+            ins = [rng.uniform(-120, 120, (n, w, 3 * w, 1)).astype(np.float32), rng.uniform(-120, 120, (n, 2 * w, w, 1)).astype(np.float32)]
+        for prec, label in ((0, "f32"), (1, "split")):
+            net = PredictionNeuralNetwork(n, w, wl.is_fc, params=wl.params, device=0)
+            net.set_option("precision", prec)
+            for _ in range(5):
+                net.predict_pel(*ins)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.5:
+                net.predict_pel(*ins)
+                reps += 1
+            dt = (time.perf_counter() - t0) / reps
+            in_b = sum(a.nbytes for a in ins) / n
+            print("%-7s %-5s batch %5d host arrays in, int32 block out: %.4f ms per call = %10.0f blocks/s  (%d B in + %d B out per block = %.1f GB/s over the link)"
+                  % (name, label, n, dt * 1e3, n / dt, in_b, 4 * w * w, (in_b + 4 * w * w) * n / dt / 1e9))
+            net.close()
+
+
+if __name__ == "__main__":
+    main()
