@@ -760,8 +760,18 @@ __global__ __launch_bounds__(256) void fuse_reduce_kernel(const float* __restric
     const long i = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 consecutive columns
     const int m = (int)(i >> 4), n = (int)(i & 15) << 2;
     if (m < M && n < N2) {
+        // (eight loads in flight, then the additions in tile order: one memory round trip per 8 tiles instead of one per tile)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ntiles; t++) acc += *reinterpret_cast<const f32x4*>(part + ((size_t)t * M + m) * 64 + n);
+        for (int t0 = 0; t0 < ntiles; t0 += 8) {
+            f32x4 v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
+                v8[j] = *reinterpret_cast<const f32x4*>(part + ((size_t)t * M + m) * 64 + n);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (t0 + j < ntiles) acc += v8[j];
+        }
         const f32x4 v = acc * scale + *reinterpret_cast<const f32x4*>(bias + n);
         if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)m * N2 + n) = v;
         if (Yi) *reinterpret_cast<int4*>(Yi + (size_t)m * N2 + n) = make_int4(hm_round(v[0], mean), hm_round(v[1], mean), hm_round(v[2], mean), hm_round(v[3], mean));
