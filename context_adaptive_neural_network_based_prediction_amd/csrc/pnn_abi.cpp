@@ -185,6 +185,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_SMALL")) c->opt_small = atol(e);
     if (const char* e = getenv("PNN_FUSE_LAST")) c->opt_fuse_last = atol(e);
     if (const char* e = getenv("PNN_F32_SEG_MODE")) c->opt_f32_seg_mode = atol(e);
+    if (const char* e = getenv("PNN_F32_PERSIST")) c->opt_f32_persist = atol(e);
     if (const char* e = getenv("PNN_FUSE_FIRST")) c->opt_fuse_first = atol(e);
     if (const char* e = getenv("PNN_FUSE_GATHER")) c->opt_fuse_gather = atol(e);
     if (const char* e = getenv("PNN_FUSE_TAIL")) c->opt_fuse_tail = atol(e);
@@ -341,6 +342,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "flag_wait")) c->opt_flag_wait = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "f32_seg_mode")) { c->opt_f32_seg_mode = value; c->tuned.clear(); c->tune_gen++; }
+    else if (!strcmp(name, "f32_persist")) { c->opt_f32_persist = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "fuse_first")) { c->opt_fuse_first = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "fuse_gather")) c->opt_fuse_gather = value;
     else if (!strcmp(name, "fuse_tail")) { c->opt_fuse_tail = value; c->tuned.clear(); c->tune_gen++; }

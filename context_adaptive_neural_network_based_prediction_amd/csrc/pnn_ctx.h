@@ -116,6 +116,7 @@ struct pnn_ctx {
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves
     long opt_fuse_last = 1;                           // 1: big FC passes run the output layer inside the last hidden layer's ring kernel
     long opt_f32_seg_mode = 0;                        // K-segmented exact-f32 layers: 0 (default) parallel segments + reduce, 1 in sequence inside the workgroups, -1 by cost model / tuner (same bits)
+    long opt_f32_persist = -1;                        // exact-f32 conv launches: -1 (default) two persistent workgroups per CU for 2-4 tiles per CU, 0 never, N > 0 always N per CU
     long opt_ring = 1;                                // 1: split GEMMs may use the LDS-DMA ring kernel (pnn_gemm_ring.hip)
     long opt_small = 1;                               // 1: split GEMMs with few output tiles run on tapgemm_small_kernel (one wave per 32 x 32 tile)
     long opt_small_tiles = 512;                       // ... "few" = at most this many tiles (two one-wave workgroups per CU)

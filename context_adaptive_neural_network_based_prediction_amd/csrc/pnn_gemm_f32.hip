@@ -66,11 +66,12 @@ __device__ __forceinline__ void wait_vm_le()
 // SEQ: K segments one after the other inside the workgroup (p.seg_seq; big launches, where more workgroups buy nothing): the
 // stages of all segments run as ONE pipeline, and where a segment ends the accumulators are folded into a running total --
 // total = (p0 + p1) + ..., the order seg_reduce_kernel adds the planes in -- so both forms give the same bits.
-template <int RT, int NT, int KC, bool FUSE, bool SEQ = false>
-__global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
+// One tile (bx, by, bz) of the launch's gx x gy x gz tiles -- what a workgroup of the plain launch does once and a workgroup of a
+// PERSISTENT launch (fewer workgroups than tiles, tapgemm_f32_kernel below) does for one tile after the other.
+template <int RT, int NT, int KC, bool FUSE, bool SEQ>
+__device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const lds, const int bx, const int by, const int bz, const int gx, const int gy)
 {
     static_assert(!(FUSE && SEQ), "the fused output layer belongs to FC layers, which are never segmented");
-    touch_kernargs<sizeof(TapGemmParams)>();
     static_assert(KC >= 2 && KC % 2 == 0, "fragment sets alternate by chunk parity");
     constexpr int BM = 128 * RT, BN = 32 * NT;
     constexpr int E = 4 * BN;                        // 16-byte pieces per staged weight chunk: [q = 4][BN]
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     // of the NEXT stage), this chunk's share of the LDS-DMA of stage s+2
     constexpr int SLOTS = 8 * NT * RT;
     constexpr bool kCoalescedOut = true;
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // [3][SE] weight stages | FUSE: [W2R][64] output-layer tile
+    // lds: [3][SE] weight stages | FUSE: [W2R][64] output-layer tile
     f32x4* const W2s = lds + 3 * SE;
 
     const int tid = threadIdx.x;
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     const int l31 = lane & 31, h = lane >> 5;
     // K segments (p.nseg > 1, never with the fused output layer): z = class * nseg + segment
     const int nseg = (!FUSE && !SEQ && p.nseg > 1) ? p.nseg : 1;
-    const int cls = nseg > 1 ? (int)blockIdx.z / nseg : (int)blockIdx.z;
-    const int seg = (int)blockIdx.z - cls * nseg;
-    const int n0 = blockIdx.y * BN;
-    const int m0 = blockIdx.x * BM + wave * (32 * RT);
+    const int cls = nseg > 1 ? bz / nseg : bz;
+    const int seg = bz - cls * nseg;
+    const int n0 = by * BN;
+    const int m0 = bx * BM + wave * (32 * RT);
 #ifdef PNN_F32_DIAG             // diagnostic library only (make diag): cycle stamps of wave 0 -> p.Xlo[workgroup][8]
     const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dq1 = 0, dq2 = 0;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     if (pmg) {
         // launch order: chunks of 8 block groups; within a chunk rank by position rank, the 8 groups side by side -- workgroups
         // i, i + 8, ... run on one XCD, so each XCD walks the positions of ONE group at a time and its L2 keeps that group's maps
-        const int gc = blockIdx.x / (SP * 8), r = blockIdx.x - gc * (SP * 8);
+        const int gc = bx / (SP * 8), r = bx - gc * (SP * 8);
         const int c = gc < (pmg >> 3) ? 8 : (pmg & 7);
         const int pr = r / c;
         const int pos = SP <= 64 ? (int)((p.pos_order[pr >> 2] >> ((pr & 3) * 8)) & 0xffu) : pr;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
     dq2 = __builtin_amdgcn_s_memtime();
     auto diag_out = [&]() {
         if (tid == 0 && p.Xlo) {
-            unsigned long long* d = (unsigned long long*)p.Xlo + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            unsigned long long* d = (unsigned long long*)p.Xlo + 8 * ((bz * gy + by) * gx + bx);
             d[0] = dq1 - dq0; d[1] = dq2 - dq1; d[2] = __builtin_amdgcn_s_memtime() - dq2; d[3] = __builtin_amdgcn_s_memrealtime() - dr0;
             d[4] = dr0;
         }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
             }
         }
         if (mv[0]) {
-            float* dst = p.part + ((size_t)blockIdx.y * p.M + (m0 + l31)) * 64;
+            float* dst = p.part + ((size_t)by * p.M + (m0 + l31)) * 64;
 #pragma unroll
             for (int ot = 0; ot < OT; ot++)
 #pragma unroll
@@ -522,6 +523,22 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
             }
     }
     diag_out();
+}
+
+// The launch: a 1-D grid over the gx x gy x gz tiles in the order a 3-D grid is dispatched (x fastest; tile i runs on XCD i % 8 either
+// way).  Plain launch: one workgroup per tile.  PERSISTENT launch (launch_f32: fewer workgroups than tiles, at most one or two per
+// CU): workgroup w takes tiles w, w + G, w + 2 G, ... -- see launch_f32 for when.
+template <int RT, int NT, int KC, bool FUSE, bool SEQ = false>
+__global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
+{
+    touch_kernargs<sizeof(TapGemmParams)>();
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    const int gx = p.grid_x, gy = p.grid_y, ntiles = gx * gy * p.grid_z;
+    for (int lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
+        if (lin != (int)blockIdx.x) __syncthreads();   // the previous tile's last fragment reads (and its LDS epilogue) before this tile's first LDS-DMA
+        const int bx = lin % gx, rest = lin / gx;
+        f32_tile<RT, NT, KC, FUSE, SEQ>(p, lds, bx, rest % gy, rest / gy, gx, gy);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -661,11 +678,29 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
             if (debug) fprintf(stderr, "[pnn] f32 %dx%d: position-major tiles, %d block groups x %d positions\n", 128 * RT, 32 * NT, plan.groups, p0.SH * p0.SW);
         }
     }
+    p.grid_x = (int)grid.x; p.grid_y = (int)grid.y; p.grid_z = (int)grid.z;
+    const long ntiles = (long)grid.x * grid.y * grid.z;
+    if (ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    // PERSISTENT workgroups (W > 0): 256 W workgroups, at most W per CU (the LDS request says so), each running its tiles one after
+    // the other.  p0.persist: 0 = never, N > 0 = N per CU whenever there are more tiles, -1 = by this rule: TWO per CU for launches of
+    // more than two and at most four tiles per CU.  That is where a plain launch has every workgroup resident from the start -- three
+    // or four waves per SIMD (the 32x32x2 instruction gives its full rate to one or two) that go through start-up and epilogue
+    // together; two persistent workgroups per CU drift apart after their first tile.  Same box, conv 16x16 f32 at batch 1024 (its big
+    // layers: 768 tiles) 0.768 -> 0.748 ms, conv 32x32 1.151 -> 1.124, conv 64x64 1.268 -> 1.244; one per CU is slower (0.787: nothing
+    // hides a tile's start-up and epilogue), three change nothing; with many tiles per CU the hardware's own turnover does better
+    // (conv 16x16 at batch 4096: 2.74 -> 2.83 ms with two persistent workgroups), and up to two per CU there is nothing to gain.
+    const int W = p0.persist >= 0 ? p0.persist : (ntiles > 512 && ntiles <= 1024 ? 2 : 0);
+    size_t lds = tapgemm_f32_lds_bytes(t, fuse, p0.SH * p0.SW == 1);
+    dim3 g1((unsigned)ntiles);
+    if (W > 0 && ntiles > 256L * W) {
+        g1.x = 256u * (unsigned)W;
+        lds = std::max(lds, (size_t)(160 * 1024 / (W + 1) + 1024) / 16 * 16);
+    }
     if constexpr (RT == 1 && NT == 5) {
         if (fuse) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)attr;
-            pnn_launch(tapgemm_f32_kernel<RT, NT, KC, true>, grid, dim3(256), tapgemm_f32_lds_bytes(t, true, false), s, p);
+            pnn_launch(tapgemm_f32_kernel<RT, NT, KC, true>, g1, dim3(256), lds, s, p);
             return hipGetLastError();
         }
     }
@@ -674,12 +709,12 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
         if ((p0.Cin / 16) % KC) return hipErrorInvalidValue;      // whole stages per tap
         static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)attr;
-        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, true>, grid, dim3(256), tapgemm_f32_lds_bytes(t, false, p0.SH * p0.SW == 1), s, p);
+        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, true>, g1, dim3(256), lds, s, p);
         return hipGetLastError();
     }
     static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
-    pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false>, grid, dim3(256), tapgemm_f32_lds_bytes(t, false, p0.SH * p0.SW == 1), s, p);
+    pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false>, g1, dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

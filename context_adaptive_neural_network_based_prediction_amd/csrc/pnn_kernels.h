@@ -98,6 +98,9 @@ struct TapGemmParams {
     // seg_seq = 1: the segments one after the other inside each workgroup instead (grid z = class), folded into a running total in
     // the same order -- same bits, no partial planes, no second launch; the caller passes the real Y, bias and act
     int seg_seq;
+    // tapgemm_f32_kernel: the launch's tiles (set by launch_f32; the kernel's grid is 1-D over them, or smaller: persistent workgroups)
+    int grid_x, grid_y, grid_z;
+    int persist;       // tapgemm_f32 launches: > 0 = persistent workgroups, that many per CU (see launch_f32)
 };
 static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }

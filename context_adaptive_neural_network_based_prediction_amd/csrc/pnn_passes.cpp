@@ -51,6 +51,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     // one after the other and folds them into a running total: no planes, no second launch -- what a big launch wants).
     // Configuration codes of a segmented layer: [0, ntile) = parallel on tile code, [ntile, 2 ntile) = sequential on tile code - ntile.
     const int ntile = tapgemm_f32_num_cfgs();
+    p.persist = (next || one_tap) ? 0 : (int)c->opt_f32_persist;   // persistent workgroups for the convolution layers, see launch_f32 (pnn_gemm_f32.hip)
     TapGemmParams pseq = p;                           // the sequential form: the real Y, bias and activation
     if (nseg > 1) {
         pseq.nseg = nseg; pseq.seg_seq = 1;

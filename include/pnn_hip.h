@@ -121,6 +121,8 @@ float pnn_mean(const pnn_ctx* ctx);
  * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
  * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
  * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
+ * "f32_persist" (-1, default: a convolution launch of more than two and at most four tiles per CU runs on two PERSISTENT workgroups
+ * per CU, each taking its tiles one after the other; 0: never; N > 0: N per CU whenever there are more tiles; same bits),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
  * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs
@@ -130,7 +132,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
 /* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE.  Diagnostics:
+ * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE, PNN_F32_PERSIST.  Diagnostics:
  * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
  * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
  * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG, PNN_F32_DIAG (diagnostic library of `make diag` only),

@@ -374,7 +374,14 @@ def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, i
                 for mode in (0, 2):
                     net.set_option("ring_pm", mode)
                     assert np.array_equal(run(), want), "K segments in form %d on tile %d, position-major mode %d change the result" % (seg_mode, cfg, mode)
-        net.set_option("f32_seg_mode", -1); net.set_option("f32_cfg", -1); net.set_option("ring_pm", 1)
+        net.set_option("f32_seg_mode", 0); net.set_option("ring_pm", 1)
+        # persistent workgroups (each takes its tiles one after the other): never, one, two, three per CU
+        for persist in (0, 1, 2, 3):
+            net.set_option("f32_persist", persist)
+            for cfg in (-1, 5, 6, 7, 8):
+                net.set_option("f32_cfg", cfg)
+                assert np.array_equal(run(), want), "%d persistent workgroups per CU on tile %d change the result" % (persist, cfg)
+        net.set_option("f32_persist", -1); net.set_option("f32_cfg", -1)
     m = min(n, 48)
     ref = oracle.fc_forward(params, w, util.flatten_fc(above[:m], left[:m])) if is_fc else oracle.conv_forward(params, w, above[:m], left[:m])
     np.testing.assert_allclose(want[:m, ..., 0], ref, rtol=0, atol=FLOAT_ATOL)
