@@ -683,13 +683,15 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     if (ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     // PERSISTENT workgroups (W > 0): 256 W workgroups, at most W per CU (the LDS request says so), each running its tiles one after
     // the other.  p0.persist: 0 = never, N > 0 = N per CU whenever there are more tiles, -1 = by this rule: TWO per CU for launches of
-    // more than two and at most four tiles per CU.  That is where a plain launch has every workgroup resident from the start -- three
-    // or four waves per SIMD (the 32x32x2 instruction gives its full rate to one or two) that go through start-up and epilogue
-    // together; two persistent workgroups per CU drift apart after their first tile.  Same box, conv 16x16 f32 at batch 1024 (its big
-    // layers: 768 tiles) 0.768 -> 0.748 ms, conv 32x32 1.151 -> 1.124, conv 64x64 1.268 -> 1.244; one per CU is slower (0.787: nothing
-    // hides a tile's start-up and epilogue), three change nothing; with many tiles per CU the hardware's own turnover does better
-    // (conv 16x16 at batch 4096: 2.74 -> 2.83 ms with two persistent workgroups), and up to two per CU there is nothing to gain.
-    const int W = p0.persist >= 0 ? p0.persist : (ntiles > 512 && ntiles <= 1024 ? 2 : 0);
+    // more than two and at most six tiles per CU.  That is where a plain launch has every workgroup resident from the start (or a last
+    // round that fills half the chip) -- three or four waves per SIMD (the 32x32x2 instruction gives its full rate to one or two) that
+    // go through start-up and epilogue together; two persistent workgroups per CU drift apart after their first tile.  Same box, conv
+    // 16x16 f32 at batch 1024 (its big layers: 768 tiles) 0.768 -> 0.748 ms, at batch 1536 (1152 tiles) 1.148 -> 1.079, conv 32x32 at
+    // batch 256 / 384 1.151 -> 1.124 / 1.714 -> 1.664, conv 64x64 at 64 / 128 1.268 -> 1.244 / 2.359 -> 2.305; one per CU is slower
+    // (0.787: nothing hides a tile's start-up and epilogue), three change nothing; at six tiles per CU both launches are equal (conv
+    // 16x16 at batch 2048, conv 32x32 at 512), with more the hardware's own turnover does better (conv 16x16 at batch 4096: 2.74 -> 2.83
+    // ms with two persistent workgroups), and up to two per CU there is nothing to gain.
+    const int W = p0.persist >= 0 ? p0.persist : (ntiles > 512 && ntiles <= 1536 ? 2 : 0);
     size_t lds = tapgemm_f32_lds_bytes(t, fuse, p0.SH * p0.SW == 1);
     dim3 g1((unsigned)ntiles);
     if (W > 0 && ntiles > 256L * W) {

@@ -121,7 +121,7 @@ float pnn_mean(const pnn_ctx* ctx);
  * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
  * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
  * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
- * "f32_persist" (-1, default: a convolution launch of more than two and at most four tiles per CU runs on two PERSISTENT workgroups
+ * "f32_persist" (-1, default: a convolution launch of more than two and at most six tiles per CU runs on two PERSISTENT workgroups
  * per CU, each taking its tiles one after the other; 0: never; N > 0: N per CU whenever there are more tiles; same bits),
  * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
  * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
