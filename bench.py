@@ -298,14 +298,34 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
                       "blocks_per_s_spread": [per_call / float(np.max(ts)), per_call / float(np.min(ts))]}))   # slowest / fastest run of this leg
 
 
+def cpu_budget():
+    """CPUs this process may actually keep busy: its affinity mask, cut to the cgroup's CPU quota.  The GPU boxes show 256 cores and
+    grant the job `cpu.max` = 16 CPUs: 64 threads there run in bursts (3.3 TFLOP/s of sgemm) between throttled periods (0.35), and a
+    leg's median lands in either mode (47 k or 406 k blocks/s for the same FC 8x8 batch on two boxes) -- the legs use the quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_legs(workload, budget_s=1.5, full=False):
     """the same graph on this box's host cores -- the oracle (a port; TF 1.x cannot be installed) and
     an independent PyTorch-CPU formulation (oneDNN / MKL), each batched (the GPU batch where the oracle finishes it in seconds)
     and at batch 1 sequential (what HM does per TB).  Bounded samples: every leg runs for about `budget_s` in its own process.
-    Thread counts: 64 (or all, below 64 cores) batched and 8 at batch 1 -- the best of the full candidate lists
-    ({all, 64, 32, 16} / {8, 1}, `--cpu-legs-full`) on the 256-core GPU boxes of rounds 1-3."""
+    Thread counts: min(64, the CPUs the job may use -- cpu_budget()) batched and 8 at batch 1; `--cpu-legs-full` tries the candidate
+    lists {all, 64, 32, 16} / {8, 1} within that budget."""
     import subprocess
-    ncores = os.cpu_count()
+    ncores = cpu_budget()
 
     def run(kind, batch1, threads):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
@@ -326,7 +346,7 @@ def cpu_legs(workload, budget_s=1.5, full=False):
         legs[tag + "_batch1"] = max(cands, key=lambda r: r.get("blocks_per_s", 0.0))
     best = max(("oracle_batched", "torch_cpu_batched"), key=lambda k: legs[k].get("blocks_per_s", 0.0))
     best1 = max(("oracle_batch1", "torch_cpu_batch1"), key=lambda k: legs[k].get("blocks_per_s", 0.0))
-    return {"value": legs[best].get("blocks_per_s"), "unit": "blocks/s", "cores": legs[best].get("threads", ncores), "host_cores": ncores, "kind": "port",
+    return {"value": legs[best].get("blocks_per_s"), "unit": "blocks/s", "cores": legs[best].get("threads", ncores), "host_cores": os.cpu_count(), "cpu_quota": ncores, "kind": "port",
             "value_leg": best, "batch1_value": legs[best1].get("blocks_per_s"), "batch1_leg": best1, "batch1_cores": legs[best1].get("threads"),
             "sample": "batches of %s blocks (batch-1: 16 single-block calls in sequence, what HM issues per TB); median of the runs that fit ~%.1f s "
                       "per leg, each leg its own process; value = the faster of oracle/pnn_oracle.c (OpenMP, -O3 -mavx2 -mfma) and a PyTorch-CPU "
@@ -539,7 +559,7 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
         out["config"].update(extra_config)
     if cpu:
         out["cpu_baseline"] = {k: (_r(cpu.get(k)) if k != "sample" else cpu[k][:200]) for k in
-                               ("value", "unit", "cores", "host_cores", "kind", "value_leg", "batch1_value", "batch1_cores", "sample")}
+                               ("value", "unit", "cores", "host_cores", "cpu_quota", "kind", "value_leg", "batch1_value", "batch1_cores", "sample")}
         if cpu.get("value"):
             out["cpu_baseline"]["gpu_over_cpu"] = _r(main_res["value"] / world / cpu["value"], 3)
     if cpu_conv16 and cpu_conv16.get("value"):
