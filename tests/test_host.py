@@ -728,3 +728,28 @@ def test_staggered_first_calls_two_ranks_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res[0][1] <= res[1][0] + 1e-3, res
+
+
+def test_cpu_budget_reads_the_cgroup_quota(tmp_path, monkeypatch):
+    """bench.cpu_budget(): the CPU legs may use what the cgroup grants, not what os.cpu_count() shows (the GPU boxes: 256 cores, quota 16)."""
+    import builtins
+    import bench
+    n = bench.cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake(quota_text):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(quota_text)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.cpu_budget() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.cpu_budget() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert bench.cpu_budget() == 1
