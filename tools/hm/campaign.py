@@ -95,6 +95,31 @@ def spot_check_contexts(width, k=6, seed=31):
     return above, left
 
 
+def _cgroup_cpu():
+    """usage_usec / nr_throttled of this job's cgroup (v2), or None: what the campaign costs the HOST -- the GPU boxes grant 16 CPUs."""
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().strip().splitlines())}
+    except (OSError, ValueError):
+        return None
+
+
+def _cpu_quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
+def _proc_cpu_s(pid):
+    """user + system CPU seconds of a live process, all its threads."""
+    try:
+        f = open("/proc/%d/stat" % pid).read().rsplit(")", 1)[1].split()
+        return (int(f[11]) + int(f[12])) / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return 0.0
+
+
 def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800, picture_set="synthetic",
                  backend="gpu", spot_check=False, cpu_threads=None):
     """backend "gpu": one batching service per device (the product).  backend "cpu": ONE service whose backend answers from the CPU
@@ -140,10 +165,16 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         def job(j):
             return run_hm.encode_decode(variant, frames[j], qp, table, mean_path, os.path.join(work, "enc"), tag=str(j),
                                         env={"PNN_SERVICE_SOCKET": socks[j % len(socks)]}, timeout=timeout)
+        cg0 = _cgroup_cpu()
         t0 = time.time()
         with ThreadPoolExecutor(in_flight) as ex:
             results = list(ex.map(job, range(n)))
         wall = time.time() - t0
+        cg1 = _cgroup_cpu()
+        host_cpu = {"service_cpu_s": round(sum(_proc_cpu_s(srv.pid) for srv in servers), 2)}     # since the services started (their start-up included)
+        if cg0 and cg1:
+            host_cpu.update({"all_processes_cpu_s": round(cg1["usage_usec"] / 1e6 - cg0["usage_usec"] / 1e6, 2), "cpu_quota": _cpu_quota(),
+                             "times_throttled": cg1["nr_throttled"] - cg0["nr_throttled"]})
         if spot_check:
             from context_adaptive_neural_network_based_prediction_amd import service as svc
             for k, sock in enumerate(socks):
@@ -197,7 +228,7 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
                  "seeded random init" if natural else "seeded synthetic pictures + seeded random-init models") + " (Kodak / BSDS and the trained production models "
                 "are not in the reference checkout)",
         "devices": list(devices), "services": len(devices), "encodes_in_flight": in_flight, "host_cores": os.cpu_count(),
-        "wall_s_all_encodes_and_decodes": round(wall, 3), "service_start_s": round(t_up, 3),
+        "wall_s_all_encodes_and_decodes": round(wall, 3), "service_start_s": round(t_up, 3), "host_cpu": host_cpu,
         "pictures_per_s": round(n / wall, 3),
         "hm_total_time_s_sum": {"encoders": round(sum(r["enc_total_time_s"] or 0 for r in results), 2),
                                 "decoders": round(sum(r["dec_total_time_s"] or 0 for r in results), 2),
