@@ -694,7 +694,7 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     const int W = p0.persist >= 0 ? p0.persist : (ntiles > 512 && ntiles <= 1536 ? 2 : 0);
     size_t lds = tapgemm_f32_lds_bytes(t, fuse, p0.SH * p0.SW == 1);
     dim3 g1((unsigned)ntiles);
-    if (W > 0 && ntiles > 256L * W) {
+    if (W > 0 && ntiles > 256L * W && lds * (size_t)W <= (size_t)160 * 1024) {   // (a tile whose ring leaves no room for W workgroups per CU: plain launch)
         g1.x = 256u * (unsigned)W;
         lds = std::max(lds, (size_t)(160 * 1024 / (W + 1) + 1024) / 16 * 16);
     }
