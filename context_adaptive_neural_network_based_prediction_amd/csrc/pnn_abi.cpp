@@ -180,6 +180,8 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_F32_KERNEL")) c->opt_f32_kernel = atol(e);
     if (const char* e = getenv("PNN_F32_CFG")) c->opt_f32_cfg = atol(e);
     if (const char* e = getenv("PNN_F32_OVERLAP")) c->opt_f32_overlap = atol(e);
+    if (const char* e = getenv("PNN_F32_SMALL")) c->opt_f32_small = atol(e);
+    if (const char* e = getenv("PNN_F32_SMALL_TILES")) c->opt_f32_small_tiles = atol(e);
     if (const char* e = getenv("PNN_CONVIMG")) c->opt_convimg = atol(e);
     if (const char* e = getenv("PNN_RING")) c->opt_ring = atol(e);
     if (const char* e = getenv("PNN_SMALL")) c->opt_small = atol(e);
@@ -354,6 +356,8 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "f32_kernel")) { c->opt_f32_kernel = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "f32_cfg")) c->opt_f32_cfg = value;
     else if (!strcmp(name, "f32_overlap")) c->opt_f32_overlap = value;
+    else if (!strcmp(name, "f32_small")) c->opt_f32_small = value;
+    else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);
     cache_clear(c);                                   // any option may change the arithmetic path: cached predictions are dropped

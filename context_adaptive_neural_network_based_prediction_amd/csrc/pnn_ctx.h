@@ -111,6 +111,10 @@ struct pnn_ctx {
     // exact-f32 passes: 1 (default) = tapgemm_f32_kernel (32x32x2 MFMA, one wave per SIMD; FC nets: output layer fused into the last
     // hidden layer's launch); 0 = the round-1 kernels (tapgemm_kernel on 16x16x4 MFMA, tapgemm_splitk_kernel for small M)
     long opt_f32_kernel = 1;
+    // exact-f32 launches of few output tiles (the in-loop single-block calls, the service's handfuls): tapgemm_f32_small_kernel, the same
+    // fmaf chain on the 16x16x4 instruction (10 instead of 32 cycles per k of the dependent chain), pnn_gemm_f32_small.hip
+    long opt_f32_small = 1;
+    long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles
     long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for
     long opt_fuse_first = 1;                          // 1: convimg configurations compute a branch's first (Cin = 1) convolution themselves

@@ -1,0 +1,280 @@
+// Exact-f32 tap GEMM for SMALL M in the canonical f32 order: one 4-wave workgroup (1 MFMA wave + 3 LDS-DMA loader waves) per
+// 16 x 16 output tile, on v_mfma_f32_16x16x4_f32.
+//
+// Why (round 5): the reference runs Session::Run in float32 (TComPrediction.cpp:572-579,601-608) one block at a time, and the
+// batching service hands over handfuls.  tapgemm_f32_kernel's canonical order -- per output a k-ordered fmaf chain, per 16-deep chunk
+// k = 0, 8, 1, 9, ..., 7, 15 (step e of v_mfma_f32_32x32x2_f32 adds k = e from lane half 0, then k = 8 + e from lane half 1) -- is one
+// dependent chain of K / 2 matrix instructions of 64 cycles each: 32 cycles per k, 16 us for a 1200-deep FC layer whatever the batch
+// (profiles/r04_batch1_latency.txt: FC 8x8 72.5 us per single-block call against 39.5 on the split-f16 mode, conv 16x16 212 against
+// 77), which is why HM ran on the split mode.  The f32 matrix instructions are bit for bit a k-ordered fmaf chain (one rounding per
+// product, no wider accumulation), so the SAME chain can be issued through the 16x16x4 form: 4 k per instruction at 40 cycles of
+// dependent latency = 10 cycles per k, 3.2 x shorter -- IF its four lane groups q are fed the k the canonical order visits next:
+//     instruction i (0..3) of a chunk, lane group q:   k = 8 (q & 1) + 2 i + (q >> 1)        i = 0: 0, 8, 1, 9;  i = 1: 2, 10, 3, 11; ...
+// Operands stay in the library's packs ([K/16][4 pieces][Npad][4 floats], k = 16 chunk + 4 piece + e; activations NHWC): lane group q
+// reads pieces 2 (q & 1) and 2 (q & 1) + 1 of the chunk (two 16-byte LDS reads per operand) and picks element 2 (i & 1) + (q >> 1)
+// with one v_cndmask per operand and instruction.  Same bits as every tile of tapgemm_f32_kernel at every batch size
+// (tests/test_gpu_parity.py: test_one_summation_order_at_every_batch_size, test_f32_small_kernel_bit_identical).
+//
+// Structure = tapgemm_small_kernel's (pnn_gemm_small.hip) at tile 16 x 16: grid = (M / 16) x (Cout / 16) x (classes x K segments);
+// wave 0 reads fragments from an LDS ring and issues MFMAs; waves 1-3 only issue LDS-DMA -- loader j owns chunk j of every 3-chunk
+// stage, two 1-KiB instructions (the chunk's weights [4 pieces][16 columns], its activations [4 pieces][16 rows]), counted vmcnt, one
+// s_barrier per stage.  Rows past M, taps outside the image: buffer-descriptor range misses (zeros, no traffic).  A 1200 x 1200 FC
+// layer at batch 1 is 75 workgroups, each streaming its 75 KiB of weights.  K segments of the deep convolution layers
+// (GemmLayer::nseg) as in tapgemm_f32_kernel: z = class * nseg + segment, raw sums to plane `segment`, seg_reduce_kernel finishes.
+#include "pnn_kernels.h"
+#include <cstddef>
+#include <cstring>
+#include "pnn_device_common.h"
+
+namespace pnn {
+
+constexpr int kF32SmallCS = 3;                      // chunks per stage = loader waves
+constexpr int kF32SmallLA = 6;                      // stages in flight ahead of the one being computed
+constexpr int kF32SmallD = kF32SmallLA + 1;         // ring slots (stages): 7 x 6 KiB
+
+constexpr int kF32SmallInlineFloats = 512;
+struct F32SmallArgs { TapGemmParams p; };
+struct F32SmallArgsInline { TapGemmParams p; float in[kF32SmallInlineFloats]; };
+typedef const __attribute__((address_space(4))) TapGemmParams CF32SmallParams;
+
+namespace {
+template <int N>
+__device__ __forceinline__ void f32s_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned voff, f32x4* l)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
+}
+}  // namespace
+
+// INL: the f32 input rows of an FC net's first layer travel INSIDE the kernel-argument block (see tapgemm_small_inline_kernel).
+template <bool INL>
+__device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz)
+{
+    constexpr int CS = kF32SmallCS, LA = kF32SmallLA, D = kF32SmallD;
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, q = lane >> 4;
+    const int nseg = p.nseg > 1 ? p.nseg : 1;
+    const int cls = nseg > 1 ? bz / nseg : bz;
+    const int seg = bz - cls * nseg;
+    const int n0 = by * 16;
+    const int SP = p.SH * p.SW;
+    const int cpt = p.Cin >> 4;
+    const int t0 = p.tap_begin[cls], t1 = p.tap_begin[cls + 1];
+    // this workgroup's taps [ts0, ts1) of the class (class-relative): all of them, or segment `seg`'s share -- the class's taps dealt in
+    // order, the first (taps % nseg) segments one more (tapgemm_f32_kernel's smask)
+    int ts0 = 0, ts1 = t1 - t0;
+    if (nseg > 1) {
+        const int base = (t1 - t0) / nseg, rem = (t1 - t0) - base * nseg;
+        ts0 = seg * base + (seg < rem ? seg : rem);
+        ts1 = ts0 + base + (seg < rem ? 1 : 0);
+    }
+    const int c0 = ts0 * cpt, c1 = ts1 * cpt;        // chunks [c0, c1) of the class
+    const int nst = (c1 - c0 + CS - 1) / CS;
+
+    // the activation row this lane works for: m = 16 bx + l15 -> (block, i, j)
+    const int mg = bx * 16 + l15;
+    const bool rowok = mg < p.M;
+    const int mc = rowok ? mg : 0;
+    int rb, ri, rj;
+    if (SP == 1) { rb = mc; ri = 0; rj = 0; }
+    else {
+        rb = mc / SP;
+        const int rq = mc - rb * SP;
+        ri = rq / p.SW; rj = rq - ri * p.SW;
+    }
+
+    if (wave != 0) {
+        // ---- loader wave j: chunk j of every stage: piece (q, column / row l15) of the weights and of the activations -----------
+        const int j = wave - 1;
+        const void* xbase = p.X;
+        if (INL) xbase = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(F32SmallArgsInline, in);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, p.x_bytes, 0x00020000);
+        const f32x4* __restrict__ Wg = reinterpret_cast<const f32x4*>(p.Wp) + (size_t)p.chunk_begin[cls] * 4 * p.Npad;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0x7fffffffu, 0x00020000);
+        const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
+        const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
+        constexpr unsigned kOob = 0x80000000u;
+        int ci = c0 + j;
+        int it = t0 + ci / cpt, icc = ci - (ci / cpt) * cpt;
+        unsigned apix = kOob;
+        auto tap_setup = [&](int t) {
+            const int tp = p.tap[t < t1 ? t : t1 - 1];
+            const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+            const int iy = ri * p.a + dy, ix = rj * p.a + dx;
+            const bool ok = rowok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            apix = ok ? (((unsigned)((rb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) : kOob;
+        };
+        tap_setup(it);
+        auto issue = [&](int slot) {
+            f32x4* dst = ring + (slot * CS + j) * 128;
+            const bool live = ci < c1;
+            const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
+            const unsigned ao = (live && apix != kOob) ? apix + (unsigned)(icc << 6) + (unsigned)(q << 4) : kOob;
+            f32s_dma16(wrsrc, wo, dst);
+            f32s_dma16(xrsrc, ao, dst + 64);
+            ci += CS; icc += CS;
+            if (icc >= cpt) {
+                do { icc -= cpt; ++it; } while (icc >= cpt);
+                tap_setup(it);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < LA; s++) issue(s);
+        f32s_wait_vm<2 * (LA - 1)>();                // stage 0 has landed
+        __builtin_amdgcn_s_barrier();
+        int slot = LA;
+        for (int s = 0; s + 1 < nst; s++) {
+            issue(slot);
+            if (++slot == D) slot = 0;
+            f32s_wait_vm<2 * (LA - 1)>();            // stage s + 1 has landed
+            __builtin_amdgcn_s_barrier();
+        }
+        f32s_wait_vm<0>();                           // trailing (range-miss) DMAs must not outlive the workgroup's LDS
+        return;
+    }
+
+    // ---- MFMA wave ---------------------------------------------------------------------------------------------------------
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();                    // stage 0 is in the ring
+    const int pc = (2 * (q & 1)) * 16 + l15;          // this lane's first piece within a 64-piece operand block; its second: + 16
+    const bool odd = (q >> 1) != 0;                  // element 2 (i & 1) + 1 instead of 2 (i & 1)
+    f32x4 fr[CS][4];                                 // per chunk: w piece 0, w piece 1, x piece 0, x piece 1
+    auto read_chunk = [&](int slot, int k) {
+        const f32x4* src = ring + (slot * CS + k) * 128 + pc;
+        fr[k][0] = src[0]; fr[k][1] = src[16]; fr[k][2] = src[64]; fr[k][3] = src[80];
+    };
+    auto mfma_chunk = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f32x4 wv = fr[k][i >> 1], xv = fr[k][2 + (i >> 1)];
+            const float w = odd ? wv[2 * (i & 1) + 1] : wv[2 * (i & 1)];
+            const float x = odd ? xv[2 * (i & 1) + 1] : xv[2 * (i & 1)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, acc, 0, 0, 0);
+        }
+    };
+    int slot = 0;
+    read_chunk(0, 0);
+    for (int s = 0; s < nst; s++) {
+        const int cb = c0 + s * CS;
+#pragma unroll
+        for (int k = 0; k < CS; k++) {
+            if (k + 1 < CS) {
+                read_chunk(slot, k + 1);
+            } else {
+                const int nslot = slot + 1 == D ? 0 : slot + 1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the whole stage is in registers
+                if (s + 1 < nst) {
+                    __builtin_amdgcn_s_barrier();    // stage s + 1 is in the ring, the slot of stage s may be refilled
+                    read_chunk(nslot, 0);
+                }
+                slot = nslot;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (cb + k < c1) mfma_chunk(k);
+        }
+    }
+
+    // ---- epilogue: lane (q, l15) holds row m = l15, channels n0 + 4 q + r ----------------------------------------------------
+    if (!rowok) return;
+    const int n = n0 + 4 * q;
+    if (n >= p.Cout) return;
+    const int py = p.py[cls], px = p.px[cls];
+    const int oy = ri * p.os + py, ox = rj * p.os + px;
+    const size_t obase = (((size_t)rb * p.OH + oy) * p.OW + ox) * p.Cout;
+    float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
+    f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+    if (Yo) *reinterpret_cast<f32x4*>(Yo + obase + n) = v;
+    if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+}
+
+__global__ __launch_bounds__(256) void tapgemm_f32_small_kernel(const F32SmallArgs args)
+{
+    touch_kernargs<sizeof(F32SmallArgs)>();
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    tapgemm_f32_small_body<false>(k->p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+__global__ __launch_bounds__(256) void tapgemm_f32_small_inline_kernel(const F32SmallArgsInline args)
+{
+    touch_kernargs<sizeof(TapGemmParams)>();
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) F32SmallArgsInline*)__builtin_amdgcn_kernarg_segment_ptr();
+    tapgemm_f32_small_body<true>(k->p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent layers in ONE launch (the same layer of the two branches of a convolutional net), see tapgemm_small_pair_kernel.
+struct F32SmallArgs2 { TapGemmParams a, b; int na; };
+__global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32SmallArgs2 args)
+{
+    touch_kernargs<sizeof(F32SmallArgs2)>();
+    (void)args;
+    const auto* k = (const __attribute__((address_space(4))) F32SmallArgs2*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int na = k->na;
+    const bool second = (int)blockIdx.x >= na;
+    CF32SmallParams* p = second ? &k->b : &k->a;
+    const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
+    const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
+    const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
+    tapgemm_f32_small_body<false>(*p, r % gx, r / gx, bz);
+}
+
+size_t tapgemm_f32_small_lds_bytes() { return (size_t)kF32SmallD * kF32SmallCS * 128 * 16; }
+
+long tapgemm_f32_small_tiles(const TapGemmParams& p)
+{
+    return (long)((p.M + 15) / 16) * ((p.Cout + 15) / 16) * p.ncls * (p.nseg > 1 ? p.nseg : 1);
+}
+
+static hipError_t f32_small_attrs()
+{
+    static int done_for = -1;                        // per device: the attribute belongs to the function ON a device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (done_for == dev) return hipSuccess;
+    const void* fns[3] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel), reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel)};
+    for (const void* f : fns)
+        if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes())) != hipSuccess) return e;
+    done_for = dev;
+    return hipSuccess;
+}
+
+hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input)
+{
+    hipError_t e = f32_small_attrs();
+    if (e != hipSuccess) return e;
+    if (p.M <= 0) return hipSuccess;
+    const dim3 grid((p.M + 15) / 16, (p.Cout + 15) / 16, (unsigned)(p.ncls * (p.nseg > 1 ? p.nseg : 1)));
+    const size_t nin = (size_t)p.M * p.IH * p.IW * p.Cin;
+    if (host_input && p.SH * p.SW == 1 && nin <= (size_t)kF32SmallInlineFloats) {
+        F32SmallArgsInline a;
+        a.p = p;
+        memcpy(a.in, host_input, nin * sizeof(float));
+        pnn_launch(tapgemm_f32_small_inline_kernel, grid, dim3(256), tapgemm_f32_small_lds_bytes(), s, a);
+        return hipGetLastError();
+    }
+    const F32SmallArgs a{p};
+    pnn_launch(tapgemm_f32_small_kernel, grid, dim3(256), tapgemm_f32_small_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s)
+{
+    if (a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
+    const hipError_t e = f32_small_attrs();
+    if (e != hipSuccess) return e;
+    F32SmallArgs2 args;
+    args.a = a; args.b = b;
+    args.na = (int)tapgemm_f32_small_tiles(a);
+    pnn_launch(tapgemm_f32_small_pair_kernel, dim3((unsigned)(args.na + tapgemm_f32_small_tiles(b))), dim3(256), tapgemm_f32_small_lds_bytes(), s, args);
+    return hipGetLastError();
+}
+
+}  // namespace pnn

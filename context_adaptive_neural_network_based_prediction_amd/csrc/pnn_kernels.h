@@ -160,6 +160,11 @@ size_t tapgemm_f32_lds_bytes(const TileCfg& t, bool fuse, bool row_out = false);
 bool tapgemm_f32_can_fuse(int idx);
 int tapgemm_f32_regs(int idx);   // registers per lane of tile idx (residency estimate of choose_cfg_f32)
 hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStream_t s);
+// Small-M form of the same order on v_mfma_f32_16x16x4_f32 (pnn_gemm_f32_small.hip): one wave per 16 x 16 tile, K segments as grid z;
+// host_input (optional, FC layers): the same rows in HOST memory; when they fit they travel inside the argument block
+long tapgemm_f32_small_tiles(const TapGemmParams& p);
+hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input = nullptr);
+hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
 hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);
 

@@ -18,7 +18,7 @@ namespace {
 // launch (tapgemm_f32_kernel, 128 x 160 tile); `part` then receives the per-column-tile partial sums [tiles][M][64], *tiles_out
 // their count, and the caller finishes with launch_fuse_reduce.  Y / Yi must be null in that case.
 int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s,
-             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr)
+             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr, const float* host_rows = nullptr)
 {
     TapGemmParams p = L.proto;
     p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
@@ -60,6 +60,41 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         if ((rrc = dev_reserve(c, sb, (size_t)nseg * out_floats * 4))) return rrc;
         if (out_floats >= 0xffffffffull) return fail(c, PNN_E_ARG, "batch too large for one pass");
         p.Y = (float*)sb.p; p.bias = (const float*)c->d_zero; p.act = 0; p.nseg = nseg; p.seg_stride = (unsigned)out_floats; p.seg_seq = 0;
+    }
+    // Few output tiles (the in-loop single-block calls, the batching service's handfuls): the same fmaf chain per output on the 16x16x4
+    // instruction, one wave per 16 x 16 tile over all CUs (pnn_gemm_f32_small.hip) -- bit-identical, 3.2 x shorter dependent chain
+    if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !getenv("PNN_F32_DIAG")) {
+        if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d nseg=%d -> f32 small kernel (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, p.ncls, nseg, tapgemm_f32_small_tiles(p));
+        if (profile || c->opt_time_launches) {
+            pnn_ctx::LaunchRec r;
+            HIPCHK(c, hipEventCreate(&r.e0));
+            HIPCHK(c, hipEventCreate(&r.e1));
+            r.kind = 6; r.flops = flops;
+            const LaunchEvents ev{r.e0, r.e1};
+            g_launch_events = &ev;
+            const hipError_t le = launch_tapgemm_f32_small(p, s, host_rows);
+            g_launch_events = nullptr;
+            HIPCHK(c, le);
+            if (profile) {
+                HIPCHK(c, hipEventSynchronize(r.e1));
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+                fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d ncls=%d f32-small us=%.1f tflops=%.2f\n", M, L.k_total, p.Cout, p.ncls, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+                (void)hipEventDestroy(r.e0);
+                (void)hipEventDestroy(r.e1);
+            } else {
+                c->launch_recs.push_back(r);
+            }
+        } else {
+            HIPCHK(c, launch_tapgemm_f32_small(p, s, host_rows));
+        }
+        if (nseg > 1) {
+            HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
+            c->stat_launches++;
+        }
+        c->stat_gemm_launches++; c->stat_launches++;
+        c->stat_gemm_flops += flops;
+        return PNN_OK;
     }
     if (f32k) {
         if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
@@ -564,7 +599,7 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
         if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
         return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
     }
-    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s))) return rc;
+    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s, nullptr, nullptr, nullptr, c->host_input))) return rc;
     if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
     // Output layer of the 4x4 / 8x8 nets (<= 64 outputs) on the exact-f32 path: summed in K segments of 160 hidden units +
     // fuse_reduce at EVERY batch size -- inside the last hidden layer's launch (big batches: its 1200-wide activations never

@@ -388,6 +388,42 @@ def test_f32_tiles_and_position_major_bit_identical(pnn, oracle, precision, w, i
     net.close()
 
 
+@pytest.mark.parametrize("w,is_fc,n", [(4, True, 37), (8, True, 50), (4, False, 45), (8, False, 21), (16, False, 11), (32, False, 5), (64, False, 2)])
+def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
+    """Round 5: tapgemm_f32_small_kernel -- the canonical f32 order (a k-ordered fmaf chain, per 16-deep chunk k = 0, 8, 1, 9, ...) issued
+    through v_mfma_f32_16x16x4_f32 with its lane groups fed the k the chain visits next, one wave per 16 x 16 tile -- gives the float bits
+    of tapgemm_f32_kernel's 32x32x2 chain: single blocks, handfuls, ragged row tiles, stride-2 layers, the four classes of the stride-2
+    transposed convolutions, the K segments of the deep layers (32x32 / 64x64 nets), FC inputs riding in the argument block."""
+    if precision != "f32":
+        pytest.skip("exact-f32 kernels only")
+    params = util.make_params(w, is_fc, 277, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 278)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    net.set_option("autotune", 0)
+    run = (lambda a, l: net.predict(util.flatten_fc(a, l))) if is_fc else (lambda a, l: net.predict(a, l))
+    net.set_option("f32_small", 0)
+    want = run(above, left)
+    alone = [run(above[i:i + 1], left[i:i + 1]) for i in range(min(n, 3))]
+    for i, a in enumerate(alone):
+        assert np.array_equal(a[0], want[i])
+    net.set_option("f32_small", 1)
+    for limit in (1 << 30, 1024, 40):                               # every layer on the small kernel / the default rule / only the smallest
+        net.set_option("f32_small_max_tiles", limit)
+        assert np.array_equal(run(above, left), want), "f32_small_max_tiles = %d changes the result" % limit
+        for i in range(min(n, 3)):
+            assert np.array_equal(run(above[i:i + 1], left[i:i + 1])[0], want[i]), "block %d alone, f32_small_max_tiles = %d" % (i, limit)
+        for m in (2, 3, 7, 17):
+            if m <= n:
+                assert np.array_equal(run(above[n - m:], left[n - m:]), want[n - m:]), "%d blocks, f32_small_max_tiles = %d" % (m, limit)
+    pel = net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))
+    net.set_option("f32_small", 0)
+    assert np.array_equal(net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left))), pel)
+    m = min(n, 24)
+    ref = oracle.fc_forward(params, w, util.flatten_fc(above[:m], left[:m])) if is_fc else oracle.conv_forward(params, w, above[:m], left[:m])
+    np.testing.assert_allclose(want[:m, ..., 0], ref, rtol=0, atol=FLOAT_ATOL)
+    net.close()
+
+
 @pytest.mark.parametrize("w,is_fc", [(8, True), (16, False)])
 def test_prediction_cache_for_single_block_calls(pnn, w, is_fc):
     """`cache_mb`: a repeated single-block call (HM's RDO re-evaluates the same TB) is answered from the cache with the
