@@ -46,6 +46,7 @@ struct DevBuf {
 struct GemmLayer {                                    // one tap-GEMM launch (all classes)
     TapGemmParams proto{};
     float* d_w = nullptr;
+    float* d_w_ch = nullptr;                          // the f32 weights in the lane order of tapgemm_f32_small_kernel (pack_kn_chain, pnn_model.cpp)
     float* d_w_sp = nullptr;                          // split-precision pack: f16 hi/lo, pre-scaled by 2^sp_shift
     float sp_inv_scale = 1.f;
     float* d_bias = nullptr;

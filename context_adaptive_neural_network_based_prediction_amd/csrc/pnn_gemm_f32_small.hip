@@ -10,15 +10,17 @@
 // product, no wider accumulation), so the SAME chain can be issued through the 16x16x4 form: 4 k per instruction at 40 cycles of
 // dependent latency = 10 cycles per k, 3.2 x shorter -- IF its four lane groups q are fed the k the canonical order visits next:
 //     instruction i (0..3) of a chunk, lane group q:   k = 8 (q & 1) + 2 i + (q >> 1)        i = 0: 0, 8, 1, 9;  i = 1: 2, 10, 3, 11; ...
-// Operands stay in the library's packs ([K/16][4 pieces][Npad][4 floats], k = 16 chunk + 4 piece + e; activations NHWC): lane group q
-// reads pieces 2 (q & 1) and 2 (q & 1) + 1 of the chunk (two 16-byte LDS reads per operand) and picks element 2 (i & 1) + (q >> 1)
-// with one v_cndmask per operand and instruction.  Same bits as every tile of tapgemm_f32_kernel at every batch size
+// The operands reach the MFMA wave already in that order: the weights from a second pack in device memory (pack_kn_chain,
+// pnn_model.cpp: [K/16][q][Npad][4], element i of lane group q = the k above), the activations (NHWC) permuted on their way into LDS
+// by the LDS-DMA itself (4-byte pieces, the loader waves choose each lane's source) -- the MFMA wave itself issues two 16-byte LDS reads and four MFMAs per chunk and nothing else, because a wave
+// that runs ONE dependent chain pays every other instruction on top of the chain's 32 cycles per MFMA (tools/f32_chain_probe.hip,
+// profiles/r05_f32_chain_probe.txt).  Same bits as every tile of tapgemm_f32_kernel at every batch size
 // (tests/test_gpu_parity.py: test_one_summation_order_at_every_batch_size, test_f32_small_kernel_bit_identical).
 //
 // Structure = tapgemm_small_kernel's (pnn_gemm_small.hip) at tile 16 x 16: grid = (M / 16) x (Cout / 16) x (classes x K segments);
 // wave 0 reads fragments from an LDS ring and issues MFMAs; waves 1-3 only issue LDS-DMA -- loader j owns chunk j of every 3-chunk
-// stage, two 1-KiB instructions (the chunk's weights [4 pieces][16 columns], its activations [4 pieces][16 rows]), counted vmcnt, one
-// s_barrier per stage.  Rows past M, taps outside the image: buffer-descriptor range misses (zeros, no traffic).  A 1200 x 1200 FC
+// stage (the chunk's weights [4 lane groups][16 columns]: one 1-KiB instruction; its activations [4 lane groups][16 rows][4]: four
+// 256-byte instructions), counted vmcnt, one s_barrier per stage.  Rows past M, taps outside the image: buffer-descriptor range misses (zeros, no traffic).  A 1200 x 1200 FC
 // layer at batch 1 is 75 workgroups, each streaming its 75 KiB of weights.  K segments of the deep convolution layers
 // (GemmLayer::nseg) as in tapgemm_f32_kernel: z = class * nseg + segment, raw sums to plane `segment`, seg_reduce_kernel finishes.
 #include "pnn_kernels.h"
@@ -89,7 +91,10 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     }
 
     if (wave != 0) {
-        // ---- loader wave j: chunk j of every stage: piece (q, column / row l15) of the weights and of the activations -----------
+        // ---- loader wave j: chunk j of every stage, LDS-DMA only (no registers, no LDS instructions).  Weights: piece (q, column l15)
+        // of the chain-ordered pack, one 16-byte instruction.  Activations (NHWC in memory, k = 4 piece + e): the MFMA wave's lane group
+        // g wants k = 8 (g & 1) + 2 i + (g >> 1), i = 0..3 -- four 4-byte instructions, one per lane group g: lane l fetches element
+        // i = l & 3 of row l >> 2, landing lane-linear at float (g * 16 + row) * 4 + i of the chunk's activation block.
         const int j = wave - 1;
         const void* xbase = p.X;
         if (INL) xbase = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(F32SmallArgsInline, in);
@@ -99,66 +104,84 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
         const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
         constexpr unsigned kOob = 0x80000000u;
+        // the activation row this lane FETCHES for: m = 16 bx + (lane >> 2)
+        const int mx = bx * 16 + (lane >> 2);
+        const bool xok = mx < p.M;
+        const int mxc = xok ? mx : 0;
+        int xb, xi, xj;
+        if (SP == 1) { xb = mxc; xi = 0; xj = 0; }
+        else {
+            xb = mxc / SP;
+            const int rq = mxc - xb * SP;
+            xi = rq / p.SW; xj = rq - xi * p.SW;
+        }
+        const unsigned xlane = (unsigned)((lane & 3) << 3);                 // element i = lane & 3: k advances by 2 per i
         int ci = c0 + j;
         int it = t0 + ci / cpt, icc = ci - (ci / cpt) * cpt;
         unsigned apix = kOob;
         auto tap_setup = [&](int t) {
             const int tp = p.tap[t < t1 ? t : t1 - 1];
             const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
-            const int iy = ri * p.a + dy, ix = rj * p.a + dx;
-            const bool ok = rowok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-            apix = ok ? (((unsigned)((rb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) : kOob;
+            const int iy = xi * p.a + dy, ix = xj * p.a + dx;
+            const bool ok = xok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            apix = ok ? (((unsigned)((xb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) + xlane : kOob;
         };
         tap_setup(it);
-        auto issue = [&](int slot) {
+        auto issue = [&](int slot) {                 // chunk `ci` into its place of ring slot `slot`, then on by one stage
             f32x4* dst = ring + (slot * CS + j) * 128;
             const bool live = ci < c1;
             const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
-            const unsigned ao = (live && apix != kOob) ? apix + (unsigned)(icc << 6) + (unsigned)(q << 4) : kOob;
+            const unsigned ao = live ? apix : kOob;
+            const unsigned so = (unsigned)(icc << 6);
             f32s_dma16(wrsrc, wo, dst);
-            f32s_dma16(xrsrc, ao, dst + 64);
+            float* xd = reinterpret_cast<float*>(dst + 64);
+            // lane group g: first k = 8 (g & 1) + (g >> 1) -> byte offsets 0, 32, 4, 36 -- in the SCALAR offset: the instruction's
+            // immediate offset moves the LDS destination as well as the source
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
             ci += CS; icc += CS;
             if (icc >= cpt) {
                 do { icc -= cpt; ++it; } while (icc >= cpt);
                 tap_setup(it);
             }
         };
+        constexpr int PER = 5;                       // vector-memory instructions per issue()
 #pragma unroll
         for (int s = 0; s < LA; s++) issue(s);
-        f32s_wait_vm<2 * (LA - 1)>();                // stage 0 has landed
+        f32s_wait_vm<PER * (LA - 1)>();              // stage 0 has landed
         __builtin_amdgcn_s_barrier();
         int slot = LA;
         for (int s = 0; s + 1 < nst; s++) {
             issue(slot);
             if (++slot == D) slot = 0;
-            f32s_wait_vm<2 * (LA - 1)>();            // stage s + 1 has landed
+            f32s_wait_vm<PER * (LA - 1)>();          // stage s + 1 has landed
             __builtin_amdgcn_s_barrier();
         }
         f32s_wait_vm<0>();                           // trailing (range-miss) DMAs must not outlive the workgroup's LDS
         return;
     }
 
-    // ---- MFMA wave ---------------------------------------------------------------------------------------------------------
+    // ---- MFMA wave: per chunk two 16-byte LDS reads (this lane's four weights, its four activations) and four MFMAs -- nothing else:
+    // whatever else the wave issues is ADDED to the chain's 32 cycles per instruction (tools/f32_chain_probe.hip; the first version
+    // of this kernel read the standard packs and picked its elements with v_cndmask: 370 cycles per chunk for 128 of matrix work)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_barrier();                    // stage 0 is in the ring
-    const int pc = (2 * (q & 1)) * 16 + l15;          // this lane's first piece within a 64-piece operand block; its second: + 16
-    const bool odd = (q >> 1) != 0;                  // element 2 (i & 1) + 1 instead of 2 (i & 1)
-    f32x4 fr[CS][4];                                 // per chunk: w piece 0, w piece 1, x piece 0, x piece 1
+    f32x4 fw[CS], fx[CS];
     auto read_chunk = [&](int slot, int k) {
-        const f32x4* src = ring + (slot * CS + k) * 128 + pc;
-        fr[k][0] = src[0]; fr[k][1] = src[16]; fr[k][2] = src[64]; fr[k][3] = src[80];
+        const f32x4* src = ring + (slot * CS + k) * 128 + lane;
+        fw[k] = src[0]; fx[k] = src[64];
     };
     auto mfma_chunk = [&](int k) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const f32x4 wv = fr[k][i >> 1], xv = fr[k][2 + (i >> 1)];
-            const float w = odd ? wv[2 * (i & 1) + 1] : wv[2 * (i & 1)];
-            const float x = odd ? xv[2 * (i & 1) + 1] : xv[2 * (i & 1)];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, acc, 0, 0, 0);
-        }
+        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][i], fx[k][i], acc, 0, 0, 0);
     };
     int slot = 0;
     read_chunk(0, 0);
+#ifdef PNN_F32_DIAG                                 // diagnostic library only (make diag): cycles and 100 MHz ticks of the MFMA wave's loop
+    const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int s = 0; s < nst; s++) {
         const int cb = c0 + s * CS;
 #pragma unroll
@@ -178,7 +201,12 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
             if (cb + k < c1) mfma_chunk(k);
         }
     }
-
+#ifdef PNN_F32_DIAG
+    if (p.Xlo && lane == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((bz * gridDim.y + by) * gridDim.x + bx);
+        d[0] = __builtin_amdgcn_s_memtime() - dq0; d[1] = __builtin_amdgcn_s_memrealtime() - dr0; d[2] = (unsigned long long)(c1 - c0); d[3] = dr0;
+    }
+#endif
     // ---- epilogue: lane (q, l15) holds row m = l15, channels n0 + 4 q + r ----------------------------------------------------
     if (!rowok) return;
     const int n = n0 + 4 * q;

@@ -55,6 +55,25 @@ std::vector<float> pack_kn(const std::vector<float>& kn, long K, int N, int npad
     return out;
 }
 
+// The same weights in the order tapgemm_f32_small_kernel's lane groups consume them (pnn_gemm_f32_small.hip): [K/16][q = 4][Npad][4],
+// element i of lane group q = k = 16 chunk + 8 (q & 1) + 2 i + (q >> 1) -- the k that instruction i of the chunk's four
+// v_mfma_f32_16x16x4_f32 takes from lane group q when the canonical chain 0, 8, 1, 9, ..., 7, 15 is issued through that instruction.
+std::vector<float> pack_kn_chain(const std::vector<float>& kn, long K, int N, int npad)
+{
+    std::vector<float> out((size_t)K * npad, 0.f);
+    parallel_chunks(K / 16, [&](long c0, long c1) {
+        for (long ch = c0; ch < c1; ch++)
+            for (int q = 0; q < 4; q++)
+                for (int i = 0; i < 4; i++) {
+                    const long k = 16 * ch + 8 * (q & 1) + 2 * i + (q >> 1);
+                    float* dst = out.data() + (((size_t)ch * 4 + q) * npad) * 4 + i;
+                    const float* src = kn.data() + (size_t)k * N;
+                    for (int n = 0; n < N; n++) dst[(size_t)n * 4] = src[n];
+                }
+    });
+    return out;
+}
+
 // Split-precision pack: [K/16][hl = hi/lo][h = k-half][Npad][8 x f16] with w * scale = hi + lo.
 std::vector<float> pack_kn_split(const std::vector<float>& kn, long K, int N, int npad, float scale)
 {
@@ -104,6 +123,8 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
     std::vector<float> packed = pack_kn(padded, chunk * 16, Cout, npad);
     int rc = upload(c, m, packed.data(), packed.size(), &L->d_w);
     if (rc) return rc;
+    packed = pack_kn_chain(padded, chunk * 16, Cout, npad);
+    if ((rc = upload(c, m, packed.data(), packed.size(), &L->d_w_ch))) return rc;
     {   // split-precision copy: scale so that max |w| lands in [2^12, 2^13) (hi and lo halves both f16-normal)
         float wmax = 0.f;
         for (float v : padded) wmax = std::max(wmax, std::fabs(v));

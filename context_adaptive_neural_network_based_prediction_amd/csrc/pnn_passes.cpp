@@ -64,6 +64,8 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     // Few output tiles (the in-loop single-block calls, the batching service's handfuls): the same fmaf chain per output on the 16x16x4
     // instruction, one wave per 16 x 16 tile over all CUs (pnn_gemm_f32_small.hip) -- bit-identical, 3.2 x shorter dependent chain
     if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !getenv("PNN_F32_DIAG")) {
+        TapGemmParams ps = p;
+        ps.Wp = L.d_w_ch;                             // the same weights in the small kernel's lane order
         if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d nseg=%d -> f32 small kernel (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, p.ncls, nseg, tapgemm_f32_small_tiles(p));
         if (profile || c->opt_time_launches) {
             pnn_ctx::LaunchRec r;
@@ -72,7 +74,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             r.kind = 6; r.flops = flops;
             const LaunchEvents ev{r.e0, r.e1};
             g_launch_events = &ev;
-            const hipError_t le = launch_tapgemm_f32_small(p, s, host_rows);
+            const hipError_t le = launch_tapgemm_f32_small(ps, s, host_rows);
             g_launch_events = nullptr;
             HIPCHK(c, le);
             if (profile) {
@@ -86,11 +88,29 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
                 c->launch_recs.push_back(r);
             }
         } else {
-            HIPCHK(c, launch_tapgemm_f32_small(p, s, host_rows));
+            HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows));
         }
         if (nseg > 1) {
             HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
             c->stat_launches++;
+        }
+        static const bool sdiag = getenv("PNN_F32S_DIAG") != nullptr;   // diagnostic library only (make diag): the MFMA wave's loop, cycles per chunk and clock
+        if (sdiag) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (dev_reserve(c, c->stage_tbs, (size_t)4 << 20)) return PNN_E_NOMEM;
+            HIPCHK(c, hipMemset(c->stage_tbs.p, 0, (size_t)4 << 20));
+            TapGemmParams q = ps;
+            q.Xlo = c->stage_tbs.p;
+            HIPCHK(c, launch_tapgemm_f32_small(q, s, host_rows));
+            HIPCHK(c, hipStreamSynchronize(s));
+            const size_t nwg = std::min<size_t>((size_t)tapgemm_f32_small_tiles(p), ((size_t)4 << 20) / 32);
+            std::vector<unsigned long long> hbuf(4 * nwg);
+            HIPCHK(c, hipMemcpy(hbuf.data(), c->stage_tbs.p, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, ticks = 0, chunks = 0;
+            unsigned long long r0 = ~0ull, r1 = 0;
+            for (size_t i = 0; i < nwg; i++) { cyc += (double)hbuf[4 * i]; ticks += (double)hbuf[4 * i + 1]; chunks += (double)hbuf[4 * i + 2]; r0 = std::min(r0, hbuf[4 * i + 3]); r1 = std::max(r1, hbuf[4 * i + 3] + hbuf[4 * i + 1]); }
+            fprintf(stderr, "[pnn-f32s-diag] M=%ld K=%.0f N=%d ncls=%d nseg=%d: %zu WGs, loop %.0f cycles for %.0f chunks = %.0f cycles per chunk (160 = the chain), %.2f us, clock %.0f MHz; first loop start -> last loop end %.1f us\n",
+                    M, L.k_total, p.Cout, p.ncls, nseg, nwg, cyc / nwg, chunks / nwg, cyc / std::max(1.0, chunks), ticks / nwg / 100.0, cyc / std::max(1.0, ticks) * 100.0, (double)(r1 - r0) / 100.0);
         }
         c->stat_gemm_launches++; c->stat_launches++;
         c->stat_gemm_flops += flops;
