@@ -454,7 +454,7 @@ def self_launch(args):
     raise SystemExit(r.returncode if r.returncode or line else 1)
 
 
-def hm_campaigns(which, devices, quick=False, pictures="synthetic", cpu_leg=True):
+def hm_campaigns(which, devices, quick=False, pictures="synthetic", cpu_leg=True, arithmetic="f32"):
     """BASELINE.json configs[3] / configs[4] at their stated picture counts through the reference's own HM binaries
     (tools/hm/campaign.py; built by __graft_entry__.build() where /root/reference exists, they travel with the tree), and -- the
     cpu_baseline leg -- the first pictures of the same campaign with the PNN answered on HOST CORES (the reference's route: inference
@@ -473,10 +473,10 @@ def hm_campaigns(which, devices, quick=False, pictures="synthetic", cpu_leg=True
     for name in which:
         work = tempfile.mkdtemp(prefix="pnn_bench_hm_")
         try:
-            rec = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300, picture_set=pictures)   # per codec process: a wedged service must not hold the line for long
+            rec = campaign.run_campaign(name, work, devices, pictures=(4 if quick else None), timeout=300, picture_set=pictures, arithmetic=arithmetic)   # per codec process: a wedged service must not hold the line for long
             if cpu_leg:
                 k = 2
-                small = campaign.run_campaign(name, os.path.join(work, "gpu_small"), devices[:1], pictures=k, timeout=300, picture_set=pictures, yardstick=False)
+                small = campaign.run_campaign(name, os.path.join(work, "gpu_small"), devices[:1], pictures=k, timeout=300, picture_set=pictures, yardstick=False, arithmetic=arithmetic)
                 cpu = campaign.run_campaign(name, os.path.join(work, "cpu"), devices[:1], pictures=k, timeout=900, picture_set=pictures, yardstick=False, backend="cpu")
                 keep = ("pictures", "wall_s_all_encodes_and_decodes", "pictures_per_s", "enc_wall_s", "dec_wall_s", "every_decode_equals_its_encoder", "bits_total", "service")
                 rec["cpu_pnn"] = {
@@ -631,7 +631,8 @@ def main():
         # configs[3] / configs[4]: whole encodes through the reference's HM binaries, one batching service per device; this
         # process never touches the GPU (the services and the codecs are child processes)
         name = args.workload[3:]
-        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick, args.hm_pictures, cpu_leg=not args.no_cpu_baseline)
+        rec = hm_campaigns([name], list(range(args.gpus)), args.hm_quick, args.hm_pictures, cpu_leg=not args.no_cpu_baseline,
+                           arithmetic="f32" if precision == 0 else "split")
         r = rec.get(name, rec)
         ok = "error" not in r
         with open(args.detail_file, "w") as f:
@@ -640,10 +641,10 @@ def main():
         print(json.dumps({
             "metric": "pnn_intra_pred_blocks_per_s", "value": _r(r["service"]["pnn_blocks_per_s_over_the_wall"], 6) if ok else None, "unit": "blocks/s",
             "n_gpus": args.gpus, "steps": 1, "warmup": 0, "ms_per_step": _r(1e3 * r["wall_s_all_encodes_and_decodes"], 6) if ok else None,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[1], "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign", "pictures": r.get("pictures"),
                        "picture_set": args.hm_pictures, "parallelism": "independent encodes dealt over one batching service per device, no collective"},
-            "hm": {k: r.get(k) for k in ("variant", "pictures", "picture_set", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
+            "hm": {k: r.get(k) for k in ("variant", "pictures", "picture_set", "arithmetic", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
                                          "every_decode_equals_its_encoder", "service_start_s", "bits_total", "host_cpu", "error")} if isinstance(r, dict) else None,
             "roofline": None,
             "cpu_baseline": {"value": cpu_pnn.get("pictures_per_s"), "unit": "pictures/s", "cores": cpu_pnn.get("cores"), "kind": "port",

@@ -173,11 +173,9 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
         delete c;
         return fail(nullptr, PNN_E_HIP, "cannot initialise HIP device %d", device);
     }
-    if (const char* e = getenv("PNN_TILE_CFG")) c->opt_tile_cfg = atol(e);
     if (const char* e = getenv("PNN_MAX_CHUNK")) c->opt_max_chunk = atol(e);
     if (const char* e = getenv("PNN_PRECISION")) c->opt_precision = atol(e);
     if (const char* e = getenv("PNN_AUTOTUNE")) c->opt_autotune = atol(e);
-    if (const char* e = getenv("PNN_F32_KERNEL")) c->opt_f32_kernel = atol(e);
     if (const char* e = getenv("PNN_F32_CFG")) c->opt_f32_cfg = atol(e);
     if (const char* e = getenv("PNN_F32_OVERLAP")) c->opt_f32_overlap = atol(e);
     if (const char* e = getenv("PNN_F32_SMALL")) c->opt_f32_small = atol(e);
@@ -193,7 +191,6 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_FUSE_TAIL")) c->opt_fuse_tail = atol(e);
     if (const char* e = getenv("PNN_RING_PM")) c->opt_ring_pm = atol(e);
     if (const char* e = getenv("PNN_BRANCH_STREAMS")) c->opt_branch_streams = atol(e);
-    if (const char* e = getenv("PNN_CANONICAL_ORDER")) c->opt_canonical = atol(e);
     if (const char* e = getenv("PNN_CACHE_MB")) c->opt_cache_mb = atol(e);
     if (const char* e = getenv("PNN_FC_OUT")) c->opt_fc_out = atol(e);
     if (const char* e = getenv("PNN_SPIN_WAIT")) c->opt_spin_wait = atol(e);
@@ -328,9 +325,10 @@ int pnn_num_f32_configs(void) { return tapgemm_f32_num_cfgs(); }
 int pnn_set_option(pnn_ctx* c, const char* name, long value)
 {
     if (!c || !name) return PNN_E_ARG;
-    if (!strcmp(name, "tile_cfg")) c->opt_tile_cfg = value;
-    else if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
-    else if (!strcmp(name, "canonical_order")) c->opt_canonical = value;
+    if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
+    else if (!strcmp(name, "canonical_order")) {       // kept as a name: one summation order at every batch size is the only mode since round 5
+        if (value != 1) return fail(c, PNN_E_ARG, "canonical_order = %ld: the kernels with another summation order were removed; 1 is the only mode", value);
+    }
     else if (!strcmp(name, "time_launches")) c->opt_time_launches = value;
     else if (!strcmp(name, "precision")) c->opt_precision = value;
     else if (!strcmp(name, "autotune")) { c->opt_autotune = value; c->tune_gen++; }
@@ -350,13 +348,12 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "fuse_tail")) { c->opt_fuse_tail = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "ring_pm")) { c->opt_ring_pm = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "branch_streams")) c->opt_branch_streams = value;
-    else if (!strcmp(name, "split_min_px")) c->opt_split_min_px = value;
     else if (!strcmp(name, "cache_mb")) { c->opt_cache_mb = value; c->cache_hits = c->cache_misses = 0; }
     else if (!strcmp(name, "sp_cfg")) c->opt_sp_cfg = value;
-    else if (!strcmp(name, "f32_kernel")) { c->opt_f32_kernel = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "f32_cfg")) c->opt_f32_cfg = value;
     else if (!strcmp(name, "f32_overlap")) c->opt_f32_overlap = value;
     else if (!strcmp(name, "f32_small")) c->opt_f32_small = value;
+    else if (!strcmp(name, "fc_out_f32")) c->opt_fc_out_f32 = value;
     else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);

@@ -87,7 +87,6 @@ struct pnn_ctx {
     pnn::DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
     // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
     // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
-    long opt_split_min_px = -1;                       // tuning aid: conv passes take the split-precision kernels from this many block pixels on (-1: built-in rule)
     long opt_branch_streams = 1;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -101,20 +100,19 @@ struct pnn_ctx {
     long cache_hits = 0, cache_misses = 0;
     char* h_pin = nullptr;                            // pinned, device-visible staging of the single-block host calls (zero-copy)
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
-    long opt_tile_cfg = -1;
     long opt_max_chunk = 0;
-    // 1 (default): one per-output summation order at every batch size -- a block's prediction does not depend on the batch
-    // it travels in (encoder behind the batching service, decoder alone: no drift).  0: small passes may take the exact-f32
-    // split-K kernels (a few us faster per single-block call; last float bits can differ from the batched result).
-    long opt_canonical = 1;
-    long opt_precision = 1;                           // 1 (default): split f16 (3 x f16 MFMA, f32-class accuracy); 0: exact-f32 MFMA
+    // One per-output summation order at every batch size, on either arithmetic: a block's prediction does not depend on the batch it
+    // travels in (encoder behind the batching service, decoder alone: no drift).  (Until round 4 an option, canonical_order = 0, let
+    // small passes take split-K kernels with another order; those kernels are gone.)
+    // 0 (default since round 5): the reference's arithmetic, IEEE float32 products and sums on the f32 matrix instructions
+    // (Session::Run in float32, TComPrediction.cpp:572-579,601-608); 1: split f16 (3 x f16 MFMA per product, f32-class accuracy,
+    // 2.3-2.7 x the blocks/s at batch) -- an encoder and its decoder must run on the same one
+    long opt_precision = 0;
     long opt_sp_cfg = -1;
-    // exact-f32 passes: 1 (default) = tapgemm_f32_kernel (32x32x2 MFMA, one wave per SIMD; FC nets: output layer fused into the last
-    // hidden layer's launch); 0 = the round-1 kernels (tapgemm_kernel on 16x16x4 MFMA, tapgemm_splitk_kernel for small M)
-    long opt_f32_kernel = 1;
     // exact-f32 launches of few output tiles (the in-loop single-block calls, the service's handfuls): tapgemm_f32_small_kernel, the same
     // fmaf chain on the 16x16x4 instruction (10 instead of 32 cycles per k of the dependent chain), pnn_gemm_f32_small.hip
     long opt_f32_small = 1;
+    long opt_fc_out_f32 = 1;                          // 1: exact-f32 FC passes of <= 512 blocks run the output layer's K segments and their reduction as ONE launch
     long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles
     long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for
@@ -184,7 +182,6 @@ int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes);
 int build_model(pnn_ctx* c, int width, int is_fc, const float* params, size_t n, Model** out);
 void free_model(Model* m);
 // pnn_tiles.cpp
-int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total);
 int convimg_images(const TapGemmParams& p, const TileCfg& t, bool one_tap);
 int choose_cfg_convimg(const TapGemmParams& p, bool one_tap);
 bool pnn_ring_few_images(const TapGemmParams& p, long M, double k_total);

@@ -1,11 +1,11 @@
 // Exact-f32 tap GEMM on v_mfma_f32_32x32x2_f32 with ONE wave per SIMD and nothing left for that wave to wait for.
 //
-// Same contract as tapgemm_kernel / tapgemm32_kernel (TapGemmParams, pnn_kernels.h):
+// The contract (TapGemmParams, pnn_kernels.h):
 //   Y[pix(m)][n] = act( sum_{taps, ci} X[b, i*a+dy, j*a+dx, ci] * W[tap][ci][n] + bias[n] )
 // i.e. the FC layers, convolutions and transposed convolutions of pnn/components.py:10-261 in the REFERENCE's arithmetic
-// (IEEE float32 products, float32 accumulation: pnn/tfutils.py:107-139, components.py:169-176).  Same per-output summation order
-// as tapgemm32_kernel (16-deep chunks in K order; MFMA step e of a chunk adds x[8h + e] * w[8h + e] for the two k-halves h),
-// so every tile of either kernel gives the same bits: this is the canonical f32 order of the library -- for a layer whose deepest
+// (IEEE float32 products, float32 accumulation: pnn/tfutils.py:107-139, components.py:169-176).  Per-output summation order: 16-deep
+// chunks in K order; MFMA step e of a chunk adds x[8h + e] * w[8h + e] for the two k-halves h, i.e. a k-ordered fmaf chain 0, 8, 1, 9,
+// ..., 7, 15 per chunk.  Every tile gives the same bits: this is the canonical f32 order of the library -- for a layer whose deepest
 // class stays under kSegMinDepth.  A DEEPER convolution layer is summed in K segments (GemmLayer::nseg, pnn_model.cpp: whole taps, at
 // most kSegDepth deep): grid z = class * nseg + segment, a workgroup walks its segment's taps only and leaves its raw sums in plane
 // `segment` of a partial buffer; seg_reduce_kernel adds the planes in order, then bias and LeakyReLU.  That is the layer's order at
@@ -13,8 +13,8 @@
 // dependent 64-cycle MFMAs per output is a latency no tiling hides -- the 6400-deep third layer of the 64x64 net took 185 us at batch
 // 64 on 192 workgroups (1536 wave tiles on 1024 SIMDs: two rounds for one and a half) and 171 us at batch 1; in four segments 145
 // and 45.  conv 64x64 at batch 64: 46.0 k -> 52.7 k blocks/s, a single-block call 538 -> 347 us; conv 32x32 +2 % / 333 -> 275 us.
-// (tapgemm32_kernel and the other round-1 kernels -- option f32_kernel = 0 -- know no segments: on those layers their sums differ
-// in the last bits.)
+// (The round-1 kernels -- tapgemm_kernel on 16x16x4, tapgemm32_kernel, the split-K kernel for small M -- were removed in round 5; the
+// small-M form of THIS order is tapgemm_f32_small_kernel, pnn_gemm_f32_small.hip.)
 //
 // Why another kernel (tools/mfma_peak.hip, tools/f32_sweep.py; profiles/r04_f32_tile_sweep.txt): the 32x32x2 instruction sustains
 // 154.5 TFLOP/s (0.98 of the 157.3 peak) with one or two waves per SIMD and 124 with four, the 16x16x4 instruction 124-139 with
@@ -597,6 +597,77 @@ hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segment
     const int segs = (p.Cin + 159) / 160;
     if (segments) *segments = segs;
     pnn_launch(fc_out_f32_kernel, dim3((p.M + 31) / 32, segs), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+// The same output layer AND its reduction in ONE launch, for small M (round 5): a single-block call is a chain of dependent launches
+// that cost 3-4 us each on the host and more on the device once the batching service's five width workers share the chip
+// (tools/corun_threads.cpp), so fc_out_f32_kernel + fuse_reduce_kernel become one workgroup of 8 waves per (32-row tile, 32-column tile):
+// wave z runs fc_out_f32_kernel's chain for K segment z of that tile (half the chain of that kernel's wave, which owns both column
+// tiles), all its operands requested up front (two waves per SIMD: 256 registers per lane; a 16-wave form that owned both column
+// tiles had 128, fetched block by block and paid the memory latency five times: 16.6 us), the partial sums meet in LDS and are added
+// in segment order, + bias, HM epilogue -- fuse_reduce_kernel's arithmetic.
+struct FcOutF32Args { TapGemmParams p; DoneSignal done; };
+__global__ __launch_bounds__(512) void fc_out_f32_small_kernel(const FcOutF32Args a)
+{
+    touch_kernargs<sizeof(FcOutF32Args)>();
+    const TapGemmParams& p = a.p;
+    constexpr int NT = 5;
+    __shared__ __attribute__((aligned(16))) float part[8][32][32];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int z = __builtin_amdgcn_readfirstlane(tid >> 6), ot = blockIdx.y;
+    const int mblk = blockIdx.x * 32;
+    const int segs = (p.Cin + 159) / 160;
+    if (z < segs) {
+        const int m = mblk + l31, n0 = z * 32 * NT;
+        const bool mv = m < p.M;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)p.chunk_begin[1] * 4u * (unsigned)p.Npad * 16u, 0x00020000);
+        f32x16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc2[i] = 0.f;
+        f32x4 x[NT][4], w2[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + 32 * nt + 8 * g + 4 * h;
+                const unsigned xo = (mv && n < p.Cin) ? ((unsigned)m * (unsigned)p.Cin + (unsigned)n) << 2 : 0x80000000u;
+                x[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0));
+                w2[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)((n >> 2) * p.Npad + ot * 32 + l31) << 4, 0, 0));
+            }
+        __builtin_amdgcn_sched_barrier(0);           // every request before the first MFMA: ONE memory latency, not one per block
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[nt][g][r], x[nt][g][r], acc2, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<f32x4*>(&part[z][l31][8 * g + 4 * h]) = (f32x4){acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
+    }
+    __syncthreads();
+    const int mr = tid >> 3, nl = (tid & 7) << 2, n = ot * 32 + nl;
+    const int mg = mblk + mr;
+    if (tid < 256 && mg < p.M && n < p.Cout) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < segs; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][mr][nl]);
+        const f32x4 v = sum + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
+        if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    }
+    signal_done(a.done);
+}
+
+// p: the output layer as a one-tap GEMM (X = f32 activations [M][Cin], Wp = its f32 pack, bias, mean, Y / Yi).  false: not this kernel's case.
+bool fc_out_f32_small_fits(const TapGemmParams& p) { return p.ncls == 1 && p.SH * p.SW == 1 && p.Cout <= 64 && p.Cout % 4 == 0 && (p.Cin + 159) / 160 <= 8 && p.M > 0; }
+
+hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done)
+{
+    if (!fc_out_f32_small_fits(p)) return hipErrorInvalidValue;
+    const FcOutF32Args a{p, done};
+    pnn_launch(fc_out_f32_small_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)((p.Cout + 31) / 32)), dim3(512), 0, s, a);
     return hipGetLastError();
 }
 

@@ -30,9 +30,20 @@
 
 namespace pnn {
 
-constexpr int kF32SmallCS = 3;                      // chunks per stage = loader waves
-constexpr int kF32SmallLA = 6;                      // stages in flight ahead of the one being computed
-constexpr int kF32SmallD = kF32SmallLA + 1;         // ring slots (stages): 7 x 6 KiB
+#ifndef PNN_F32S_CPL
+#define PNN_F32S_CPL 1
+#endif
+#ifndef PNN_F32S_LA
+#define PNN_F32S_LA 6
+#endif
+constexpr int kF32SmallNL = 3;                      // loader waves
+constexpr int kF32SmallCPL = PNN_F32S_CPL;          // chunks per loader and stage
+constexpr int kF32SmallCS = kF32SmallNL * kF32SmallCPL;   // chunks per stage: one barrier per stage in the MFMA wave
+constexpr int kF32SmallLA = PNN_F32S_LA;            // stages in flight ahead of the one being computed
+// ring slots (stages).  TWO more than in flight: the loaders refill the slot of stage s - 2 behind the barrier that ends stage s - 1 in
+// the MFMA wave, so that wave need not wait for its last fragment reads in front of the barrier (with LA + 1 slots it had to:
+// 212 cycles per chunk with nothing else in the way, tools/f32_chain_probe.hip says 146)
+constexpr int kF32SmallD = kF32SmallLA + 2;
 
 constexpr int kF32SmallInlineFloats = 512;
 struct F32SmallArgs { TapGemmParams p; };
@@ -55,10 +66,17 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 template <bool INL>
 __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz)
 {
-    constexpr int CS = kF32SmallCS, LA = kF32SmallLA, D = kF32SmallD;
+    constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, LA = kF32SmallLA, D = kF32SmallD;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
     const int lane = threadIdx.x & 63;
+    // Which wave runs the MFMA chain rotates with the tile (role 0 = the chain, roles 1-3 = the loaders): a workgroup's wave i sits on
+    // SIMD i, and with several small launches on the chip at once (the batching service's five width workers) two tiles that share a
+    // CU would otherwise both run their chains on SIMD 0 -- each at half the rate -- beside three SIMDs that only issue loads.
+#ifdef PNN_F32S_NO_ROT
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    const int wave = __builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) + (unsigned)(bx + by + bz)) & 3u));
+#endif
     const int l15 = lane & 15, q = lane >> 4;
     const int nseg = p.nseg > 1 ? p.nseg : 1;
     const int cls = nseg > 1 ? bz / nseg : bz;
@@ -116,7 +134,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
             xi = rq / p.SW; xj = rq - xi * p.SW;
         }
         const unsigned xlane = (unsigned)((lane & 3) << 3);                 // element i = lane & 3: k advances by 2 per i
-        int ci = c0 + j;
+        int ci = c0 + j;                             // this loader's chunks: c0 + j, + NL, + 2 NL, ...
         int it = t0 + ci / cpt, icc = ci - (ci / cpt) * cpt;
         unsigned apix = kOob;
         auto tap_setup = [&](int t) {
@@ -127,12 +145,17 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
             apix = ok ? (((unsigned)((xb * p.IH + iy) * p.IW + ix) * (unsigned)p.Cin) << 2) + xlane : kOob;
         };
         tap_setup(it);
-        auto issue = [&](int slot) {                 // chunk `ci` into its place of ring slot `slot`, then on by one stage
-            f32x4* dst = ring + (slot * CS + j) * 128;
+        auto issue1 = [&](int slot, int u) {         // chunk `ci` into place j + NL u of ring slot `slot`, then on to this loader's next chunk
+            f32x4* dst = ring + (slot * CS + j + NL * u) * 128;
             const bool live = ci < c1;
             const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
             const unsigned ao = live ? apix : kOob;
             const unsigned so = (unsigned)(icc << 6);
+            ci += NL; icc += NL;
+#ifdef PNN_F32S_NO_DMA                              // ablation build: the loaders issue nothing (timing only, results are garbage)
+            (void)wo; (void)ao; (void)so; (void)dst;
+            return;
+#endif
             f32s_dma16(wrsrc, wo, dst);
             float* xd = reinterpret_cast<float*>(dst + 64);
             // lane group g: first k = 8 (g & 1) + (g >> 1) -> byte offsets 0, 32, 4, 36 -- in the SCALAR offset: the instruction's
@@ -141,20 +164,24 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
-            ci += CS; icc += CS;
             if (icc >= cpt) {
                 do { icc -= cpt; ++it; } while (icc >= cpt);
                 tap_setup(it);
             }
         };
-        constexpr int PER = 5;                       // vector-memory instructions per issue()
+        auto issue = [&](int slot) {                 // this loader's CPL chunks of one stage
+#pragma unroll
+            for (int u = 0; u < CPL; u++) issue1(slot, u);
+        };
+        constexpr int PER = 5 * CPL;                 // vector-memory instructions per issue()
+        static_assert(PER * LA < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
         for (int s = 0; s < LA; s++) issue(s);
         f32s_wait_vm<PER * (LA - 1)>();              // stage 0 has landed
         __builtin_amdgcn_s_barrier();
         int slot = LA;
         for (int s = 0; s + 1 < nst; s++) {
-            issue(slot);
+            issue(slot);                             // stage s + LA into the slot stage s - 2 left
             if (++slot == D) slot = 0;
             f32s_wait_vm<PER * (LA - 1)>();          // stage s + 1 has landed
             __builtin_amdgcn_s_barrier();
@@ -167,38 +194,47 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     // whatever else the wave issues is ADDED to the chain's 32 cycles per instruction (tools/f32_chain_probe.hip; the first version
     // of this kernel read the standard packs and picked its elements with v_cndmask: 370 cycles per chunk for 128 of matrix work)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifndef PNN_F32S_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);                   // the chain cannot hide a lost issue slot; the loaders beside it can
+#endif
     __builtin_amdgcn_s_barrier();                    // stage 0 is in the ring
     f32x4 fw[CS], fx[CS];
-    auto read_chunk = [&](int slot, int k) {
-        const f32x4* src = ring + (slot * CS + k) * 128 + lane;
-        fw[k] = src[0]; fx[k] = src[64];
-    };
-    auto mfma_chunk = [&](int k) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][i], fx[k][i], acc, 0, 0, 0);
-    };
     int slot = 0;
-    read_chunk(0, 0);
+    { const f32x4* src = ring + lane; fw[0] = src[0]; fx[0] = src[64]; }
 #ifdef PNN_F32_DIAG                                 // diagnostic library only (make diag): cycles and 100 MHz ticks of the MFMA wave's loop
     const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // The next chunk's two reads sit BETWEEN this chunk's MFMAs (one behind the first, one behind the third): both in front of the
+    // four measured 170 cycles per chunk in tools/f32_chain_probe.hip, interleaved 146 (the bare chain: 128).
     for (int s = 0; s < nst; s++) {
         const int cb = c0 + s * CS;
 #pragma unroll
         for (int k = 0; k < CS; k++) {
-            if (k + 1 < CS) {
-                read_chunk(slot, k + 1);
-            } else {
+            constexpr int kLast = CS - 1;
+            const int kn = k == kLast ? 0 : k + 1;
+            bool rd = true;
+            const f32x4* nsrc = ring + (slot * CS + kn) * 128 + lane;
+            if (k == kLast) {
                 const int nslot = slot + 1 == D ? 0 : slot + 1;
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the whole stage is in registers
-                if (s + 1 < nst) {
-                    __builtin_amdgcn_s_barrier();    // stage s + 1 is in the ring, the slot of stage s may be refilled
-                    read_chunk(nslot, 0);
-                }
+                rd = s + 1 < nst;
+                if (rd) __builtin_amdgcn_s_barrier();    // stage s + 1 is in the ring, the slot of stage s - 1 may be refilled
+                nsrc = ring + (nslot * CS) * 128 + lane;
                 slot = nslot;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (cb + k < c1) mfma_chunk(k);
+            if (cb + k < c1) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][0], fx[k][0], acc, 0, 0, 0);
+                if (rd) fw[kn] = nsrc[0];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][1], fx[k][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][2], fx[k][2], acc, 0, 0, 0);
+                if (rd) fx[kn] = nsrc[64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][3], fx[k][3], acc, 0, 0, 0);
+            } else if (rd) {
+                fw[kn] = nsrc[0]; fx[kn] = nsrc[64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #ifdef PNN_F32_DIAG

@@ -105,13 +105,9 @@ struct TapGemmParams {
 static_assert(sizeof(TapGemmParams) <= 512, "the argument block of the tap-GEMM kernels: 8 lines of 64 bytes");
 inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); }
 
-// Tile configurations of the MFMA kernel: BM = 64 * RT rows (4 waves x RT 16-row tiles), BN = 16 * NT.
 constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
 constexpr int kSegDepth = 1600, kSegMinDepth = 2304;   // K segments of the exact-f32 summation order, see finish_gemm_layer (pnn_model.cpp)
-struct TileCfg { int rt, nt, kc, mf, wm = 4, d = 2; };   // mf: MFMA shape, 16 (16x16x4, BM = 64*rt) or 32 (32x32x2, BM = 128*rt)
-int tapgemm32_num_cfgs();
-TileCfg tapgemm32_cfg(int idx);
-hipError_t launch_tapgemm32(const TapGemmParams& p, int idx, hipStream_t s);
+struct TileCfg { int rt, nt, kc, mf, wm = 4, d = 2; };   // a tile configuration of one of the tap-GEMM kernel families (mf: rows of the MFMA shape)
 int tapgemm_sp_num_cfgs();
 TileCfg tapgemm_sp_cfg(int idx);
 hipError_t launch_tapgemm_sp(const TapGemmParams& p, int idx, hipStream_t s);   // 3 x f16 MFMA, f32-class accuracy
@@ -149,9 +145,6 @@ hipError_t launch_tapgemm_small(const TapGemmParams& p, bool a_is_f32, int seg_c
 bool fc_out_small_fits(const TapGemmParams& p, int seg_chunks);
 hipError_t launch_fc_out_small(const TapGemmParams& p, int seg_chunks, hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 hipError_t launch_tapgemm_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
-int tapgemm_num_cfgs();
-TileCfg tapgemm_cfg(int idx);
-hipError_t launch_tapgemm(const TapGemmParams& p, int cfg_idx, hipStream_t s);
 // Exact-f32 tap GEMM on v_mfma_f32_32x32x2_f32, one wave per SIMD (pnn_gemm_f32.hip): the canonical f32 summation order.
 // fuse: apply the output layer p.W2p (f32 pack, <= 64 outputs) to the activated tile, partial sums to p.part[column tile][M][64]
 int tapgemm_f32_num_cfgs();
@@ -167,6 +160,9 @@ hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const
 hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
 hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);
+// ... and, for small M, the same segments AND their reduction (+ bias, HM epilogue) in one launch: fuse_reduce_kernel's bits
+bool fc_out_f32_small_fits(const TapGemmParams& p);
+hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
 
 // Cin == 1 forward convolution (first layer of each branch): direct VALU kernel.
 struct Conv1Params {
@@ -198,7 +194,6 @@ struct MergerParams {
     const float* A; const float* L; const float* Wp; const float* bias /* [j][C] */; float* Y;
     int B, C, na, nl, nout;
     int split;   // 1: write Y in the split f16 activation layout
-    int one_order;   // 1: always the batch kernel (canonical_order: one summation order for every batch size)
     int* range_flag; // split output only: raised when a value leaves the f16 range
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);

@@ -31,13 +31,9 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     static const bool debug = getenv("PNN_DEBUG") != nullptr;
     static const bool profile = getenv("PNN_PROFILE") != nullptr;   // tuning aid: per-launch timing, synchronous
     const double flops = 2.0 * (double)M * L.k_total * p.Cout + (next ? 2.0 * (double)M * next->k_total * next->proto.Cout : 0.0);
-    // ---- which kernel: tapgemm_f32_kernel (32x32x2 MFMA, the canonical f32 order) unless switched off, or, with canonical_order = 0,
-    // for launches too small to fill the chip with 128-row tiles (the split-K kernel spreads those over all CUs)
     const bool one_tap = (L.k_total == (double)p.Cin);
     const int cpt = p.Cin / 16;
-    bool f32k = c->opt_f32_kernel && c->opt_tile_cfg < 0;
-    if (f32k && !c->opt_canonical && !next && ((M + 127) / 128) * ((p.Cout + 31) / 32) * p.ncls < 192) f32k = false;
-    if (next && !f32k) return fail(c, PNN_E_ARG, "the fused output layer needs the tapgemm_f32 kernel");
+    constexpr bool f32k = true;                       // (until round 4 an option chose the round-1 kernels here)
     int cfg = -1;
     std::function<hipError_t(int)> launch;
     p.pm_groups = c->opt_ring_pm == 0 ? -1 : c->opt_ring_pm == 2 ? 1 : 0;   // position-major tiles: never / whenever possible / by the planner's model (launch_tapgemm_f32)
@@ -63,7 +59,8 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     }
     // Few output tiles (the in-loop single-block calls, the batching service's handfuls): the same fmaf chain per output on the 16x16x4
     // instruction, one wave per 16 x 16 tile over all CUs (pnn_gemm_f32_small.hip) -- bit-identical, 3.2 x shorter dependent chain
-    if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !getenv("PNN_F32_DIAG")) {
+    static const bool big_diag = getenv("PNN_F32_DIAG") != nullptr;
+    if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
         TapGemmParams ps = p;
         ps.Wp = L.d_w_ch;                             // the same weights in the small kernel's lane order
         if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d nseg=%d -> f32 small kernel (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, p.ncls, nseg, tapgemm_f32_small_tiles(p));
@@ -160,12 +157,9 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             }
         }
         if (tiles_out) { const TileCfg t = tapgemm_f32_cfg(cfg % ntile); *tiles_out = (int)((p.Cout + 32L * t.nt - 1) / (32L * t.nt)); }
-    } else {
-        cfg = choose_cfg(c, M, p.Cout, p.ncls, p.Cin, L.k_total);
-        launch = [&, p](int i) { return launch_tapgemm(p, i, s); };
     }
     const bool seq = f32k && nseg > 1 && cfg >= ntile;
-    const TileCfg t = f32k ? tapgemm_f32_cfg(cfg % ntile) : tapgemm_cfg(cfg);
+    const TileCfg t = tapgemm_f32_cfg(cfg % ntile);
     if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d -> %s cfg %d {rt %d, nt %d, kc %d}%s%s\n", M, L.k_total, p.Cout, p.ncls,
                        f32k ? "f32" : "legacy", cfg, t.rt, t.nt, t.kc, next ? " + fused output layer" : "",
                        nseg > 1 ? (seq ? ", K segments in sequence" : ", K segments in parallel + reduce") : "");
@@ -173,7 +167,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         pnn_ctx::LaunchRec r;
         HIPCHK(c, hipEventCreate(&r.e0));
         HIPCHK(c, hipEventCreate(&r.e1));
-        r.kind = (!f32k && t.rt == 0) ? 1 : 0;
+        r.kind = 0;
         r.flops = flops;
         const LaunchEvents ev{r.e0, r.e1};            // recorded by the launch itself: the kernel's own begin -> end
         g_launch_events = &ev;
@@ -515,7 +509,7 @@ bool branches_overlap_at_batch(const pnn_ctx* c, const Model* m, long nb)
     if (m->branch[0].size() < 2 || m->branch[1].size() < 2) return false;
     // (exact-f32 passes too, option f32_kernel: their launches end with a tail of big workgroups -- one or two per CU -- that the other
     // branch's launches fill)
-    return nb * m->width * m->width >= 65536 && (pass_uses_split(c, m, nb) || (c->opt_precision == 0 && c->opt_f32_kernel && c->opt_tile_cfg < 0 && c->opt_f32_overlap));
+    return nb * m->width * m->width >= 65536 && (pass_uses_split(c, m, nb) || (c->opt_precision == 0 && c->opt_f32_overlap));
 }
 
 int ensure_ws(pnn_ctx* c, const Model* m, long nb)
@@ -543,21 +537,8 @@ int ensure_ws(pnn_ctx* c, const Model* m, long nb)
 
 }  // namespace
 
-// Which arithmetic a pass of nb blocks runs on: the split-precision GEMM wins once the layers fill the chip; small
-// passes (HM's per-TB calls, short batches) are latency-bound and faster on the f32 kernels, whose split-K variant
-// spreads a small-M layer over all CUs (crossovers measured on device: ~500 blocks for the FC nets, ~200 for the
-// convolutional ones).  With canonical_order = 1 the choice must not depend on the batch size.
-bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb)
-{
-    if (c->opt_precision != 1) return false;
-    if (c->opt_canonical) return true;
-    if (c->opt_split_min_px >= 0) return nb * m->width * m->width >= c->opt_split_min_px;
-    if (m->is_fc) return nb >= 512;
-    // measured crossover of the two kernel families (host calls, rule-based tiles; option "split_min_px" to re-measure with
-    // sweeps of both paths around the crossover): 8x8 net ~150 blocks, 16x16 ~70, 32x32 ~34, 64x64 ~17
-    const long px = nb * m->width * m->width;
-    return px >= (m->width <= 8 ? 10000 : m->width == 16 ? 18000 : m->width == 32 ? 35000 : 70000);
-}
+// Which arithmetic a pass runs on: the context's, whatever the batch size (one summation order at every batch size).
+bool pass_uses_split(const pnn_ctx* c, const Model*, long) { return c->opt_precision == 1; }
 
 namespace {
 
@@ -626,7 +607,7 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
     // leave the registers of the waves that produce them; the 29 us / 14 %-of-peak launch of rounds 1-3 is gone) or from the
     // stored activations by fc_out_f32_kernel, which repeats the fused kernel's MFMA chain operand for operand.
     const int n_out = m->fc[3].proto.Cout;
-    if (c->opt_f32_kernel && c->opt_tile_cfg < 0 && n_out <= 64 && n_out % 4 == 0 && (c->opt_canonical || nb >= 1024)) {
+    if (n_out <= 64 && n_out % 4 == 0) {
         const int segs = (m->fc[3].proto.Cin + 159) / 160;
         if ((rc = dev_reserve(c, c->ws[3], (size_t)segs * nb * 64 * 4))) return rc;
         float* part = (float*)c->ws[3].p;
@@ -637,6 +618,18 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
             if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
             TapGemmParams q = m->fc[3].proto;
             q.X = P0; q.Wp = m->fc[3].d_w; q.part = part; q.M = (int)nb; q.x_bytes = (unsigned)(4.0 * (double)nb * q.Cin);
+            // small passes: the K segments and their reduction in ONE launch (fc_out_f32_small_kernel: the same bits, one launch less
+            // in the chain of a single-block call)
+            if (c->opt_fc_out_f32 && nb <= 512 && !c->opt_time_launches) {
+                TapGemmParams r = q;
+                r.part = nullptr; r.bias = m->fc[3].d_bias; r.mean = c->mean; r.Y = d_out; r.Yi = d_dst;
+                if (fc_out_f32_small_fits(r)) {
+                    HIPCHK(c, launch_fc_out_f32_small(r, s, take_done_signal(c)));
+                    c->stat_gemm_launches++; c->stat_launches++;
+                    c->stat_gemm_flops += 2.0 * (double)nb * m->fc[3].k_total * n_out;
+                    return PNN_OK;
+                }
+            }
             HIPCHK(c, launch_fc_out_f32(q, s, &tiles));
             c->stat_gemm_launches++; c->stat_launches++;
             c->stat_gemm_flops += 2.0 * (double)nb * m->fc[3].k_total * n_out;
@@ -673,7 +666,8 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     // cost ~4 us each whatever they do.  Layer i of both branches goes into ONE launch (conv_cin1_pair_kernel, then
     // tapgemm_small_pair_kernel): 13 -> 9 launches for the 16x16 net, no event traffic between streams.  Same kernels' bodies,
     // same arithmetic: bit-identical to the separate launches.
-    bool pair = sp && c->opt_pair && c->opt_small && c->opt_sp_cfg < 0 && !c->opt_time_launches && !getenv("PNN_PROFILE") &&
+    static const bool env_profile = getenv("PNN_PROFILE") != nullptr, env_sdiag = getenv("PNN_F32S_DIAG") != nullptr;   // (not per pass: getenv walks the environment)
+    bool pair = sp && c->opt_pair && c->opt_small && c->opt_sp_cfg < 0 && !c->opt_time_launches && !env_profile &&
                 m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
     for (size_t i = 0; pair && i < m->branch[0].size(); i++) {
         long tiles = 0;
@@ -717,6 +711,75 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             c->stat_gemm_launches++; c->stat_launches++;
             cur ^= 1;
         }
+    }
+    // The same on the exact-f32 arithmetic (round 5): conv_cin1_pair_kernel with f32 output (the context gather inside when the pass
+    // reads the picture plane itself), then tapgemm_f32_small_pair_kernel per layer; K-segmented layers (32x32 / 64x64 nets) leave
+    // their planes and get one seg_reduce launch per branch.
+    bool pair32 = !sp && !pair && c->opt_pair && c->opt_f32_small && c->opt_f32_cfg < 0 &&
+                  !c->opt_time_launches && !env_profile && !env_sdiag && m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
+    for (size_t i = 0; pair32 && i < m->branch[0].size(); i++) {
+        long tiles = 0;
+        for (int br = 0; br < 2; br++) {
+            TapGemmParams q = m->branch[br][i].proto;
+            q.M = (int)(nb * q.SH * q.SW); q.nseg = m->branch[br][i].nseg;
+            tiles += tapgemm_f32_small_tiles(q);
+        }
+        pair32 = tiles <= c->opt_f32_small_tiles;
+    }
+    if (pair32) {
+        if ((rc = dev_reserve(c, c->ws[4], (size_t)nb * m->pmax * 4))) return rc;
+        if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
+        float* Q[2][2] = {{P[0], P[1]}, {(float*)c->ws[4].p, (float*)c->ws[5].p}};
+        Conv1Params f[2];
+        for (int br = 0; br < 2; br++) {
+            f[br] = m->first[br].proto;
+            f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
+            f[br].Wsp = m->first[br].d_w_sp; f[br].out_scale = m->first[br].sp_inv_scale; f[br].npad = m->first[br].npad;
+            f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 0;
+            if (!f[br].X && c->lazy.plane) {
+                f[br].plane = c->lazy.plane; f[br].tbs = reinterpret_cast<const TbDev*>(c->lazy.tbs); f[br].pel_bytes = c->lazy.pel_bytes; f[br].unit = c->lazy.unit;
+                f[br].w = m->width; f[br].branch = br; f[br].mean = c->mean;
+            }
+        }
+        HIPCHK(c, launch_conv_cin1_pair(f[0], f[1], s));
+        c->stat_launches++;
+        const size_t nl = m->branch[0].size();
+        int cur = 0;
+        for (size_t i = 0; i < nl; i++) {
+            const bool last = i + 1 == nl;
+            TapGemmParams q[2];
+            float* dst[2];
+            size_t out_floats[2];
+            for (int br = 0; br < 2; br++) {
+                const GemmLayer& L = m->branch[br][i];
+                q[br] = L.proto;
+                q[br].X = Q[br][cur]; q[br].Wp = L.d_w_ch; q[br].bias = L.d_bias; q[br].mean = c->mean;
+                dst[br] = last ? F[br] : Q[br][cur ^ 1];
+                q[br].Y = dst[br];
+                q[br].M = (int)(nb * q[br].SH * q[br].SW);
+                q[br].x_bytes = (unsigned)(4.0 * (double)nb * q[br].IH * q[br].IW * q[br].Cin);
+                out_floats[br] = (size_t)nb * (size_t)L.out_per_block;
+                if (L.nseg > 1) {                     // raw sums into the branch's planes; seg_reduce below applies bias and activation
+                    DevBuf& sb = c->seg_part[br];
+                    if ((rc = dev_reserve(c, sb, (size_t)L.nseg * out_floats[br] * 4))) return rc;
+                    if (out_floats[br] >= 0xffffffffull) return fail(c, PNN_E_ARG, "batch too large for one pass");
+                    q[br].Y = (float*)sb.p; q[br].bias = (const float*)c->d_zero; q[br].act = 0; q[br].nseg = L.nseg; q[br].seg_stride = (unsigned)out_floats[br];
+                }
+                c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
+            }
+            static const bool dbg = getenv("PNN_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[pnn] f32 gemm pair: branch layer %zu, M = %d / %d -> one f32 small-kernel launch\n", i + 1, q[0].M, q[1].M);
+            HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s));
+            c->stat_gemm_launches++; c->stat_launches++;
+            for (int br = 0; br < 2; br++) {
+                const GemmLayer& L = m->branch[br][i];
+                if (L.nseg <= 1) continue;
+                HIPCHK(c, launch_seg_reduce(q[br].Y, L.nseg, out_floats[br], q[br].Cout, L.d_bias, L.proto.act, dst[br], s));
+                c->stat_launches++;
+            }
+            cur ^= 1;
+        }
+        pair = true;                                  // the branches are done
     }
     float* PB[2][2] = {{P[0], P[1]}, {P[0], P[1]}};
     if (par) { PB[1][0] = (float*)c->ws[4].p; PB[1][1] = (float*)c->ws[5].p; }
@@ -768,7 +831,6 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     MergerParams mp = m->merger.proto;
     mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
     mp.split = (sp && nt > 0) ? 1 : 0;
-    mp.one_order = c->opt_canonical ? 1 : 0;
     mp.range_flag = c->h_range;
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;

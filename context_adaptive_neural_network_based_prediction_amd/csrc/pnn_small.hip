@@ -555,54 +555,10 @@ __global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
     if (SPLIT) report_range(p.range_flag, amax);
 }
 
-// Small batches (the in-loop single-block calls): the 80-position sum of one output is split over 4 threads (positions
-// p = pg, pg + 4, ...) and combined through LDS in a fixed order -- four times the threads, a quarter of the dependent
-// load chain (the batch kernel above took ~20 us for ONE block: its 80 steps are serial per thread).
-// Workgroup = 64 channels x 4 position groups; grid = (C / 64, 4 output quads, B).  Same sum order for every batch size
-// that takes this kernel; the result differs from the batch kernel's in the last bits like any other re-association.
-__global__ __launch_bounds__(256) void merger_small_kernel(const MergerParams p)
-{
-    touch_kernargs<sizeof(MergerParams)>();
-    __shared__ float red[4][4][64];
-    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, jq = blockIdx.y;
-    const long b = blockIdx.z;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < p.C) {
-        auto part = [&](const float* src, int np, int pbase) {
-#pragma unroll 4
-            for (int pp = pg; pp < np; pp += 4) {
-                const float xv = src[(b * np + pp) * p.C + c];
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] += xv * p.Wp[((size_t)(pbase + pp) * 16 + 4 * jq + j) * p.C + c];
-            }
-        };
-        part(p.A, p.na, 0);
-        part(p.L, p.nl, p.na);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) red[pg][j][cl] = acc[j];
-    __syncthreads();
-    if (pg == 0 && c < p.C) {
-        float amax = 0.f;                            // range guard of the split output (pnn_device_common.h)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float v = leaky(((red[0][j][cl] + red[1][j][cl]) + (red[2][j][cl] + red[3][j][cl])) + p.bias[(size_t)(4 * jq + j) * p.C + c]);
-            if (p.split) store_split1(p.Y, ((size_t)b * 16 + 4 * jq + j) * p.C, c, v, amax);
-            else p.Y[(b * 16 + 4 * jq + j) * p.C + c] = v;
-        }
-        if (p.split) report_range(p.range_flag, amax);
-    }
-}
-
 hipError_t launch_merger(const MergerParams& p, hipStream_t s)
 {
     if (p.B <= 0) return hipSuccess;
     if (p.nout != 16) return hipErrorInvalidValue;
-    if (!p.one_order && (long)p.B * p.C <= 4096) {    // fewer than 64 waves in the batch kernel; not under canonical_order
-        hipLaunchKernelGGL(merger_small_kernel, dim3((p.C + 63) / 64, 4, p.B), dim3(256), 0, s, p);
-        return hipGetLastError();
-    }
     if (p.C % 16 == 0 && p.na % 4 == 0 && p.na + p.nl == 80) {
         const long bgs = ((p.B + 15) / 16 + 7) / 8 * 8;       // block groups, padded to the 8-way XCD interleave
         const dim3 grid((unsigned)(bgs * (p.C / 16))), block(256);

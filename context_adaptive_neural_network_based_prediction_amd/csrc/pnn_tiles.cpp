@@ -14,41 +14,6 @@
 
 namespace pnn {
 
-// Tile / pipeline choice. Rules distilled from on-device sweeps over every kernel configuration
-// (tools_cfg_sweep.sh; all shapes of the FC-8 and conv-16 nets): once the grid fills the chip every
-// reasonable tile lands within ~3 % (the f32 matrix pipes run at ~1.9 GHz under this load and are
-// ~82 % busy), so the choice only has to (a) avoid column padding, (b) keep >= 2-3 workgroups per CU,
-// and (c) switch to the split-K kernel when M is too small to fill 256 CUs with 64-row tiles.
-namespace {
-int find_cfg(int rt, int nt, int kc, int mf)
-{
-    for (int i = 0; i < tapgemm_num_cfgs(); i++) {
-        const TileCfg t = tapgemm_cfg(i);
-        if (t.rt == rt && t.nt == nt && t.kc == kc && t.mf == mf) return i;
-    }
-    return -1;
-}
-}  // namespace
-
-int choose_cfg(const pnn_ctx* c, long M, int cout, int ncls, int cin, double k_total)
-{
-    if (c->opt_tile_cfg >= 0 && c->opt_tile_cfg < tapgemm_num_cfgs()) return (int)c->opt_tile_cfg;
-    const int cpt = cin / 16;
-    const bool one_tap = (k_total == (double)cin);
-    const int kc = (one_tap || cpt % 2 == 0) ? 2 : 1;             // a stage must not straddle two taps
-    int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : ((cout % 128 == 0 && M >= 32768) ? 8 : 4));
-    const long wgs_std = ((M + 63) / 64) * ((cout + 16L * nt - 1) / (16L * nt)) * ncls;
-    if (wgs_std < 192 && !c->opt_canonical) {                     // small M: four waves split K instead
-        int nts = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
-        while (nts > 1 && ((M + 15) / 16) * ((cout + 16L * nts - 1) / (16L * nts)) * ncls < 128) nts >>= 1;
-        const int i = find_cfg(0, nts, 1, 16);
-        if (i >= 0) return i;
-    }
-    int i = find_cfg(1, nt, kc, 16);
-    if (i < 0) i = find_cfg(1, nt, 1, 16);
-    return i < 0 ? 0 : i;
-}
-
 // tapgemm_f32_kernel (32x32x2 MFMA, few waves with big tiles): the tile that finishes first by a list-scheduling estimate.  Every
 // tile runs its loop at 0.95-0.98 of the matrix rate (PNN_F32_DIAG stamps), so a launch costs its padded
 // MFMA work spread over 256 CUs, plus a tail of about half a workgroup unless the workgroups fit the chip exactly (FC 8x8 at batch

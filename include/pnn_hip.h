@@ -63,90 +63,66 @@ void pnn_destroy(pnn_ctx* ctx);
 const char* pnn_last_error(const pnn_ctx* ctx);     /* ctx may be NULL: last error of a failed create */
 float pnn_mean(const pnn_ctx* ctx);
 
-/* Options: "precision" (1, default: tap GEMMs form every f32 product from three f16 MFMAs on hi/lo operand halves --
- * f32-class accuracy: operands carry 22 significand bits and the lo x lo term is dropped; 2.3-2.7x the blocks/s of 0 on
- * the bench workloads; 0: exact-f32 MFMA, IEEE float32 operands -- the reference's arithmetic), "sp_cfg" / "tile_cfg" (-1 = automatic tile choice; an
- * "sp_cfg" code in [0, pnn_num_split_configs()) forces one configuration of one of the three split-GEMM kernels on
- * every layer it can run -- all of them give bit-identical results), "ring" / "convimg" (1, default: the LDS-DMA ring
- * kernel / the LDS-resident-image convolution kernel may be chosen; 0: never), "fuse_last" (1, default: passes of
- * >= 1024 blocks through a fully-connected PNN with <= 64 outputs run the output layer inside the last hidden layer's
- * kernel; 0: separate launches), "cache_mb" (0, default: off; > 0: single-block host calls -- pnn_predict_pel / _fc /
- * _conv with n == 1, what HM issues -- are answered from a direct-mapped cache of that many MiB when the same input
- * bytes were predicted before: HM's rate-distortion search asks for the same block repeatedly; exact
- * match on the inputs, dropped whenever a model or an option changes),
- * "autotune" (the first call that meets a new (layer, batch size) pair times every legal configuration of the three
- * split-precision GEMM kernels on the device and keeps the fastest -- all of them give bit-identical results, so only
- * the speed depends on it; 2, default: only for launches of >= 4 GFLOP, i.e. big batches, where it costs a few tens
- * of milliseconds once; 1: always; 0: rule-based choice only.  Do the first call outside any timed region; while the
- * stream is being captured into a hipGraph nothing is timed -- the rule-based choice is used),
- * "fuse_first" (1, default: a convolutional net's second layer, when it runs on the LDS-resident-image kernel, computes
- * the branch's first (one-input-channel) convolution itself instead of reading it back from memory; 0: separate launch.
- * Bit-identical either way),
- * "fuse_gather" (1, default: pnn_predict_tbs_device / _cost_device on a convolutional net whose first convolutions run fused
- * inside the image kernel let that kernel read the contexts straight from the picture plane through the TB descriptors -- no
- * gather launch; bit-identical; 0: always gather first),
- * "flag_wait" (1, default: a small host call -- pnn_predict_pel / pnn_predict_f32 / pnn_predict_f32_pel on up to 64 KiB of input,
- * i.e. what HM and the batching service issue -- ends when the call's LAST kernel, behind its results in pinned host memory,
- * raises a sequence number there, which the calling thread spins on, instead of when the runtime reports the stream idle:
- * 3-7 us less per call; 0: hipStreamSynchronize.  Results do not depend on it),
- * "ring_pm" (1, default: convolutions at batch on the LDS-DMA ring kernel take position-major tiles -- a tile = many blocks at
- * ONE position of the feature map, so a tap that only meets the SAME padding there is skipped for the whole tile -- where
- * the launch model of pnn_gemm_ring.hip expects them to finish no later; 2: wherever possible; 0: never.  The skipped products
- * are exact zeros: bit-identical in every mode),
- * "fuse_tail" (1, default: when the last 64-channel layer of a convolutional net runs on the LDS-resident-image kernel, that
- * kernel applies the net's last layer -- the one-output-channel transposed convolution -- to its output tile in registers: no
- * round trip of the 64-channel maps, one launch less; 0: separate launch.  Bit-identical either way),
- * "split_min_px" (-1, default: built-in rule; >= 0: with precision 1, passes through a convolutional net use the
- * split-precision kernels from this many block pixels (blocks x w^2) on and the exact-f32 kernels below -- tuning aid),
- * "branch_streams" (1, default: small passes of the 32x32 / 64x64 convolutional nets -- the in-loop single-block
- * calls -- run the two independent branches on two HIP streams, forked and joined by events, and so do passes at batch
- * (>= 65536 block pixels on the split-precision kernels) from the third pass of a shape on, i.e. once a one-stream pass
- * needed no tuning sweep; 2: also every small conv pass; 0: one stream.  Results do not depend on it),
- * "small" (1, default: split-precision GEMMs with at most "small_max_tiles" (512) output tiles of 32 x 32 -- single-block
- * calls, small batches -- run on tapgemm_small_kernel, one wave per tile spread over the chip, in the SAME per-output
- * summation order as the big-tile kernels; 0: big-tile kernels only),
- * "pair" (1, default: such small passes of a convolutional net run layer i of BOTH branches as one launch -- they do not
- * depend on each other and a launch costs ~4 us whatever it does; bit-identical to separate launches; 0: one launch each),
- * "fc_out" (0, default; 1: small passes through a fully-connected PNN with <= 64 outputs run the output layer's K segments
- * AND their reduction as one launch, fc_out_small_kernel -- bit-identical, one launch less, measured no faster) and
- * "spin_wait" (0, default; 1: synchronous host calls poll the stream with hipStreamQuery instead of blocking in
- * hipStreamSynchronize -- measured no faster): two round-3 experiments on the single-block call kept as switches,
- * "f32_kernel" (1, default: exact-f32 passes -- "precision" 0, the range fallback of host calls -- run their tap GEMMs on
- * tapgemm_f32_kernel: v_mfma_f32_32x32x2_f32, one wave per SIMD, one per-output summation order for every tile and batch size;
- * fully-connected nets with <= 64 outputs sum the output layer in K segments of 160 hidden units at every batch size, inside the
- * last hidden layer's launch from 1024 blocks on ("fuse_last"); convolution layers deeper than 2304 per output are summed in K
- * segments of at most 1600 -- whole taps, added in order: by a second launch over planes of partial sums where the segments run as
- * separate workgroups ("f32_seg_mode" 0, default), inside the workgroups where they run in sequence (1: no planes, no second launch;
- * measured no faster at any batch size; -1: by cost model / tuner); same bits -- at every batch size; "ring_pm", "branch_streams", "fuse_gather" and "autotune" apply to
- * these passes like to the split-precision ones; 0: the round-1 kernels, tapgemm_kernel on 16x16x4 MFMA and the split-K kernel
- * for small M), "f32_cfg" (-1, default; >= 0 forces one tapgemm_f32 tile on every layer it is legal for -- tuning aid, all tiles
- * give the same bits), "f32_overlap" (1, default: the two branches of an exact-f32 conv pass at batch on two streams; 0: one),
- * "f32_persist" (-1, default: a convolution launch of more than two and at most six tiles per CU runs on two PERSISTENT workgroups
- * per CU, each taking its tiles one after the other; 0: never; N > 0: N per CU whenever there are more tiles; same bits),
- * "max_chunk" (blocks per pass, 0 = automatic), "ws_cap_mb", "time_launches",
- * "canonical_order" (1, default: every batch size uses the same per-output summation order, so a block's float
- * prediction is bit-identical whether it is predicted alone or inside any batch -- what an encoder/decoder pair needs
- * (single-block calls then run on tapgemm_small_kernel, the output layer of the 4x4 / 8x8 nets is summed in the same K
- * segments as the big batches' fused output layer); 0: small passes may use the exact-f32 split-K kernels, a few
- * microseconds faster per single-block call, whose float result can differ in the last bits, i.e. by one LSB on an
- * exact .5 tie -- never mix the two modes between an encoder and its decoder). */
+/* Options (name, default, meaning).  None of them changes a result bit unless it says so; most exist for A/B measurements.
+ *
+ * ARITHMETIC -- the one option an encoder and its decoder must agree on:
+ *   "precision"      0  the reference's arithmetic: IEEE float32 products and sums (Session::Run in float32, TComPrediction.cpp:572-579,
+ *                       601-608; pnn/components.py:169-176) on the f32 matrix instructions.  Default since round 5.
+ *                    1  every f32 product from three f16 MFMAs on hi/lo operand halves (22 significand bits per operand, lo x lo dropped:
+ *                       f32-class accuracy, within the same +-1 LSB of the oracle) -- 2.3-2.7 x the blocks/s at batch, 5-25 % less per
+ *                       single-block call.  Predictions of the two modes differ in the last float bits, i.e. by one LSB on .5 ties.
+ *   Within a mode ONE per-output summation order holds at every batch size and on every kernel: a block's prediction is bit-identical
+ *   whether it is predicted alone, in a handful or in any batch ("canonical_order" is kept as a name and accepts only 1).
+ *
+ * EXACT-F32 KERNELS ("precision" 0; also the range fallback of mode 1):
+ *   "f32_small"            1   launches of at most "f32_small_max_tiles" (1024) output tiles of 16 x 16 -- single-block calls, the
+ *                              batching service's handfuls -- run on tapgemm_f32_small_kernel (the canonical fmaf chain issued through
+ *                              v_mfma_f32_16x16x4_f32, one wave per tile); 0: tapgemm_f32_kernel's 128-row tiles at every size
+ *   "fc_out_f32"           1   FC passes of <= 512 blocks: output layer's K segments + their reduction in one launch
+ *   "f32_cfg"             -1   >= 0: force tile code [0, pnn_num_f32_configs()) of tapgemm_f32_kernel on every layer it is legal for
+ *   "f32_seg_mode"         0   K segments of the deep convolution layers (> 2304 per output: summed in segments of <= 1600, whole taps,
+ *                              added in order): 0 separate workgroups + a reduction launch, 1 in sequence inside the workgroups, -1 by model
+ *   "f32_persist"         -1   convolution launches of 2-6 tiles per CU on two persistent workgroups per CU; 0 never; N > 0: N per CU
+ *   "f32_overlap"          1   the two branches of a conv pass at batch on two streams
+ *   "fuse_last"            1   FC passes of >= 1024 blocks run the <= 64-output layer inside the last hidden layer's kernel (both modes)
+ * SPLIT-F16 KERNELS ("precision" 1):
+ *   "sp_cfg"              -1   >= 0: force configuration code [0, pnn_num_split_configs()) of the three split-GEMM kernel families
+ *   "ring" / "convimg"     1   the LDS-DMA ring kernel / the LDS-resident-image convolution kernel may be chosen
+ *   "small"                1   GEMMs of at most "small_max_tiles" (512) tiles of 32 x 32 run on tapgemm_small_kernel (one wave per tile)
+ *   "fc_out"               0   1: small FC passes run output-layer segments + reduction as one launch (measured no faster)
+ *   "fuse_first"           1   the image kernel computes a branch's first (one-input-channel) convolution itself
+ *   "fuse_tail"            1   the image kernel of the last 64-channel layer applies the net's last layer to its output tile
+ *   "ring_pm"              1   position-major tiles (skip the taps that only meet SAME padding) where the launch model expects a gain;
+ *                              2 wherever possible; 0 never.  Applies to tapgemm_f32_kernel's convolution launches too
+ *   "autotune"             2   on first sight of a (layer, batch) pair time the legal configurations on the device and keep the fastest:
+ *                              2 only launches >= 4 GFLOP, 1 always, 0 rule-based choice only.  Never while the stream is being captured
+ * BOTH:
+ *   "pair"                 1   small conv passes run layer i of BOTH branches as one launch
+ *   "branch_streams"       1   small passes of the 32x32 / 64x64 nets, and passes at batch, run the two branches on two streams; 2: every
+ *                              small conv pass too; 0: one stream
+ *   "fuse_gather"          1   pnn_predict_tbs_device on a conv net: the first convolution reads the picture plane through the descriptors
+ *   "cache_mb"             0   > 0: single-block host calls are answered from a direct-mapped cache of that many MiB when the same input
+ *                              bytes were predicted before (HM's RD search repeats itself); dropped on any option / model change
+ *   "flag_wait"            1   a small host call ends when its LAST kernel raises a sequence number in pinned host memory (3-7 us earlier
+ *                              than the runtime's completion signal); "spin_wait" (0): hipStreamQuery polling instead of hipStreamSynchronize
+ *   "host_pipeline"        1   batched HOST-array calls above 64 KiB stream through a pinned ring in chunks: H2D, compute and D2H overlap;
+ *                              0: one synchronous copy in, one pass, one copy out
+ *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
+ */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
-/* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING,
- * PNN_CONVIMG, PNN_SMALL, PNN_CANONICAL_ORDER, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER, PNN_FUSE_TAIL, PNN_RING_PM, PNN_FUSE_LAST, PNN_BRANCH_STREAMS, PNN_TILE_CFG, PNN_MAX_CHUNK, PNN_F32_KERNEL, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE, PNN_F32_PERSIST.  Diagnostics:
- * PNN_DEBUG (tile choice of every GEMM launch on stderr), PNN_DEBUG_TUNE (every timed configuration), PNN_PROFILE
- * (synchronous per-launch timing), PNN_LIB_PATH (Python loader: another build of the library).  Experiment switches of
- * individual launchers, not part of the interface: PNN_SK_WAVES, PNN_LDS_PAD, PNN_SP_DIAG, PNN_F32_DIAG (diagnostic library of `make diag` only),
- * PNN_F32_SEG_DEPTH / PNN_F32_SEG_MIN (the K segments of the exact-f32 summation order, read when a model is loaded; 0 = none. They
- * DEFINE that order: an encoder and its decoder must run with the same values -- leave them alone outside A/B measurements). */
-/* Input-range contract of the default arithmetic ("precision" = 1): operands travel as pairs of f16 values, so every
- * intermediate activation must satisfy |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude
- * below that; arbitrary float inputs or models may not.  The kernels detect a violation (they never emit
- * a silent NaN; the raw context a convolutional net's first layer splits in registers is checked where it is staged): host entry points (pnn_predict_fc / _conv / _pel / _f32_pel) then recompute, on the exact-f32 kernels and
- * by themselves, exactly the blocks that overflow when predicted alone (batches of <= 256; the other blocks of the batch keep
- * the bits they get in any batch), and they refuse non-finite inputs (PNN_E_ARG) -- the guard's max would drop a NaN; models
- * with a non-finite parameter are refused at load (PNN_E_MODEL).  Device entry points are asynchronous, so the NEXT call on the context fails with PNN_E_RANGE, and
- * pnn_check_range -- which waits for `stream` -- tells right away (returns PNN_OK or PNN_E_RANGE; *host_fallbacks, optional,
- * = how many host calls took the exact-f32 repeat so far). */
+/* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING, PNN_CONVIMG,
+ * PNN_SMALL, PNN_F32_SMALL, PNN_F32_SMALL_TILES, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER,
+ * PNN_FUSE_TAIL, PNN_FUSE_LAST, PNN_RING_PM, PNN_BRANCH_STREAMS, PNN_MAX_CHUNK, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE,
+ * PNN_F32_PERSIST.  Diagnostics: PNN_DEBUG (kernel choice of every GEMM launch on stderr), PNN_DEBUG_TUNE, PNN_PROFILE (synchronous
+ * per-launch timing), PNN_HOST_TRACE, PNN_LIB_PATH (Python loader: another build of the library); diagnostic library of `make diag`
+ * only: PNN_SP_DIAG, PNN_F32_DIAG, PNN_F32S_DIAG. */
+/* Input-range contract of "precision" 1: operands travel as pairs of f16 values, so every intermediate activation must satisfy
+ * |v| < 65504.  8-bit contexts through trained models stay two orders of magnitude below that; arbitrary float inputs or
+ * models may not.  The kernels detect a violation (never a silent NaN): host entry points then recompute, on the exact-f32 kernels,
+ * exactly the blocks that overflow when predicted alone (batches of <= 256; the other blocks keep the bits they get in any batch) and
+ * refuse non-finite inputs (PNN_E_ARG); models with a non-finite parameter are refused at load (PNN_E_MODEL).  Device entry points are
+ * asynchronous: the NEXT call on the context fails with PNN_E_RANGE, and pnn_check_range -- which waits for `stream` -- tells right
+ * away (*host_fallbacks, optional = how many host calls took the exact-f32 repeat so far).  "precision" 0 has no such bound. */
 int pnn_check_range(pnn_ctx* ctx, void* stream, long* host_fallbacks);
 
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
@@ -232,8 +208,8 @@ int pnn_predict_tbs_cost_device(pnn_ctx* ctx, int width, const void* d_plane, co
 int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_flops, int* n_launches);
 
 /* With pnn_set_option(ctx, "time_launches", 1) every tap-GEMM launch is bracketed by HIP events on its launch
- * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_kernel / tapgemm32_kernel,
- * 1 = tapgemm_splitk_kernel, 2 = tapgemm_sp_kernel, 3 = convimg_sp_kernel, 4 = tapgemm_ring_kernel, 5 = tapgemm_small_kernel), the number of
+ * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_f32_kernel, 2 = tapgemm_sp_kernel,
+ * 3 = convimg_sp_kernel, 4 = tapgemm_ring_kernel, 5 = tapgemm_small_kernel, 6 = tapgemm_f32_small_kernel), the number of
  * launches since the last call, their summed duration and their summed algorithmic FLOPs. */
 int pnn_launch_times(pnn_ctx* ctx, int kind, int* n_launches, double* total_us, double* total_flops);
 

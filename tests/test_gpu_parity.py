@@ -416,6 +416,9 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
             if m <= n:
                 assert np.array_equal(run(above[n - m:], left[n - m:]), want[n - m:]), "%d blocks, f32_small_max_tiles = %d" % (m, limit)
     pel = net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))
+    net.set_option("fc_out_f32", 0)                                  # FC: the output layer's K segments and their reduction as two launches
+    assert np.array_equal(run(above, left), want)
+    assert np.array_equal(net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left))), pel)
     net.set_option("f32_small", 0)
     assert np.array_equal(net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left))), pel)
     m = min(n, 24)
@@ -537,9 +540,8 @@ def _natural_contexts(w, n, seed):
 @pytest.mark.parametrize("w", [4, 8])
 def test_trained_checkpoints_through_the_split_kernels(pnn, oracle, precision, w):
     """The reference's two trained models on the 3 x f16 split-product kernels (ring / register-staged / LDS-resident-image),
-    the default arithmetic of every batched call: 1024 natural-like contexts in one pass (the batch rule sends that to the
-    split kernels), and the committed 8 contexts with `split_min_px` = 0 and under `canonical_order` (which pin the split
-    kernels at any batch size).  Float predictions within FLOAT_ATOL of the oracle, Pel within one LSB."""
+    1024 natural-like contexts in one pass and the committed 8 contexts (small-M kernels: the same summation order).  Float
+    predictions within FLOAT_ATOL of the oracle, Pel within one LSB."""
     if precision != "split_f16":
         pytest.skip("split-precision kernels only")
     path = os.path.join(GOLD, "conv%d_single.pnnw" % w)
@@ -554,13 +556,11 @@ def test_trained_checkpoints_through_the_split_kernels(pnn, oracle, precision, w
     _check_pel(net.predict_pel(ab, lf), oracle.epilogue(want, util.MEAN))
     assert want.max() - want.min() > 60                              # real pictures, not a flat answer
     g = np.load(os.path.join(GOLD, "nets.npz"))
-    for opt in ("split_min_px", "canonical_order"):
-        net2 = pnn.PredictionNeuralNetwork(8, w, False, path_to_model=path)
-        net2.set_option(opt, 0 if opt == "split_min_px" else 1)
-        got8 = net2.predict(g["real%d_above" % w], g["real%d_left" % w])
-        np.testing.assert_allclose(got8[..., 0], g["real%d_out" % w], rtol=0, atol=FLOAT_ATOL)
-        _check_pel(net2.predict_pel(g["real%d_above" % w], g["real%d_left" % w]), oracle.epilogue(g["real%d_out" % w], util.MEAN))
-        net2.close()
+    net2 = pnn.PredictionNeuralNetwork(8, w, False, path_to_model=path)
+    got8 = net2.predict(g["real%d_above" % w], g["real%d_left" % w])
+    np.testing.assert_allclose(got8[..., 0], g["real%d_out" % w], rtol=0, atol=FLOAT_ATOL)
+    _check_pel(net2.predict_pel(g["real%d_above" % w], g["real%d_left" % w]), oracle.epilogue(g["real%d_out" % w], util.MEAN))
+    net2.close()
 
 
 @pytest.mark.parametrize("w,n", [(16, 200), (16, 2), (8, 300), (32, 40)])
@@ -890,9 +890,6 @@ def test_full_size_properties(pnn, oracle, w, is_fc, n):
     net.set_option("max_chunk", 300)                                 # ragged chunks: 300, 300, ..., remainder
     assert np.array_equal(run(above, left), full)                    # one summation order (the default): chunking changes nothing, bit for bit
     assert np.array_equal(run(above[5:6], left[5:6])[0], full[5])    # ... down to a batch of one
-    net.set_option("canonical_order", 0)                             # opt-out: small passes may take the f32 split-K kernels
-    np.testing.assert_allclose(run(above, left), full, rtol=0, atol=FLOAT_ATOL)
-    net.set_option("canonical_order", 1)
     net.set_option("max_chunk", 0)
     assert np.array_equal(full[n // 2], full[3])
     idx = np.arange(n) if is_fc else np.random.RandomState(1).choice(n, 256, replace=False)

@@ -362,16 +362,20 @@ def test_hm_with_the_pnn_on_host_cores_needs_no_gpu(hm_built, oracle, tmp_path, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,picture_set", [("kodak", "synthetic"), ("kodak", "natural"), ("bsds", "synthetic"), ("bsds", "natural")])
-def test_hm_campaign_at_stated_counts(hm_built, oracle, tmp_path, config, picture_set):
+@pytest.mark.parametrize("config,picture_set,arithmetic", [("kodak", "synthetic", "f32"), ("kodak", "natural", "f32"), ("bsds", "synthetic", "f32"), ("bsds", "natural", "f32"),
+                                                           ("kodak", "natural", "split"), ("bsds", "synthetic", "split")])
+def test_hm_campaign_at_stated_counts(hm_built, oracle, tmp_path, config, picture_set, arithmetic):
     """BASELINE.json configs[3] / configs[4] AS STATED: 24 pictures of 768 x 512 through hm_16_15_substitution, 100 pictures of
     480 x 320 through hm_16_15_switch (all widths 4-64), every encode in flight behind one batching service per device -- on the
     engineered synthetic pictures and on windows of the natural fixtures (widths 4 / 8 then run the reference's trained checkpoints).
     Every decoded picture must equal its encoder's reconstruction, and the service that served the campaign must answer seeded
-    contexts of every width like the oracle (within 1 LSB: .5 ties) -- asked through the same socket before it stops."""
+    contexts of every width like the oracle (within 1 LSB: .5 ties) -- asked through the same socket before it stops.
+    All four on the reference's arithmetic (float32, TComPrediction.cpp:572-579,601-608: the library's default since round 5), two of
+    them on the split-f16 mode as well."""
     import campaign
     from tests import util
-    r = campaign.run_campaign(config, str(tmp_path / "work"), [0], picture_set=picture_set, yardstick=False, spot_check=True, timeout=600)
+    r = campaign.run_campaign(config, str(tmp_path / "work"), [0], picture_set=picture_set, yardstick=False, spot_check=True, timeout=600, arithmetic=arithmetic)
+    assert r["arithmetic"] == arithmetic
     assert r["pictures"] == campaign.CONFIGS[config]["pictures"] == (24 if config == "kodak" else 100)
     assert r["picture_size"] == ("768x512 4:0:0" if config == "kodak" else "480x320 4:0:0")
     assert r["variant"] == ("hm_16_15_substitution" if config == "kodak" else "hm_16_15_switch")

@@ -67,7 +67,7 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
     assert n_objects >= 5 and n_mfma > 1000           # really looked at the kernels
     # every kernel family has device code in the shipped library: hipcc once emitted a host object WITHOUT its .hip_fatbin section,
     # with exit code 0 (an LDS-DMA builtin called straight from a lambda inside a __global__ template, pnn_convimg_sp.hip)
-    for family in ("tapgemm_f32_kernel", "tapgemm_ring_kernel", "convimg_sp_kernel", "tapgemm_sp_kernel", "tapgemm_small_kernel", "tapgemm_kernel",
+    for family in ("tapgemm_f32_kernel", "tapgemm_ring_kernel", "convimg_sp_kernel", "tapgemm_sp_kernel", "tapgemm_small_kernel", "tapgemm_f32_small_kernel",
                    "conv_cin1_kernel", "merger_mfma_kernel", "tconv_cout1_mfma_kernel", "fuse_reduce_kernel", "fc_out_f32_kernel", "block_cost_kernel"):
         assert any(k.startswith(family) for k in kernels_seen), "no device code for %s in %s" % (family, _lib.LIB_PATH)
 

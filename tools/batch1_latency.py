@@ -1,9 +1,8 @@
 """Batch-1 latency of the host-buffer entry point HM binds (pnn_predict_pel: staging + net + epilogue + wait), per width and
 arithmetic, and the weight stream it amounts to (a single-block call is bound by streaming the net's parameters):
-    split f16 (the library default, what HM in the loop uses; one summation order at every batch size),
-    exact f32 in the canonical order (round 5: tapgemm_f32_small_kernel, the canonical fmaf chain on the 16x16x4 instruction; with
+    split f16 (option precision = 1; one summation order at every batch size),
+    exact f32 in the canonical order (the library default since round 5: tapgemm_f32_small_kernel, the canonical fmaf chain on the 16x16x4 instruction; with
     f32_small = 0 tapgemm_f32_kernel's 128-row tiles at M = 1; fc_out_f32_kernel: the same bits as any batch),
-    exact f32 with canonical_order = 0 (the split-K kernels: faster, last float bits differ from the batched result).
         python tools/batch1_latency.py > profiles/rNN_batch1_latency.txt        (GPU box)"""
 import os, sys, time
 import numpy as np
@@ -18,10 +17,8 @@ for w, fc in ((4, True), (8, True), (16, False), (32, False), (64, False)):
     x = util.flatten_fc(a, l) if fc else a
     dst = np.zeros((w, w), np.int32)
     lp = None if fc else l.ctypes.data_as(_lib.f32p)
-    for label, precision, canonical, small in (("split f16", 1, 1, 1), ("exact f32, canonical order (16x16x4 chain)", 0, 1, 1),
-                                               ("exact f32, canonical order, f32_small = 0", 0, 1, 0), ("exact f32, canonical_order = 0", 0, 0, 0)):
+    for label, precision, small in (("exact f32 (the default; 16x16x4 chain)", 0, 1), ("exact f32, f32_small = 0 (128-row tiles)", 0, 0), ("split f16", 1, 1)):
         net.set_option("precision", precision)
-        net.set_option("canonical_order", canonical)
         net.set_option("f32_small", small)
         for _ in range(50):
             L.pnn_predict_pel(net.ctx, w, x.ctypes.data_as(_lib.f32p), lp, 1, dst.ctypes.data_as(_lib.i32p), w)

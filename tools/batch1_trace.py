@@ -1,5 +1,5 @@
 """Single-block calls (what HM issues) for rocprofv3 --kernel-trace: per-kernel time of one width at batch 1.
-usage: batch1_trace.py <width> <canonical 0|1> [calls]"""
+usage: batch1_trace.py <width> <unused> [calls]      (arithmetic: PNN_PRECISION, default exact f32)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,6 @@ calls = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 fc = w <= 8
 L = _lib.lib()
 net = PredictionNeuralNetwork(1, w, fc, params=util.make_params(w, fc, 1))
-net.set_option("canonical_order", canon)
 a, l = util.make_contexts(w, 1, 2)
 x = util.flatten_fc(a, l) if fc else a
 dst = np.zeros((w, w), np.int32)

@@ -42,6 +42,30 @@ __global__ __launch_bounds__(64) void probe(const float* in, float* out, unsigne
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, acc, 0, 0, 0);
             }
             w0 = nw0; w1 = nw1; x0 = nx0; x1 = nx1;
+        } else if (MODE == 6 || MODE == 7 || MODE == 8) {
+            // two chunks per iteration, two register sets (no copies): the kernel's real loop.  6: both reads of the next chunk in front of
+            // a chunk's four MFMAs; 7: one read behind MFMA 0, one behind MFMA 2; 8: as 6 with a 32-byte-per-lane layout read as ONE
+            // ds_read_b128 + nothing (weights only: the activations stay in registers)
+            const f32x4* src = lds + ((it & 1) << 9) + lane;
+            f32x4 nw, nx;
+            if (MODE == 6) { nw = src[0]; nx = src[64]; __builtin_amdgcn_sched_barrier(0); }
+            if (MODE == 8) { nw = src[0]; nx = x1; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[i], x0[i], acc, 0, 0, 0);
+                if (MODE == 7 && i == 0) { nw = src[0]; __builtin_amdgcn_sched_barrier(0); }
+                if (MODE == 7 && i == 2) { nx = src[64]; __builtin_amdgcn_sched_barrier(0); }
+            }
+            f32x4 mw, mx;
+            if (MODE == 6) { mw = src[128]; mx = src[192]; __builtin_amdgcn_sched_barrier(0); }
+            if (MODE == 8) { mw = src[128]; mx = x0; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nw[i], nx[i], acc, 0, 0, 0);
+                if (MODE == 7 && i == 0) { mw = src[128]; __builtin_amdgcn_sched_barrier(0); }
+                if (MODE == 7 && i == 2) { mx = src[192]; __builtin_amdgcn_sched_barrier(0); }
+            }
+            w0 = mw; x0 = mx;
         } else if (MODE == 3) {                       // the 32x32x2 chain: 8 dependent MFMAs per 16 k
 #pragma unroll
             for (int i = 0; i < 8; i++) acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[i & 3], x0[i & 3], acc32, 0, 0, 0);
@@ -61,19 +85,22 @@ __global__ __launch_bounds__(64) void probe(const float* in, float* out, unsigne
 int main()
 {
     float *in, *out; unsigned long long* cyc;
-    hipMalloc(&in, 4096); hipMalloc(&out, 1 << 16); hipMalloc(&cyc, 64);
+    hipMalloc(&in, 4096); hipMalloc(&out, 1 << 16); hipMalloc(&cyc, 128);
     hipMemset(in, 0, 4096);
     const int n = 2000;
-    const char* names[6] = {"16x16x4 chain, bare", "16x16x4 chain + operand selects", "16x16x4 chain + selects + LDS reads", "32x32x2 chain, bare", "4x4x1 chain, bare", "v_fma_f32 chain"};
-    const int per[6] = {4, 4, 4, 8, 16, 16};
+    const char* names[9] = {"16x16x4 chain, bare", "16x16x4 chain + operand selects (hoisted by the compiler)", "16x16x4 chain + selects + LDS reads (exposed)", "32x32x2 chain, bare", "4x4x1 chain, bare", "v_fma_f32 chain",
+                            "16x16x4 chain + 2 LDS reads per chunk, in front", "16x16x4 chain + 2 LDS reads per chunk, interleaved", "16x16x4 chain + 1 LDS read per chunk"};
+    const int per[9] = {4, 4, 4, 8, 16, 16, 8, 8, 8};
+    const int chunks[9] = {1, 1, 1, 1, 1, 1, 2, 2, 2};
     for (int rep = 0; rep < 2; rep++) {
         probe<0><<<1, 64>>>(in, out, cyc, n); probe<1><<<1, 64>>>(in, out, cyc, n); probe<2><<<1, 64>>>(in, out, cyc, n);
         probe<3><<<1, 64>>>(in, out, cyc, n); probe<4><<<1, 64>>>(in, out, cyc, n); probe<5><<<1, 64>>>(in, out, cyc, n);
+        probe<6><<<1, 64>>>(in, out, cyc, n); probe<7><<<1, 64>>>(in, out, cyc, n); probe<8><<<1, 64>>>(in, out, cyc, n);
         hipDeviceSynchronize();
     }
-    unsigned long long h[8];
-    hipMemcpy(h, cyc, 48, hipMemcpyDeviceToHost);
-    for (int m = 0; m < 6; m++)
-        printf("%-40s %7.1f cycles per 16-deep chunk, %6.1f per instruction, %5.1f per k\n", names[m], (double)h[m] / n, (double)h[m] / n / per[m], (double)h[m] / n / 16);
+    unsigned long long h[16];
+    hipMemcpy(h, cyc, 72, hipMemcpyDeviceToHost);
+    for (int m = 0; m < 9; m++)
+        printf("%-62s %7.1f cycles per 16-deep chunk, %6.1f per instruction, %5.1f per k\n", names[m], (double)h[m] / n / chunks[m], (double)h[m] / n / per[m], (double)h[m] / n / 16 / chunks[m]);
     return 0;
 }

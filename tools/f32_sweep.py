@@ -1,5 +1,5 @@
 """Every tile of the exact-f32 tap-GEMM kernel (tapgemm_f32_kernel, option `f32_cfg`) forced onto every layer it is legal for, beside
-the rule-based choice, the autotuned choice and the round-1 kernels (`f32_kernel` = 0): whole-pass time by wall clock over
+the rule-based choice and the autotuned choice: whole-pass time by wall clock over
 synchronised regions, GEMM time and rate from the per-launch events (option `time_launches`).  All tiles of the new kernel must
 give the same bits (checked here on the int32 predictions and by tests/test_gpu_parity.py on the floats).
 
@@ -24,7 +24,7 @@ def step():
     rc = wl.L.pnn_predict_tbs_device(net.ctx, wl.width, wl.d_plane.data_ptr(), 4, wl.d_tbs.data_ptr(), wl.batch, wl.d_dst.data_ptr(), None, None)
     if rc: raise RuntimeError(wl.L.pnn_last_error(net.ctx))
 ref = None
-cases = [("round-1 kernels", {"f32_kernel": 0}), ("rule", {"f32_kernel": 1, "autotune": 0, "f32_cfg": -1}), ("autotuned", {"autotune": 1})]
+cases = [("rule", {"autotune": 0, "f32_cfg": -1}), ("autotuned", {"autotune": 1})]
 cases += [("f32_cfg %%d" %% i, {"autotune": 0, "f32_cfg": i}) for i in range(wl.L.pnn_num_f32_configs())]
 for label, opts in cases:
     for k, v in opts.items():

@@ -120,11 +120,16 @@ def _proc_cpu_s(pid):
         return 0.0
 
 
+ARITHMETIC = {"f32": "0", "split": "1"}               # value of PNN_PRECISION in the service processes (csrc/pnn_ctx.h: opt_precision)
+
+
 def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=32, seed=1, yardstick=True, timeout=1800, picture_set="synthetic",
-                 backend="gpu", spot_check=False, cpu_threads=None):
+                 backend="gpu", spot_check=False, cpu_threads=None, arithmetic=None):
     """backend "gpu": one batching service per device (the product).  backend "cpu": ONE service whose backend answers from the CPU
     oracle (tools/hm/cpu_pnn_service.py) -- the reference's route, PNN inference on host cores, as bench.py's cpu_baseline leg.
     picture_set "natural": windows of the natural fixtures, widths 4 / 8 on the reference's trained (convolutional) checkpoints.
+    arithmetic "f32": the services compute on the reference's IEEE-float32 arithmetic (Session::Run in float32, TComPrediction.cpp:572-579,
+    601-608), "split": on the split-f16 mode, None: the library's default (f32 since round 5).
     spot_check: before the services stop, a client asks each of them for the predictions of seeded contexts of every width; they come
     back under "_spot_check" (numpy arrays, popped by the callers that serialise the record) for the tests to hold against the oracle."""
     cfg = CONFIGS[config]
@@ -142,6 +147,8 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
     for k, dev in enumerate(devices):
         sock = os.path.join(work, "pnn%d.sock" % k)
         env = dict(os.environ, PNN_SERVICE_DEBUG="1")
+        if arithmetic is not None:
+            env["PNN_PRECISION"] = ARITHMETIC[arithmetic]
         log = open(os.path.join(work, "service%d.err" % k), "w+")      # a file, not a pipe: a chatty service must never block on a full pipe
         logs.append(log)
         if backend == "cpu":
@@ -224,6 +231,7 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
     out = {
         "config": cfg["baseline"], "variant": "hm_16_15_" + variant, "pictures": n, "picture_size": "%dx%d 4:0:0" % (w, h), "qp": qp,
         "picture_set": picture_set, "pnn_backend": backend,
+        "arithmetic": "f32 (CPU oracle)" if backend == "cpu" else (arithmetic or {"0": "f32", "1": "split"}.get(os.environ.get("PNN_PRECISION", "0"), "f32")),
         "data": ("windows of the natural fixtures (tests/golden/natural_luma.npz); widths 4 / 8 on the reference's trained convolutional checkpoints, 16 / 32 / 64 "
                  "seeded random init" if natural else "seeded synthetic pictures + seeded random-init models") + " (Kodak / BSDS and the trained production models "
                 "are not in the reference checkout)",
@@ -270,6 +278,7 @@ def main():
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--picture-set", default="synthetic", choices=["synthetic", "natural"])
     ap.add_argument("--backend", default="gpu", choices=["gpu", "cpu"])
+    ap.add_argument("--arithmetic", default=None, choices=sorted(ARITHMETIC), help="arithmetic of the GPU services (default: the library's = f32)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hm_campaign"))
     args = ap.parse_args()
     import shutil
@@ -277,7 +286,7 @@ def main():
     work = tempfile.mkdtemp(prefix="hm_campaign_")
     try:
         res = run_campaign(args.config, work, [int(d) for d in args.devices.split(",")], args.pictures or None, args.in_flight or None, args.qp,
-                           picture_set=args.picture_set, backend=args.backend)
+                           picture_set=args.picture_set, backend=args.backend, arithmetic=args.arithmetic)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(res))

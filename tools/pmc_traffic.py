@@ -5,7 +5,7 @@ units of a 128-byte-wide read path: x2; both counters are in KiB).  Writes profi
 reports as roofline.traffic.   usage: tools/pmc_traffic.py <out.json> <workload> [<workload> ...]"""
 import collections, csv, glob, json, sys
 GEMM_SPLIT = ("tapgemm_ring_kernel", "tapgemm_sp_kernel", "convimg_sp_kernel")
-GEMM_F32 = ("tapgemm_f32_kernel", "tapgemm_kernel", "tapgemm32_kernel", "tapgemm_splitk_kernel")
+GEMM_F32 = ("tapgemm_f32_kernel", "tapgemm_f32_small_kernel")
 out = {}
 for wl in sys.argv[2:]:                      # "<workload>_split" = split-f16 arithmetic, "<workload>_f32" = exact-f32 passes (tools/profile_round.sh)
     GEMM = GEMM_F32 if wl.endswith("_f32") else GEMM_SPLIT
