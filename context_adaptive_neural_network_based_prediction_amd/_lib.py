@@ -50,6 +50,8 @@ SIGNATURES = {
     "pnn_num_split_configs": (ci, []),
     "pnn_num_f32_configs": (ci, []),
     "pnn_check_range": (ci, [vp, vp, ctypes.POINTER(ctypes.c_long)]),
+    "pnn_host_alloc": (ci, [ctypes.POINTER(vp), ctypes.c_size_t]),
+    "pnn_host_free": (None, [vp]),
     "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),
     "pnn_predict_conv": (ci, [vp, ci, f32p, f32p, ci, f32p]),

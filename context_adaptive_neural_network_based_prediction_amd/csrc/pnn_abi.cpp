@@ -524,6 +524,19 @@ static uint64_t hash_bytes(const void* data, size_t bytes, uint64_t h = 0x9e3779
     return h ^ (h >> 29);
 }
 
+// No NaN / infinity among n floats: on the bit patterns (exponent all ones), so that the loop vectorises -- std::isfinite with an early
+// exit ran at 13 M floats/ms, 0.4 ms of a 0.8 ms FC-8 call of 4096 blocks (PNN_HOST_TRACE).
+static bool all_finite(const float* x, size_t n)
+{
+    uint32_t bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t u;
+        memcpy(&u, x + i, 4);
+        bad |= (uint32_t)((u & 0x7f800000u) == 0x7f800000u);
+    }
+    return bad == 0;
+}
+
 static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst,
                         int dst_stride)
 {
@@ -534,10 +547,7 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (!m->is_fc && !left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
     {   // the range guard's v_max_f32 drops NaN operands: non-finite inputs are refused here (a few hundred floats per block)
         const size_t ca = (size_t)n * (m->is_fc ? 5 : 3) * w2, cl = m->is_fc ? 0 : (size_t)n * 2 * w2;
-        bool finite = true;
-        for (size_t i = 0; i < ca && finite; i++) finite = std::isfinite(above[i]);
-        for (size_t i = 0; i < cl && finite; i++) finite = std::isfinite(left[i]);
-        if (!finite) return fail(c, PNN_E_ARG, "non-finite value in the input contexts");
+        if (!all_finite(above, ca) || !all_finite(left, cl)) return fail(c, PNN_E_ARG, "non-finite value in the input contexts");
     }
     // ---- prediction cache (single-block calls only) ----
     pnn_ctx::CacheEntry* slot = nullptr;
@@ -623,6 +633,11 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         }
         return PNN_OK;
     }
+    // One copy in, one pass, one copy out.  Streaming the batch through in chunks (staging copy, H2D, compute and D2H of successive chunks
+    // overlapped on three streams) was built in round 5 and measured SLOWER at every bench batch (FC 8x8 x 4096: 0.58 against 0.48 ms,
+    // conv 16x16 x 1024: 1.23 against 1.08): the runtime's own copy from pageable memory already runs at 25 GB/s, and a quarter or half
+    // of a bench batch does not fill the chip -- FC 8x8 at 4096 is exactly one workgroup per CU, so half of it takes as long as all of
+    // it (profiles/r05_host_rate.txt).  Pinned caller arrays (pnn_host_alloc) save another 10 %.
     HIPCHK(c, hipMemcpyAsync(c->stage_in[0].p, above, in_a, hipMemcpyHostToDevice, s));
     if (in_l) HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
     if (slot && !dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;   // a cached entry serves both result kinds
@@ -659,6 +674,19 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     HIPCHK(c, hipStreamSynchronize(s));
     if (slot) { slot->hash = hash; slot->valid = true; }
     return PNN_OK;
+}
+
+int pnn_host_alloc(void** out, size_t bytes)
+{
+    if (!out || !bytes) return PNN_E_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc(%zu) failed", bytes); }
+    return PNN_OK;
+}
+
+void pnn_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int pnn_check_range(pnn_ctx* c, void* stream, long* host_fallbacks)

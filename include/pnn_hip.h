@@ -105,8 +105,6 @@ float pnn_mean(const pnn_ctx* ctx);
  *                              bytes were predicted before (HM's RD search repeats itself); dropped on any option / model change
  *   "flag_wait"            1   a small host call ends when its LAST kernel raises a sequence number in pinned host memory (3-7 us earlier
  *                              than the runtime's completion signal); "spin_wait" (0): hipStreamQuery polling instead of hipStreamSynchronize
- *   "host_pipeline"        1   batched HOST-array calls above 64 KiB stream through a pinned ring in chunks: H2D, compute and D2H overlap;
- *                              0: one synchronous copy in, one pass, one copy out
  *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
  */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
@@ -143,6 +141,12 @@ int pnn_predict_conv(pnn_ctx* ctx, int width, const float* above, const float* l
  * `left` is ignored when it equals above + 3w^2 or is NULL (one flattened buffer, TComPattern.cpp:352-353). */
 int pnn_predict_pel(pnn_ctx* ctx, int width, const float* above, const float* left, int n, int32_t* dst,
                     int dst_stride);
+
+/* Batched calls of these entry points (more than 64 KiB of input) copy in, compute, copy out.  From PINNED caller arrays the copies
+ * run ~10 % of the call faster (no staging inside the runtime): hipHostMalloc / hipHostRegister, or these two (page-locked,
+ * device-visible; any thread may free). */
+int pnn_host_alloc(void** out, size_t bytes);
+void pnn_host_free(void* p);
 
 /* Both results of one pass: the float prediction (as pnn_predict_fc / pnn_predict_conv) into `out` [n][w][w] and the
  * HM-epilogue Pel values (as pnn_predict_pel, dense) into `dst` [n][w][w]; either may be NULL. */

@@ -427,6 +427,41 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
     net.close()
 
 
+@pytest.mark.parametrize("w,is_fc,n", [(8, True, 3001), (16, False, 333)])
+def test_pinned_caller_arrays(pnn, oracle, precision, w, is_fc, n):
+    """Batched host-array calls (the shape of Session::Run / pnn/batching.py:7-88) from PINNED caller arrays (pnn_host_alloc: the copy
+    engines reach them directly) give the bits of the same call from pageable arrays; a non-finite input is refused from either."""
+    import ctypes
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    params = util.make_params(w, is_fc, 311, out_gain=util.out_gain(w, is_fc))
+    above, left = util.make_contexts(w, n, 312)
+    ins = (util.flatten_fc(above, left),) if is_fc else (above, left)
+    net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+    want_f, want_p = net.predict(*ins), net.predict_pel(*ins)
+    handles, pinned = [], []
+    for a in ins:
+        p = ctypes.c_void_p()
+        assert L.pnn_host_alloc(ctypes.byref(p), a.nbytes) == 0
+        b = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(a.size,)).reshape(a.shape)
+        b[...] = a
+        handles.append(p); pinned.append(b)
+    po, pd = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.pnn_host_alloc(ctypes.byref(po), n * w * w * 4) == 0 and L.pnn_host_alloc(ctypes.byref(pd), n * w * w * 4) == 0
+    out = np.ctypeslib.as_array(ctypes.cast(po, ctypes.POINTER(ctypes.c_float)), shape=(n * w * w,))
+    dst = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_int32)), shape=(n * w * w,))
+    out[...] = -1; dst[...] = -1
+    call = lambda: L.pnn_predict_f32_pel(net.ctx, w, pinned[0].ctypes.data_as(_lib.f32p), None if is_fc else pinned[1].ctypes.data_as(_lib.f32p), n,
+                                         ctypes.cast(po, _lib.f32p), ctypes.cast(pd, _lib.i32p))
+    assert call() == 0, L.pnn_last_error(net.ctx)
+    assert np.array_equal(out.reshape(want_f.shape), want_f) and np.array_equal(dst.reshape(want_p.shape), want_p)
+    pinned[0].reshape(-1)[pinned[0].size // 2 + 3] = np.inf              # the vectorised finite check sees one bad value anywhere
+    assert call() == -1 and b"non-finite" in L.pnn_last_error(net.ctx)
+    net.close()
+    for h in handles + [po, pd]:
+        L.pnn_host_free(h)
+
+
 @pytest.mark.parametrize("w,is_fc", [(8, True), (16, False)])
 def test_prediction_cache_for_single_block_calls(pnn, w, is_fc):
     """`cache_mb`: a repeated single-block call (HM's RDO re-evaluates the same TB) is answered from the cache with the

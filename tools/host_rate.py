@@ -7,9 +7,20 @@ of the same batch sustains -- never the bench value, noted in DESIGN.md section 
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import numpy as np
 import bench
-from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork
+from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork, _lib
+
+
+def pinned_like(a):
+    """A copy of `a` in pinned host memory (pnn_host_alloc): what a caller that owns its buffers would hand over."""
+    L = _lib.lib()
+    p = ctypes.c_void_p()
+    assert L.pnn_host_alloc(ctypes.byref(p), a.nbytes) == 0
+    b = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(a.size,)).reshape(a.shape)
+    b[...] = a
+    return b, p
 
 
 def main():
@@ -25,17 +36,30 @@ def main():
         for prec, label in ((0, "f32"), (1, "split")):
             net = PredictionNeuralNetwork(n, w, wl.is_fc, params=wl.params, device=0)
             net.set_option("precision", prec)
-            for _ in range(5):
-                net.predict_pel(*ins)
-            reps, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 1.5:
-                net.predict_pel(*ins)
-                reps += 1
-            dt = (time.perf_counter() - t0) / reps
             in_b = sum(a.nbytes for a in ins) / n
-            print("%-7s %-5s batch %5d host arrays in, int32 block out: %.4f ms per call = %10.0f blocks/s  (%d B in + %d B out per block = %.1f GB/s over the link)"
-                  % (name, label, n, dt * 1e3, n / dt, in_b, 4 * w * w, (in_b + 4 * w * w) * n / dt / 1e9))
+            L = _lib.lib()
+            dst = np.zeros((n, w, w), np.int32)
+            pins = [pinned_like(a) for a in ins]
+            pdst, pdst_h = pinned_like(dst.view(np.float32))
+            for how in ("pageable arrays", "pinned arrays (pnn_host_alloc)"):
+                arrs = [p[0] for p in pins] if how.startswith("pinned") else ins
+                d = pdst if how.startswith("pinned") else dst
+                a0 = arrs[0].ctypes.data_as(_lib.f32p)
+                a1 = None if wl.is_fc else arrs[1].ctypes.data_as(_lib.f32p)
+                dp = ctypes.cast(d.ctypes.data, _lib.i32p)
+                call = lambda: L.pnn_predict_pel(net.ctx, w, a0, a1, n, dp, w)
+                for _ in range(5):
+                    assert call() == 0
+                reps, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 1.5:
+                    call()
+                    reps += 1
+                dt = (time.perf_counter() - t0) / reps
+                print("%-7s %-5s batch %5d %-32s %.4f ms per call = %10.0f blocks/s  (%d B in + %d B out per block = %.1f GB/s over the link)"
+                      % (name, label, n, how + ":", dt * 1e3, n / dt, in_b, 4 * w * w, (in_b + 4 * w * w) * n / dt / 1e9), flush=True)
             net.close()
+            for _, p in pins + [(None, pdst_h)]:
+                L.pnn_host_free(p)
 
 
 if __name__ == "__main__":
