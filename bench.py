@@ -140,7 +140,7 @@ def stagger(dist, fn):
         dist.barrier()
 
 
-def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sustain_s=0.0, ramp_s=RAMP_SECONDS):
+def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sustain_s=0.0, ramp_s=RAMP_SECONDS, global_batch=None):
     """Times the hot path of workload `wl` on arithmetic `precision` (1: split products on f16 MFMA, 0: exact-f32 MFMA)
     and derives the dominant kernel's roofline from HIP events attached to every tap-GEMM launch."""
     import torch
@@ -176,11 +176,14 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sus
     stats = net.last_call_stats()
     elapsed = float(np.median(regions))
     world = dist.get_world_size() if dist is not None else 1
+    # blocks the JOB processes per step: N batches of n (weak scaling) or the ONE batch the ranks share (strong: global_batch)
+    job_blocks = float(global_batch) if global_batch else float(n) * world
     res = {
-        "value": float(n) * world * steps / elapsed, "unit": "blocks/s", "ms_per_step": 1e3 * elapsed / steps,
+        "value": job_blocks * steps / elapsed, "unit": "blocks/s", "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong" if global_batch else "weak",
+        "global_batch": int(job_blocks),
         "dtype": DTYPE_LONG[precision], "precision": precision, "steps": steps, "workload": wl.name, "batch_per_gpu": n,
         "repeats": {"n": repeats, "regions_of_steps": steps, "value_is": "median region",
-                    "blocks_per_s_min": float(n) * world * steps / max(regions), "blocks_per_s_max": float(n) * world * steps / min(regions),
+                    "blocks_per_s_min": job_blocks * steps / max(regions), "blocks_per_s_max": job_blocks * steps / min(regions),
                     "ms_per_step_all": [round(1e3 * r / steps, 5) for r in regions]},
         "launches_per_step": stats["launches"],
     }
@@ -241,7 +244,11 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sus
         "gemm_launches_per_pass": nstats["gemm_launches"], "non_gemm_launches_per_pass": nstats["launches"] - nstats["gemm_launches"],
         "gemm_us_per_pass": gemm_us,
         "whole_pass": {"tflops": flops_per_block(w, wl.is_fc) * n / (1e-3 * res["ms_per_step"]) / 1e12,
-                       "frac_of_peak": flops_per_block(w, wl.is_fc) * n / (1e-3 * res["ms_per_step"]) / 1e12 / peak},
+                       "frac_of_peak": flops_per_block(w, wl.is_fc) * n / (1e-3 * res["ms_per_step"]) / 1e12 / peak,
+                       # the same step priced on the multiply-adds its tap GEMMs ISSUED: position-major tiles skip the taps that only
+                       # meet SAME padding (SURVEY 8(d) counts them), so this -- not frac_of_peak -- is matrix-pipe utilisation
+                       "issued_frac_of_peak": nstats["gemm_flops_issued"] / (1e-3 * res["ms_per_step"]) / 1e12 / peak,
+                       "issued_over_algorithmic": nstats["gemm_flops_issued"] / max(nstats["gemm_flops"], 1.0)},
         "other_gemm_kernels": [{"kernel": v["kernel"], "launches_timed": v["launches_timed"],
                                 "avg_launch_us": v["total_us"] / max(v["launches_timed"], 1),
                                 "tflops": v["flops"] / max(v["total_us"], 1e-9) / 1e6}
@@ -299,23 +306,9 @@ def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
 
 
 def cpu_budget():
-    """CPUs this process may actually keep busy: its affinity mask, cut to the cgroup's CPU quota.  The GPU boxes show 256 cores and
-    grant the job `cpu.max` = 16 CPUs: 64 threads there run in bursts (3.3 TFLOP/s of sgemm) between throttled periods (0.35), and a
-    leg's median lands in either mode (47 k or 406 k blocks/s for the same FC 8x8 batch on two boxes) -- the legs use the quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(float(q) / float(per))))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return n
+    """CPUs this process may actually keep busy (affinity cut to the cgroup quota): sharding.cpu_budget."""
+    from context_adaptive_neural_network_based_prediction_amd import sharding
+    return sharding.cpu_budget()
 
 
 def cpu_legs(workload, budget_s=1.5, full=False):
@@ -422,6 +415,16 @@ def live_traffic(workload, batch, precision, steps=3, timeout=90):
                       "mean over the pass's GEMM dispatches of 2 x FETCH_SIZE + WRITE_SIZE" % steps}
 
 
+def preflight_error_line(args, have):
+    """The ONE line of a `--gpus N` run on a node that shows fewer than N devices: same shape as a result line, value null, the reason
+    spelled out -- so a driver that parses the last JSON line of stdout records WHY there is no number instead of a traceback."""
+    return json.dumps({"metric": "pnn_intra_pred_blocks_per_s", "value": None, "unit": "blocks/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                       "config": {"workload": WORKLOADS[args.workload][3] if args.workload in WORKLOADS else args.workload},
+                       "error": "--gpus %d: this node exposes %d HIP device(s) (torch.cuda.device_count()); nothing was launched" % (args.gpus, have),
+                       "devices_visible": have}, separators=(",", ":"))
+
+
 def self_launch(args):
     """`python bench.py --gpus N` run plainly: this process stays off the GPU and starts the N ranks as a CHILD
     (`python -m torch.distributed.run`, one process per GPU, rendezvous on 127.0.0.1), relays rank 0's JSON line and
@@ -432,7 +435,9 @@ def self_launch(args):
     if os.environ.get("PNN_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()             # counting devices does not initialise HIP on this image
         if have < args.gpus:
-            raise SystemExit("--gpus %d: this node exposes %d GPU(s)" % (args.gpus, have))
+            print(preflight_error_line(args, have))
+            sys.stdout.flush()
+            raise SystemExit(1)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -503,6 +508,8 @@ def natural_pred_psnr(device):
     from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork, weights as wts
     from oracle import pnn_oracle as O
     from tests import test_natural as tn, util
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "natural_luma.npz")):     # generated by __graft_entry__.build() where the reference checkout exists
+        return None
     out = {}
     for w in (4, 8):
         flat, _, _ = wts.load_pnnw(os.path.join(ROOT, "tests", "golden", "conv%d_single.pnnw" % w))
@@ -533,7 +540,8 @@ def compact(res):
     """One measurement as the line carries it."""
     rf = res["roofline"]
     return {"value": _r(res["value"], 5), "ms_per_step": _r(res["ms_per_step"], 5), "frac": _r(rf["frac"], 3),
-            "pass_frac": _r(rf["whole_pass"]["frac_of_peak"], 3), "launches": res["launches_per_step"], "lsb": res.get("max_abs_lsb_vs_oracle")}
+            "pass_frac": _r(rf["whole_pass"]["frac_of_peak"], 3), "issued_frac": _r(rf["whole_pass"].get("issued_frac_of_peak"), 3),
+            "launches": res["launches_per_step"], "lsb": res.get("max_abs_lsb_vs_oracle")}
 
 
 def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=None, cpu=None, cpu_conv16=None, detail_file=None, extra_config=None,
@@ -542,9 +550,9 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
     rf = main_res["roofline"]
     out = {
         "metric": "pnn_intra_pred_blocks_per_s", "value": _r(main_res["value"], 6), "unit": "blocks/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": _r(main_res["ms_per_step"], 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": _r(main_res["ms_per_step"], 6), "higher_is_better": True, "scaling": main_res.get("scaling", "weak"), "vs_baseline": None,
         "dtype": DTYPE[main_res["precision"]], "data": "synthetic",
-        "config": {"workload": cfg_name, "batch_per_gpu": main_res["batch_per_gpu"], "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
+        "config": {"workload": cfg_name, "batch_per_gpu": main_res["batch_per_gpu"], "global_batch": main_res.get("global_batch"), "path": "gather + net + HM epilogue (pnn_predict_tbs_device)",
                    "weights": "seeded random init (reference initialisers' statistics)", "parallelism": "independent blocks sharded over ranks, no collective",
                    "timing": "%d regions of K steps, median" % main_res["repeats"]["n"]},
         "max_abs_lsb_vs_oracle": main_res.get("max_abs_lsb_vs_oracle"),
@@ -578,7 +586,7 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
                 row[arith] = compact(r)
             tab[str(w)] = row
         out["per_width"] = tab
-        out["per_width_note"] = "f32 frac vs 157.3, split frac vs 2500/3 TFLOP/s; frac = dominant GEMM kernel, pass_frac = whole step; conv FLOPs count padding taps"
+        out["per_width_note"] = "f32 frac vs 157.3, split vs 2500/3 TFLOP/s; frac = dominant GEMM kernel, pass_frac = whole step on algorithmic FLOPs (padding taps counted), issued_frac = on the multiply-adds issued (matrix-pipe utilisation)"
     if natural:
         out["natural_pred_psnr_db"] = {w: {"gpu_f32": _r(v.get("f32_db"), 5), "gpu_split": _r(v.get("split_db"), 5), "oracle": _r(v.get("oracle_db"), 5)} for w, v in natural.items()}
     if rccl_ranks_seen is not None:
@@ -601,6 +609,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fc8", choices=sorted(WORKLOADS) + ["hm_kodak", "hm_bsds"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--gpus N > 1: weak = every rank its own batch of the workload's size (the contract's default); strong = ONE batch of that "
+                         "size split over the ranks (sharding.shard_bounds), at least 200 steps per region")
     ap.add_argument("--arithmetic", default=None, choices=sorted(ARITH), help="top-level arithmetic (default f32 = the reference's; env PNN_PRECISION=1 -> split)")
     ap.add_argument("--hm-quick", action="store_true", help=argparse.SUPPRESS)   # 4 pictures per campaign (plumbing tests)
     ap.add_argument("--hm-pictures", default="synthetic", choices=["synthetic", "natural"], help="hm_* workloads: picture set")
@@ -681,10 +692,21 @@ def main():
         ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": ndev}
 
     t_start = time.perf_counter()
-    wl = Workload(args.workload, args.batch, rank, local_rank)
+    strong = args.scaling == "strong" and world > 1
+    global_batch = args.batch or WORKLOADS[args.workload][2]
+    if strong:
+        # ONE batch split over the ranks: rank r takes the contiguous shard shard_bounds(global_batch, r, world); a step of the job is
+        # still one pass over the whole batch, so `value` = global_batch * steps / (slowest rank's time).  Shards of a bench batch are
+        # short (FC 8x8: 512 blocks at N = 8, ~60 us of device time), so regions are at least 200 steps
+        _, mine = sharding.strong_shard(global_batch, rank, world)
+        args.steps = max(args.steps, 200)
+        wl = Workload(args.workload, mine, rank, local_rank)
+    else:
+        wl = Workload(args.workload, args.batch, rank, local_rank)
     single = world == 1
     sustain = SUSTAIN_SECONDS if args.sustained else 0.0
-    main_res = measure(wl, precision, args.steps, args.warmup, dist, check=(rank == 0 and single), sustain_s=sustain)
+    main_res = measure(wl, precision, args.steps, args.warmup, dist, check=(rank == 0 and single), sustain_s=sustain,
+                       global_batch=global_batch if strong else None)
     detail = {"cmd": " ".join(sys.argv), "n_gpus": world, "main": main_res,
               "config": {"rank_placement": ("rank 0 bound to cpus %s (its GPU's NUMA node)" % bound) if bound else "no NUMA binding (one node / not exposed)",
                          "tile_autotune": "split kernels: on first use, before the warm-up steps; f32 kernels: rule-based",

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pnn_num_split_configs": (ci, []),
     "pnn_num_f32_configs": (ci, []),
     "pnn_check_range": (ci, [vp, vp, ctypes.POINTER(ctypes.c_long)]),
+    "pnn_last_call_issued_flops": (ci, [vp, ctypes.POINTER(ctypes.c_double)]),
+    "pnn_arithmetic_tag": (ci, [vp, ctypes.c_char_p, ctypes.c_size_t]),
     "pnn_host_alloc": (ci, [ctypes.POINTER(vp), ctypes.c_size_t]),
     "pnn_host_free": (None, [vp]),
     "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),

@@ -18,9 +18,26 @@
 
 using namespace pnn;
 
-namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
+namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; thread_local double g_last_issued_frac = 1.0; }
 namespace { thread_local std::string g_create_error; }
 namespace pnn {
+
+const DeviceInfo& device_info()
+{
+    static DeviceInfo cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { static const DeviceInfo fallback; return fallback; }
+    DeviceInfo& d = cache[dev];
+    if (d.dev != dev) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+            if (pr.multiProcessorCount > 0) d.cus = pr.multiProcessorCount;
+            if (pr.maxSharedMemoryPerMultiProcessor > 0) d.lds = (size_t)pr.maxSharedMemoryPerMultiProcessor;
+        }
+        d.dev = dev;
+    }
+    return d;
+}
 
 void set_create_error(const std::string& msg) { g_create_error = msg; }
 
@@ -78,7 +95,7 @@ Model* model_for(pnn_ctx* c, int width, int want_fc /* -1 any */, int* rc)
     return m;
 }
 
-void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; c->stat_gemm_flops = 0; }
+void reset_stats(pnn_ctx* c) { c->stat_gemm_launches = 0; c->stat_launches = 0; c->stat_gemm_flops = 0; c->stat_gemm_flops_skipped = 0; }
 
 // Device (asynchronous) entry points cannot wait for their own pass; a pass that left the f16 range is reported by the
 // next call on the context (and by pnn_check_range, which waits for the stream).
@@ -106,9 +123,36 @@ int wait_stream(pnn_ctx* c, hipStream_t s)
 
 // The last kernel of the pass took a completion signal (take_done_signal): spin on the flag word it raises in pinned host
 // memory behind its results.  Bounded: a launch that failed never raises it, the stream then says why.
-int wait_done_flag(pnn_ctx* c, hipStream_t s)
+int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1)
 {
     const unsigned* flag = reinterpret_cast<const unsigned*>(c->h_range) + 1;
+    if (c->opt_wait_sleep) {
+        // sleep through the predictable part of the wait (see pnn_ctx::opt_wait_sleep), spin for the rest
+        constexpr double kMarginUs = 14.0, kMinSleepUs = 12.0;
+        int b = 0;
+        while ((2L << b) <= n && b < 11) b++;
+        double& ema = c->wait_ema_us[b];
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        const double nap = ema - kMarginUs;
+        bool overslept = false;
+        if (nap >= kMinSleepUs) {
+            timespec ts{0, (long)(nap * 1e3)};
+            nanosleep(&ts, nullptr);
+            overslept = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->done_seq;
+        }
+        for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; spins++) {
+            if (spins < 400000) { __builtin_ia32_pause(); continue; }
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
+            break;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        // the flag already stood when the nap ended: the true wait is unknown but shorter -- back off instead of learning the nap's length
+        ema = overslept ? ema * 0.85 : (ema == 0.0 ? us : 0.9 * ema + 0.1 * us);
+        return PNN_OK;
+    }
     for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; spins++) {
         if (spins < 200000) { __builtin_ia32_pause(); continue; }   // ~ a few milliseconds
         HIPCHK(c, hipStreamSynchronize(s));
@@ -195,6 +239,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_FC_OUT")) c->opt_fc_out = atol(e);
     if (const char* e = getenv("PNN_SPIN_WAIT")) c->opt_spin_wait = atol(e);
     if (const char* e = getenv("PNN_FLAG_WAIT")) c->opt_flag_wait = atol(e);
+    if (const char* e = getenv("PNN_WAIT_SLEEP")) c->opt_wait_sleep = atol(e);
     if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
@@ -319,6 +364,18 @@ int pnn_model_info(const pnn_ctx* c, int width, int* is_fc, int* n_layers, long*
     return PNN_OK;
 }
 
+int pnn_arithmetic_tag(const pnn_ctx* c, char* out, size_t bytes)
+{
+    if (!c || !out || bytes == 0) return PNN_E_ARG;
+    // everything that decides the last float bits of a prediction: the arithmetic, its per-output summation order, the library's
+    // order revision (bumped whenever a kernel change moves a bit)
+    if (c->opt_precision == 0)
+        snprintf(out, bytes, "pnn-order-5:f32:fmaf-chain k=0,8,1,9..7,15 per 16:kseg %d/%d:fc-out-seg 160", kSegDepth, kSegMinDepth);
+    else
+        snprintf(out, bytes, "pnn-order-5:split-f16x3:hi*hi,hi*lo,lo*hi per 16:fc-out-seg %d", 16 * kFuseSegChunks);
+    return PNN_OK;
+}
+
 int pnn_num_split_configs(void) { return tapgemm_sp_num_cfgs() + convimg_sp_num_cfgs() + tapgemm_ring_num_cfgs(); }
 int pnn_num_f32_configs(void) { return tapgemm_f32_num_cfgs(); }
 
@@ -340,6 +397,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "fc_out")) c->opt_fc_out = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "flag_wait")) c->opt_flag_wait = value;
+    else if (!strcmp(name, "wait_sleep")) c->opt_wait_sleep = value;
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "f32_seg_mode")) { c->opt_f32_seg_mode = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "f32_persist")) { c->opt_f32_persist = value; c->tuned.clear(); c->tune_gen++; }
@@ -367,6 +425,13 @@ int pnn_last_call_stats(const pnn_ctx* c, int* n_gemm, double* flops, int* n_lau
     if (n_gemm) *n_gemm = c->stat_gemm_launches;
     if (flops) *flops = c->stat_gemm_flops;
     if (n_launches) *n_launches = c->stat_launches;
+    return PNN_OK;
+}
+
+int pnn_last_call_issued_flops(const pnn_ctx* c, double* flops)
+{
+    if (!c || !flops) return PNN_E_ARG;
+    *flops = c->stat_gemm_flops - c->stat_gemm_flops_skipped;
     return PNN_OK;
 }
 
@@ -609,7 +674,7 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         c->done_want = false;
         if (rc) return rc;
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht1);
-        if ((rc = c->done_armed ? wait_done_flag(c, s) : wait_stream(c, s))) return rc;
+        if ((rc = c->done_armed ? wait_done_flag(c, s, n) : wait_stream(c, s))) return rc;
         if (host_trace) {
             clock_gettime(CLOCK_MONOTONIC, &ht2);
             static double s_launch = 0, s_wait = 0; static long s_n = 0;

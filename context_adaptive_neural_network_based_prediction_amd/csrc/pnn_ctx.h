@@ -159,11 +159,18 @@ struct pnn_ctx {
     unsigned done_seq = 0;
     bool done_want = false, done_last_chunk = true, done_armed = false;
     long opt_flag_wait = 1;
+    // The host thread of a small call spins on the completion flag for as long as the device works: 45-400 us of a CPU per call, and the
+    // batching service runs five such threads (19 of its 31 CPU-seconds per Kodak-size campaign, round 4).  wait_sleep = 1: the thread
+    // SLEEPS for the part of the wait it can predict -- a running mean of this context's waits per batch-size bucket, minus a margin --
+    // and spins only for the rest.  Off by default (a stand-alone codec has nothing else to do with its core); the service turns it on.
+    long opt_wait_sleep = 0;
+    double wait_ema_us[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // by floor(log2(blocks))
     long opt_ring_pm = 1;                             // ring kernel: position-major tiles that skip the taps in the padding (pnn_gemm_ring.hip)
     size_t ws_cap_bytes = (size_t)8 << 30;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
     double stat_gemm_flops = 0;
+    double stat_gemm_flops_skipped = 0;               // ... of which position-major tiles skipped (taps that only meet SAME padding)
 };
 
 namespace pnn {

@@ -729,6 +729,7 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     const TileCfg t{RT, NT, KC, 32};
     TapGemmParams p = p0;
     p.pm_groups = 0;
+    g_last_issued_frac = 1.0;
     // (not with a last block group that is mostly padding rows: 64 blocks of the 64x64 net in 128-row tiles ran 3 % slower)
     const long nblk = p0.M / (p0.SH * p0.SW), bm = 128 * RT;
     if (!fuse && p0.pm_groups >= 0 && p0.SH * p0.SW > 1 && (p0.pm_groups == 1 || (nblk + bm - 1) / bm * bm * 100 <= nblk * 115)) {
@@ -740,6 +741,7 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
         // conv 32x32 at batch 256: 1.089 / 1.077-1.083 / 1.128-1.130 ms
         static const double l2_mb = getenv("PNN_F32_PM_L2_MB") ? atof(getenv("PNN_F32_PM_L2_MB")) : 7.0;
         const PmPlan& plan = position_major_plan(q, 128 * RT, 32 * NT, KC, tapgemm_f32_lds_bytes(t, false, false), l2_mb);
+        g_last_issued_frac = plan.use ? plan.live_frac : 1.0;
         if (plan.use) {
             p.pm_groups = plan.groups;
             p.nblk = p0.M / (p0.SH * p0.SW);
@@ -762,17 +764,31 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     // (0.787: nothing hides a tile's start-up and epilogue), three change nothing; at six tiles per CU both launches are equal (conv
     // 16x16 at batch 2048, conv 32x32 at 512), with more the hardware's own turnover does better (conv 16x16 at batch 4096: 2.74 -> 2.83
     // ms with two persistent workgroups), and up to two per CU there is nothing to gain.
-    const int W = p0.persist >= 0 ? p0.persist : (ntiles > 512 && ntiles <= 1536 ? 2 : 0);
+    const DeviceInfo& di = device_info();
+    int idx_self = 0;
+    for (int i = 0; i < tapgemm_f32_num_cfgs(); i++) if (kCfgsF32[i].rt == RT && kCfgsF32[i].nt == NT && kCfgsF32[i].kc == KC) idx_self = i;
+    const int by_regs = std::max(1, 512 / kRegsF32[idx_self]);       // workgroups (one wave per SIMD each) the register file keeps resident
+    int W = p0.persist >= 0 ? p0.persist : (ntiles > 2L * di.cus && ntiles <= 6L * di.cus ? 2 : 0);
+    W = std::min(W, by_regs);                         // never more persistent workgroups than are resident: the rest would run as a second round
     size_t lds = tapgemm_f32_lds_bytes(t, fuse, p0.SH * p0.SW == 1);
     dim3 g1((unsigned)ntiles);
-    if (W > 0 && ntiles > 256L * W && lds * (size_t)W <= (size_t)160 * 1024) {   // (a tile whose ring leaves no room for W workgroups per CU: plain launch)
-        g1.x = 256u * (unsigned)W;
-        lds = std::max(lds, (size_t)(160 * 1024 / (W + 1) + 1024) / 16 * 16);
+    if (W > 0 && ntiles > (long)di.cus * W && lds * (size_t)W <= di.lds) {   // (a tile whose ring leaves no room for W workgroups per CU: plain launch)
+        g1.x = (unsigned)di.cus * (unsigned)W;
+        lds = std::max(lds, (size_t)(di.lds / (W + 1) + 1024) / 16 * 16);
     }
+    // the LDS attribute belongs to (function, device): set once per device, and a failure is the launch's error, not an opaque launch failure later
+    auto set_attr = [&](const void* fn, int (&done)[16]) -> hipError_t {
+        const int dev = di.dev >= 0 && di.dev < 16 ? di.dev : 0;
+        if (done[dev]) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)di.lds);
+        if (e == hipSuccess) done[dev] = 1;
+        return e;
+    };
     if constexpr (RT == 1 && NT == 5) {
         if (fuse) {
-            static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)attr;
+            static int done[16] = {};
+            const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, done);
+            if (e != hipSuccess) return e;
             pnn_launch(tapgemm_f32_kernel<RT, NT, KC, true>, g1, dim3(256), lds, s, p);
             return hipGetLastError();
         }
@@ -780,13 +796,15 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     if (fuse) return hipErrorInvalidValue;
     if (seq) {
         if ((p0.Cin / 16) % KC) return hipErrorInvalidValue;      // whole stages per tap
-        static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)attr;
+        static int done[16] = {};
+        const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, true>, done);
+        if (e != hipSuccess) return e;
         pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, true>, g1, dim3(256), lds, s, p);
         return hipGetLastError();
     }
-    static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_f32_kernel<RT, NT, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr;
+    static int done[16] = {};
+    const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false>, done);
+    if (e != hipSuccess) return e;
     pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false>, g1, dim3(256), lds, s, p);
     return hipGetLastError();
 }

@@ -841,6 +841,15 @@ PmPlan plan_position_major(const TapGemmParams& p, int BM, int BN, int KC, size_
         inside += total[pos];
     }
     if (inside >= (long)SP * ntaps) return plan;                     // nothing to skip
+    {
+        long live = 0;                               // (cnt / total hold 1 for a class without a live tap: it fetches zeros once)
+        for (int pos = 0; pos < SP; pos++)
+            for (int t = 0; t < ntaps; t++) {
+                const int iy = (pos / p.SW) * p.a + (p.tap[t] >> 16), ix = (pos % p.SW) * p.a + (int)(short)(p.tap[t] & 0xffff);
+                live += iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            }
+        plan.live_frac = (double)live / ((double)SP * ntaps);
+    }
     std::vector<int> order(SP);
     for (int i = 0; i < SP; i++) order[i] = i;
     if (SP <= 64) {                                  // heaviest positions first: the light ones fill the tail of the launch
@@ -897,9 +906,11 @@ static hipError_t launch_ring(const TapGemmParams& p, hipStream_t s)
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ncls);
     TapGemmParams q = p;
     q.pm_groups = 0;
+    g_last_issued_frac = 1.0;
     if (!FUSE && p.pm_groups >= 0 && p.SH * p.SW > 1) {
         static const double l2_mb = getenv("PNN_RING_PM_L2_MB") ? atof(getenv("PNN_RING_PM_L2_MB")) : 4.5;   // (round 4 re-check at 7 MB, which the f32 kernel takes: see NOTES.md)
         const PmPlan& plan = position_major_plan(p, BM, BN, KC, lds, l2_mb);
+        g_last_issued_frac = plan.use ? plan.live_frac : 1.0;
         if (plan.use) {
             q.pm_groups = plan.groups;
             q.nblk = p.M / (p.SH * p.SW);

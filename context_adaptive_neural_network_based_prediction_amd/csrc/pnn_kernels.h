@@ -21,6 +21,11 @@ inline void pnn_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
     else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
 }
 
+// What the launch rules need to know about the CURRENT device (hipGetDevice), read once per device from hipDeviceProp: compute units
+// and LDS bytes per CU (MI355X: 256 and 160 KiB; a partitioned GPU -- CPX / DPX -- or another SKU shows other numbers).
+struct DeviceInfo { int cus = 256; size_t lds = (size_t)160 << 10; int dev = -1; };
+const DeviceInfo& device_info();
+
 constexpr int kMaxTaps = 32;
 constexpr int kMaxClasses = 4;
 
@@ -125,7 +130,10 @@ hipError_t launch_tapgemm_ring(const TapGemmParams& p, int idx, hipStream_t s); 
 // skipped): whether a launch of tile BM x BN, KC chunks per stage, `lds` bytes per workgroup takes them, in how many block
 // groups, and the position order (pnn_gemm_ring.hip; shared by the ring kernel and tapgemm_f32_kernel).  p.pm_groups on entry:
 // -1 never, 1 whenever possible, 0 by the planner's list-scheduling model.
-struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; };
+struct PmPlan { bool use = false; int groups = 0; unsigned order[16] = {}; double live_frac = 1.0; };   // live_frac: in-image taps / all taps, over the positions
+// Fraction of a tap GEMM's algorithmic multiply-adds that the LAST launch of this thread issued: 1 for block-major tiles, the plan's
+// live_frac for position-major ones (the skipped taps only meet SAME padding) -- bench.py's executed-MFMA fractions
+extern thread_local double g_last_issued_frac;
 const PmPlan& position_major_plan(const TapGemmParams& p, int BM, int BN, int KC, size_t lds, double l2_mb = 4.5);
 int convimg_sp_num_cfgs();
 TileCfg convimg_sp_cfg(int idx);

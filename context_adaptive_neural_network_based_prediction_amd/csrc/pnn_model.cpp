@@ -148,8 +148,14 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
     // as ONE chain left a quarter of the chip idle at batch 64 and took 171 us at batch 1), whole taps, never more segments than
     // the shallowest class has taps.  One-tap layers (FC) are never segmented.
     {
+        // The segment layout DEFINES the exact-f32 summation order -- the bits an encoder and its decoder must share -- so in the shipped
+        // library it is the pair of constants (reported by pnn_arithmetic_tag); only the diagnostic build (make diag) reads the A/B variables.
+#ifdef PNN_F32_DIAG
         static const int seg_depth = getenv("PNN_F32_SEG_DEPTH") ? atoi(getenv("PNN_F32_SEG_DEPTH")) : kSegDepth;
         static const int seg_min = getenv("PNN_F32_SEG_MIN") ? atoi(getenv("PNN_F32_SEG_MIN")) : kSegMinDepth;
+#else
+        constexpr int seg_depth = kSegDepth, seg_min = kSegMinDepth;
+#endif
         int tmax = 0, tmin = 1 << 30;
         for (int cls = 0; cls < p.ncls; cls++) {
             const int t = p.tap_begin[cls + 1] - p.tap_begin[cls];

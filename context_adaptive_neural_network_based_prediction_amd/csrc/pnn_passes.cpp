@@ -220,6 +220,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     }
     c->stat_gemm_launches++; c->stat_launches++;
     c->stat_gemm_flops += flops;
+    c->stat_gemm_flops_skipped += flops * (1.0 - g_last_issued_frac);
     return PNN_OK;
 }
 
@@ -463,6 +464,7 @@ int run_gemm_sp(pnn_ctx* c, const GemmLayer& L, const void* Xhi, const void* Xlo
     c->stat_gemm_launches++; c->stat_launches++;
     if (lastp && !fused_last) c->stat_launches++;    // the net's last layer went out as a launch of its own
     c->stat_gemm_flops += 2.0 * (double)M * L.k_total * p.Cout;
+    if (cfg >= nsp + nci) c->stat_gemm_flops_skipped += 2.0 * (double)M * L.k_total * p.Cout * (1.0 - g_last_issued_frac);   // (ring launches may skip padding taps)
     if (next) {
         c->stat_gemm_flops += 2.0 * (double)M * next->k_total * next->proto.Cout;
         if (tiles_out) *tiles_out = (int)((p.Cout + 32L * t.nt * (4 / t.wm) - 1) / (32L * t.nt * (4 / t.wm)));

@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <poll.h>
 #include <sys/epoll.h>
+#include <sys/prctl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -189,10 +190,13 @@ struct Server {
     long calls_w[5] = {0, 0, 0, 0, 0}, served_w[5] = {0, 0, 0, 0, 0};   // backend calls / requests per worker
 
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
+    static int kServiceWidthsOf(int k) { return 4 << k; }
     int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
 
     void worker(int k, int r)
     {
+        { char nm[16]; snprintf(nm, sizeof nm, "pnn-w%d", nworkers == 1 ? 0 : kServiceWidthsOf(k)); prctl(PR_SET_NAME, nm, 0, 0, 0); }   // (per-thread CPU accounting: campaign.py reads /proc/<pid>/task/*/stat)
+        prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // the contexts' "wait_sleep" naps are tens of microseconds: not with the default 50 us of slack
         std::vector<Req> batch;
         std::vector<float> above, left, out;
         std::vector<int32_t> dst;
@@ -292,6 +296,7 @@ struct Server {
     // bounded the server; event data = client ID (0: listener, 1: this thread's wake pipe).
     void io_loop(const int t, const int lfd, const int ep)
     {
+        if (t > 0) { char nm[16]; snprintf(nm, sizeof nm, "pnn-io%d", t); prctl(PR_SET_NAME, nm, 0, 0, 0); }
         std::map<uint64_t, Client> clients;          // by client ID
         auto ep_ctl = [&](int op, int fd, uint32_t events, uint64_t id) {
             epoll_event ev;
@@ -610,6 +615,7 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
         for (int r = 0; r < nrep && rc == PNN_OK; r++) {
             rc = pnn_create_empty(&ctxs[k][r], mean, device);
             if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
+            if (rc == PNN_OK && !getenv("PNN_WAIT_SLEEP")) pnn_set_option(ctxs[k][r], "wait_sleep", 1);   // five workers that spin would hold five CPUs for the length of a campaign
             // the file must hold a model of the width its table row names (pnn_create's check)
             if (rc == PNN_OK && pnn_model_info(ctxs[k][r], kWidths[k], nullptr, nullptr, nullptr) != PNN_OK) rc = PNN_E_MODEL;
         }

@@ -31,6 +31,8 @@ int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double
     }
     int best = -1;
     double best_cost = 1e300;
+    const DeviceInfo& di = device_info();
+    const double ncu = (double)di.cus, lds_cu = (double)di.lds;
     for (int i = 0; i < tapgemm_f32_num_cfgs(); i++) {
         const TileCfg t = tapgemm_f32_cfg(i);
         if (fused && !tapgemm_f32_can_fuse(i)) continue;
@@ -38,18 +40,18 @@ int choose_cfg_f32(const pnn_ctx* c, long M, int cout, int ncls, int cin, double
         const long bm = 128L * t.rt, bn = 32L * t.nt;
         const double wgs = (double)((M + bm - 1) / bm) * (double)((cout + bn - 1) / bn) * ncls;
         const double regs = tapgemm_f32_regs(i);
-        const int res = (int)std::max(1.0, std::min(std::min(4.0, std::floor(512.0 / regs)), std::floor(160.0 * 1024 / (double)tapgemm_f32_lds_bytes(t, fused))));
+        const int res = (int)std::max(1.0, std::min(std::min(4.0, std::floor(512.0 / regs)), std::floor(lds_cu / (double)tapgemm_f32_lds_bytes(t, fused))));
         const double chunks = std::ceil(k_total / 16.0 / ncls / t.kc) * t.kc;
         const double mfma = chunks * 8.0 * t.rt * t.nt * 64.0;
         const double fixed = 5000.0 + 2500.0 * t.rt * t.nt;
-        const bool exact = std::fmod(wgs, 256.0) == 0.0 && wgs / 256.0 <= res;
+        const bool exact = std::fmod(wgs, ncu) == 0.0 && wgs / ncu <= res;
         // start-up and epilogue hide behind OTHER workgroups' loops only when a CU's slots turn over (>= 2 rounds); workgroups that are all
         // resident from the start go through them together, and the more of them share a CU the longer those phases last (FC 8x8 first
         // layer, K = 320, 32-column tiles: 4.75 workgroups per CU, 14 k + 10 k cycles of prologue + epilogue around 10 k of MFMAs)
-        const double per_cu = wgs / 256.0, rounds = per_cu / res;
+        const double per_cu = wgs / ncu, rounds = per_cu / res;
         const double fixed_eff = rounds >= 2.0 ? 0.4 * fixed : fixed * std::max(1.0, std::min((double)res, per_cu));
-        double cost = wgs * mfma / 256.0 + (exact ? 0.0 : 0.6 * mfma) + fixed_eff;
-        if (wgs < 256.0) cost = mfma + fixed;                         // under-filled chip: the launch lasts one workgroup
+        double cost = wgs * mfma / ncu + (exact ? 0.0 : 0.6 * mfma) + fixed_eff;
+        if (wgs < ncu) cost = mfma + fixed;                         // under-filled chip: the launch lasts one workgroup
         if (t.rt == 2) cost *= 1.2;
         cost *= 1.0 + 0.01 / (t.rt * t.nt) + (t.kc == 2 ? 0.005 : 0.0);   // ties: the bigger wave tile, the longer stage
         if (cost < best_cost) { best_cost = cost; best = i; }

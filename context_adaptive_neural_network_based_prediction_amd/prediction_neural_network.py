@@ -146,10 +146,20 @@ class PredictionNeuralNetwork(object):
                                            dst.ctypes.data_as(_lib.i32p), w), self._ctx)
         return dst
 
+    def arithmetic_tag(self):
+        """What decides the last float bits of this network's predictions (pnn_arithmetic_tag): equal tags <=> identical predictions --
+        what an encoder and its decoder compare once at start-up."""
+        buf = ctypes.create_string_buffer(160)
+        if self._L.pnn_arithmetic_tag(self._ctx, buf, len(buf)) != 0:
+            raise _lib.PnnError("pnn_arithmetic_tag failed")
+        return buf.value.decode()
+
     def last_call_stats(self):
         ng, fl, nl = ctypes.c_int(), ctypes.c_double(), ctypes.c_int()
         self._L.pnn_last_call_stats(self._ctx, ctypes.byref(ng), ctypes.byref(fl), ctypes.byref(nl))
-        return {"gemm_launches": ng.value, "gemm_flops": fl.value, "launches": nl.value}
+        issued = ctypes.c_double()
+        self._L.pnn_last_call_issued_flops(self._ctx, ctypes.byref(issued))
+        return {"gemm_launches": ng.value, "gemm_flops": fl.value, "gemm_flops_issued": issued.value, "launches": nl.value}
 
     def cache_stats(self):
         """(hits, misses) of the single-block prediction cache (option "cache_mb")."""

@@ -112,7 +112,26 @@ class Client:
             self._c = ctypes.c_void_p()
 
 
+def die_with_parent():
+    """SIGTERM for this process when the one that started it dies (PR_SET_PDEATHSIG), so a campaign killed from outside -- a `timeout`
+    around bench.py sends SIGTERM, which skips `finally` -- leaves no service alive on the GPU.  Called first thing in main(), from
+    the service itself rather than from a preexec_fn of its parent; PNN_SERVICE_PARENT = the starter's pid closes the window in which
+    the parent died before the call."""
+    import os
+    import signal
+    parent = os.environ.get("PNN_SERVICE_PARENT")
+    if not parent:
+        return
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)      # PR_SET_PDEATHSIG
+    except OSError:
+        return
+    if os.getppid() != int(parent):
+        raise SystemExit("pnn service: the process that started it (%s) is gone" % parent)
+
+
 def main():
+    die_with_parent()
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--socket", required=True)
     ap.add_argument("--table", required=True, help="model table (width,is_pair,channel,path per line)")

@@ -89,6 +89,45 @@ def gather_predictions(local, n_total, dist=None):
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
 
 
+def cpu_budget(cgroup_root="/sys/fs/cgroup"):
+    """CPUs this process may actually keep busy: its affinity mask, cut to the cgroup's CPU quota.  The GPU boxes show 256 cores and
+    grant the job `cpu.max` = 16 CPUs: 64 threads there run in bursts between throttled periods -- CPU legs, encoder pools and
+    services size themselves by THIS, never by os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            per = int(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def encodes_in_flight(n_encodes, n_services, budget=None):
+    """How many codec processes a campaign keeps in flight.  An encoder behind the batching service is LATENCY-bound, not CPU-bound: it
+    spends four fifths of its wall clock blocked on the socket (configs[3]: 24 encoders use 24 CPU-seconds over a 5.3 s wall), and the
+    service batches better the more of them wait at once -- 14 in flight instead of 24 doubled the campaign's wall (10.4 against 5.3 s,
+    round 5).  So the pool oversubscribes the CPUs the job may really use (the cgroup quota, not the cores the box shows) eight times,
+    after one CPU per service for its I/O and launch threads; at least one encode per service, never more than there are."""
+    b = cpu_budget() if budget is None else int(budget)
+    return int(max(n_services, min(int(n_encodes), 8 * max(1, b - int(n_services)))))
+
+
+def strong_shard(global_batch, rank, world_size):
+    """Blocks of `rank` when ONE batch of `global_batch` blocks is split over the ranks (bench.py --scaling strong): shard_bounds,
+    returned as (begin, count); every rank must get at least one block."""
+    b, e = shard_bounds(global_batch, rank, world_size)
+    if e <= b:
+        raise ValueError("a batch of %d blocks cannot be split over %d ranks" % (global_batch, world_size))
+    return b, e - b
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Host-side placement of a rank next to its GPU, read from sysfs only (nothing here initialises HIP: it runs BEFORE the
 # first HIP call of a rank, and in the self-launching parent of bench.py, which must never touch the GPU).

@@ -105,6 +105,9 @@ float pnn_mean(const pnn_ctx* ctx);
  *                              bytes were predicted before (HM's RD search repeats itself); dropped on any option / model change
  *   "flag_wait"            1   a small host call ends when its LAST kernel raises a sequence number in pinned host memory (3-7 us earlier
  *                              than the runtime's completion signal); "spin_wait" (0): hipStreamQuery polling instead of hipStreamSynchronize
+ *   "wait_sleep"           0   1: the thread of a small host call sleeps through the predictable part of its wait (running mean per batch
+ *                              size, minus a margin) and spins only for the rest: the batching service's workers set it (two thirds of
+ *                              their CPU time was that spin); a stand-alone codec keeps 0
  *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
  */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
@@ -122,6 +125,12 @@ int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
  * asynchronous: the NEXT call on the context fails with PNN_E_RANGE, and pnn_check_range -- which waits for `stream` -- tells right
  * away (*host_fallbacks, optional = how many host calls took the exact-f32 repeat so far).  "precision" 0 has no such bound. */
 int pnn_check_range(pnn_ctx* ctx, void* stream, long* host_fallbacks);
+
+/* A short string naming everything that decides the last float bits of this context's predictions -- the arithmetic ("precision"), its
+ * per-output summation order and the K-segment layout of the deep exact-f32 layers, the library's order revision.  An encoder and its
+ * decoder (or an encoder and the batching service it talks to) produce identical predictions iff their tags are equal: compare them
+ * once at start-up. */
+int pnn_arithmetic_tag(const pnn_ctx* ctx, char* out, size_t bytes);
 
 /* Number of configuration codes "sp_cfg" accepts (tile shapes of tapgemm_sp_kernel, convimg_sp_kernel, tapgemm_ring_kernel). */
 int pnn_num_split_configs(void);
@@ -210,6 +219,10 @@ int pnn_predict_tbs_cost_device(pnn_ctx* ctx, int width, const void* d_plane, co
 /* Per-launch accounting of the last *_device call (for bench.py's roofline object): number of tap-GEMM
  * launches and their algorithmic FLOPs (2 * M * K * N summed, padding excluded). */
 int pnn_last_call_stats(const pnn_ctx* ctx, int* n_gemm_launches, double* gemm_flops, int* n_launches);
+
+/* The same FLOPs without the multiply-adds of the taps that position-major tiles skipped (they only meet SAME padding: exact zeros) --
+ * what the matrix cores were actually asked to do, for bench.py's executed-MFMA fractions of the convolutional nets. */
+int pnn_last_call_issued_flops(const pnn_ctx* ctx, double* flops);
 
 /* With pnn_set_option(ctx, "time_launches", 1) every tap-GEMM launch is bracketed by HIP events on its launch
  * stream. This call waits for them and returns, for kernel family `kind` (0 = tapgemm_f32_kernel, 2 = tapgemm_sp_kernel,

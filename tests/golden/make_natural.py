@@ -7,6 +7,10 @@ What it records (data only: uint8 luminance planes, no reference source text):
                               (hevc/visualization/map_intra_prediction_modes/readme/luminance_{cactus,kimono,parkscene}.png)
   cliff, library              luminance of hevc/pseudo_data/rgb_{cliff,library}.jpg, converted by the REFERENCE's own
                               tools.tools.rgb_to_ycbcr (imported from /root/reference), cropped to 640 x 960
+Provenance: the three PNGs are first frames of JCT-VC class-B test sequences (Cactus, Kimono, ParkScene) as the reference's authors
+published them in their repository; the two JPEGs are the authors' own test photographs.  The fixture is therefore GENERATED where the
+reference checkout exists (__graft_entry__.build() calls this script) and git-ignored: it travels to the GPU box with the working tree
+and is never committed or redistributed; tests and campaigns that need it skip / refuse when it is absent.
 The trained networks were trained on natural (ImageNet) luminance: these are the only natural pictures the repository holds, and
 what the parity / evidence tests (tests/test_natural.py) and the natural-picture HM campaigns (tools/hm/campaign.py) run on.
 """

@@ -41,6 +41,7 @@ int pnn_model_info(const pnn_ctx*, int width, int* is_fc, int*, long*)
 // ... and the context calls of pnn_service_run_table (not exercised here: they need the GPU)
 int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
 int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
+int pnn_set_option(pnn_ctx*, const char*, long) { return PNN_E_HIP; }
 void pnn_destroy(pnn_ctx*) {}
 }
 namespace pnn { void set_create_error(const std::string&) {} }

@@ -427,6 +427,22 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
     net.close()
 
 
+def test_arithmetic_tag_names_the_summation_order(pnn):
+    """pnn_arithmetic_tag: one string per arithmetic, the same for every context and width of a library build; it changes with the
+    "precision" option and with nothing else -- what an encoder and its decoder compare once at start-up."""
+    nets = [pnn.PredictionNeuralNetwork(1, w, fc, params=util.make_params(w, fc, 5)) for w, fc in ((4, True), (16, False))]
+    tags = {}
+    for prec in (0, 1):
+        for net in nets:
+            net.set_option("precision", prec)
+            net.set_option("autotune", 0); net.set_option("pair", 0)        # options that do not touch the bits do not touch the tag
+            tags.setdefault(prec, set()).add(net.arithmetic_tag())
+    assert len(tags[0]) == 1 and len(tags[1]) == 1 and tags[0] != tags[1]
+    assert "f32" in next(iter(tags[0])) and "kseg 1600/2304" in next(iter(tags[0])) and "split" in next(iter(tags[1]))
+    for net in nets:
+        net.close()
+
+
 @pytest.mark.parametrize("w,is_fc,n", [(8, True, 3001), (16, False, 333)])
 def test_pinned_caller_arrays(pnn, oracle, precision, w, is_fc, n):
     """Batched host-array calls (the shape of Session::Run / pnn/batching.py:7-88) from PINNED caller arrays (pnn_host_alloc: the copy

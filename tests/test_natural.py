@@ -31,6 +31,8 @@ MIN_DROP_DB = 0.5                                      # every perturbation must
 def natural_contexts(w, n, seed=5):
     """n (above [w, 3w], left [2w, w], target [w, w]) triples of uint8 natural luminance, all context available, blocks on the
     w-grid of the five fixture pictures (the layout of extraction_context.cpp:3-208 / sets/common.py:466-473)."""
+    if not os.path.exists(os.path.join(GOLD, "natural_luma.npz")):
+        pytest.skip("tests/golden/natural_luma.npz is generated from the reference checkout by __graft_entry__.build() (tests/golden/make_natural.py)")
     pics = np.load(os.path.join(GOLD, "natural_luma.npz"))
     rng = np.random.RandomState(seed)
     names = sorted(pics.files)

@@ -52,17 +52,6 @@ def binaries_present(variants=("substitution", "switch", "regular")):
         return False
 
 
-def _die_with_parent():
-    """preexec_fn of the service processes: SIGTERM when the parent dies (PR_SET_PDEATHSIG), so a campaign killed from outside -- a
-    `timeout` around bench.py sends SIGTERM, which skips `finally` -- leaves no service alive on the GPU."""
-    import ctypes
-    import signal
-    try:
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
-    except OSError:
-        pass
-
-
 def np_cat(above, left):
     import numpy as np
     return np.concatenate([above.reshape(-1), left.reshape(-1)])       # sets/common.py:466-473: [above | left], both row-major
@@ -111,6 +100,23 @@ def _cpu_quota():
         return None
 
 
+def _thread_cpu_s(pid):
+    """{thread name: CPU seconds} of a live process, threads of one name summed (the service names its I/O threads and width workers)."""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/%d/task" % pid):
+            try:
+                f = open("/proc/%d/task/%s/stat" % (pid, tid)).read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                g = f.rsplit(")", 1)[1].split()
+                out[name] = round(out.get(name, 0.0) + (int(g[11]) + int(g[12])) / os.sysconf("SC_CLK_TCK"), 2)
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def _proc_cpu_s(pid):
     """user + system CPU seconds of a live process, all its threads."""
     try:
@@ -137,7 +143,11 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
     h, w, variant = cfg["height"], cfg["width"], cfg["variant"]
     if backend == "cpu":
         devices = [0]
-    in_flight = int(in_flight or min(n, max(1, (os.cpu_count() or 8) - 2 * len(devices))))
+    if not in_flight:
+        # by the CPUs the job may really use (cgroup quota), not by the cores the box shows: sharding.encodes_in_flight
+        from context_adaptive_neural_network_based_prediction_amd import sharding
+        in_flight = sharding.encodes_in_flight(n, len(devices))
+    in_flight = int(in_flight)
     os.makedirs(work, exist_ok=True)
     natural = picture_set == "natural"
     table, mean_path = run_hm.make_models(os.path.join(work, "models"), trained_small=natural)
@@ -156,7 +166,10 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         else:
             cmd = [sys.executable, "-m", "context_adaptive_neural_network_based_prediction_amd.service", "--socket", sock,
                    "--table", table, "--device", str(dev), "--max-batch", "256", "--window-us", "0"]
-        servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True, preexec_fn=_die_with_parent))
+        # (the services ask for SIGTERM on their parent's death themselves, service.die_with_parent: no preexec_fn -- Python code between
+        # fork and exec of a process whose runtime threads are alive can deadlock)
+        env["PNN_SERVICE_PARENT"] = str(os.getpid())
+        servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True))
         socks.append(sock)
     results, stats, spot = [], [], {}
     try:
@@ -178,7 +191,8 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
             results = list(ex.map(job, range(n)))
         wall = time.time() - t0
         cg1 = _cgroup_cpu()
-        host_cpu = {"service_cpu_s": round(sum(_proc_cpu_s(srv.pid) for srv in servers), 2)}     # since the services started (their start-up included)
+        host_cpu = {"service_cpu_s": round(sum(_proc_cpu_s(srv.pid) for srv in servers), 2),     # since the services started (their start-up included)
+                    "service_threads_cpu_s": _thread_cpu_s(servers[0].pid)}
         if cg0 and cg1:
             host_cpu.update({"all_processes_cpu_s": round(cg1["usage_usec"] / 1e6 - cg0["usage_usec"] / 1e6, 2), "cpu_quota": _cpu_quota(),
                              "times_throttled": cg1["nr_throttled"] - cg0["nr_throttled"]})
@@ -235,7 +249,7 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         "data": ("windows of the natural fixtures (tests/golden/natural_luma.npz); widths 4 / 8 on the reference's trained convolutional checkpoints, 16 / 32 / 64 "
                  "seeded random init" if natural else "seeded synthetic pictures + seeded random-init models") + " (Kodak / BSDS and the trained production models "
                 "are not in the reference checkout)",
-        "devices": list(devices), "services": len(devices), "encodes_in_flight": in_flight, "host_cores": os.cpu_count(),
+        "devices": list(devices), "services": len(devices), "encodes_in_flight": in_flight, "host_cores": os.cpu_count(), "cpu_budget": _cpu_quota() or os.cpu_count(),
         "wall_s_all_encodes_and_decodes": round(wall, 3), "service_start_s": round(t_up, 3), "host_cpu": host_cpu,
         "pictures_per_s": round(n / wall, 3),
         "hm_total_time_s_sum": {"encoders": round(sum(r["enc_total_time_s"] or 0 for r in results), 2),

@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    from context_adaptive_neural_network_based_prediction_amd import service as _svc
+    _svc.die_with_parent()                            # SIGTERM when the campaign that started this service dies
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--socket", required=True)
     ap.add_argument("--table", required=True)
