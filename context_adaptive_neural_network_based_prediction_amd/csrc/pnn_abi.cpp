@@ -398,6 +398,17 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "flag_wait")) c->opt_flag_wait = value;
     else if (!strcmp(name, "wait_sleep")) c->opt_wait_sleep = value;
+    else if (!strcmp(name, "stream_priority")) {
+        // the context's own stream (the host entry points run on it) at the device's greatest (< 0), default (0) or least (> 0) priority
+        HIPCHK(c, hipSetDevice(c->device));
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int pr = value < 0 ? greatest : value > 0 ? least : (least + greatest) / 2;
+        hipStream_t ns = nullptr;
+        HIPCHK(c, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
+        if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+        c->stream = ns;
+    }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "f32_seg_mode")) { c->opt_f32_seg_mode = value; c->tuned.clear(); c->tune_gen++; }
     else if (!strcmp(name, "f32_persist")) { c->opt_f32_persist = value; c->tuned.clear(); c->tune_gen++; }

@@ -616,8 +616,16 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             rc = pnn_create_empty(&ctxs[k][r], mean, device);
             if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
             if (rc == PNN_OK && !getenv("PNN_WAIT_SLEEP")) pnn_set_option(ctxs[k][r], "wait_sleep", 1);   // five workers that spin would hold five CPUs for the length of a campaign
-            // the file must hold a model of the width its table row names (pnn_create's check)
-            if (rc == PNN_OK && pnn_model_info(ctxs[k][r], kWidths[k], nullptr, nullptr, nullptr) != PNN_OK) rc = PNN_E_MODEL;
+            // Stream priorities per width: PNN_SERVICE_PRIORITIES = five of h / n / l (default: all normal).  Streams of one priority
+            // share the runtime's few hardware queues and two busy widths on one queue serialise -- with the two FC widths on high-priority
+            // streams a conv 16x16 / 32x32 call takes 114 / 198 us instead of 180 / 258 inside a configs[3] campaign, but a 4x4 call 68
+            // instead of 57 and a 64x64 call 760 instead of 370, and the 4x4 worker is the one the encoders wait for: campaign walls
+            // 6.3-6.4 s against 6.0-6.4 (hhlll / hhnll / hhhll against nnnnn, same box, round 5).  Left as a knob.
+            if (rc == PNN_OK) {
+                const char* pr = getenv("PNN_SERVICE_PRIORITIES");
+                const char lvl = (pr && strlen(pr) == 5) ? pr[k] : 'n';
+                if (lvl != 'n') pnn_set_option(ctxs[k][r], "stream_priority", lvl == 'h' ? -1 : 1);
+            }
         }
     }
     if (rc == PNN_OK) {

@@ -105,6 +105,7 @@ float pnn_mean(const pnn_ctx* ctx);
  *                              bytes were predicted before (HM's RD search repeats itself); dropped on any option / model change
  *   "flag_wait"            1   a small host call ends when its LAST kernel raises a sequence number in pinned host memory (3-7 us earlier
  *                              than the runtime's completion signal); "spin_wait" (0): hipStreamQuery polling instead of hipStreamSynchronize
+ *   "stream_priority"      0   < 0 / > 0: the context's own stream (host entry points) at the device's greatest / least priority
  *   "wait_sleep"           0   1: the thread of a small host call sleeps through the predictable part of its wait (running mean per batch
  *                              size, minus a margin) and spins only for the rest: the batching service's workers set it (two thirds of
  *                              their CPU time was that spin); a stand-alone codec keeps 0

@@ -636,7 +636,8 @@ def _canned_measurement(name, precision, lsb=0):
             "roofline": {"bound": "mfma", "kernel": "tapgemm_ring_kernel (same split-product MFMAs; 4 MFMA + 4 loader waves, LDS-DMA ring; incl. the fused output layer)",
                          "achieved": 118.7654321, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.7550123456, "traffic": 59355500.61482544,
                          "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE", "flops_per_launch": 8912345678.9, "avg_launch_us": 75.0123456,
-                         "launches_timed": 150, "whole_pass": {"tflops": 107.123456, "frac_of_peak": 0.681234567}}}
+                         "launches_timed": 150, "held_sclk_mhz": 1904.123456, "frac_at_held_clock": 0.4512345678,
+                         "whole_pass": {"tflops": 107.123456, "frac_of_peak": 0.681234567, "issued_frac_of_peak": 0.612345678, "issued_over_algorithmic": 0.8312345}}}
 
 
 def test_bench_line_fits_the_driver_tail_buffer():

@@ -37,6 +37,7 @@ int main(int argc, char** argv)
         for (int a = 4; a < argc; a++) {
             std::string s(argv[a]);
             const size_t eq = s.find('=');
+            if (s == "fcprio") { pnn_set_option(ctx[k], "stream_priority", k < 2 ? -1 : 1); continue; }   // widths 4 / 8 ahead of the conv widths
             if (eq != std::string::npos) pnn_set_option(ctx[k], s.substr(0, eq).c_str(), atol(s.c_str() + eq + 1));
         }
         pnn_model_info(ctx[k], kCases[k].w, &is_fc[k], nullptr, nullptr);

@@ -3,9 +3,9 @@
 #   rocprofv3 --kernel-trace --stats of the bench command per width and arithmetic (the exact-f32 reference arithmetic first),
 #   separate --pmc passes (counters only) for MFMA utilisation, LDS conflicts and HBM traffic of FC 8x8 and conv 16x16 on both
 #   arithmetics, the step timelines, the f32 tile sweep, and the default bench line with its detail file.
-#   usage: tools/profile_round.sh r04        (from the repo root, ~6 minutes)
+#   usage: tools/profile_round.sh r05        (from the repo root, ~8 minutes)
 export TMPDIR=/tmp
-r=${1:-r04}
+r=${1:-r05}
 out=gpurun_out/profiles_$r
 mkdir -p $out
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
@@ -39,5 +39,13 @@ python3 tools/pmc_traffic.py $out/pmc_traffic.json fc8_split conv16_split fc8_f3
 python3 tools/f32_sweep.py fc8 conv16 fc4 conv32 conv64 > $out/f32_tile_sweep.txt 2>&1
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 cp bench_detail.json $out/bench_default_detail.json
+# round 5: the single-block path on the reference's arithmetic, the host-array entry points, the width workers side by side
+( echo "tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
+( echo "# tools/host_rate.py on one MI355X: the batched HOST-array entry points (pnn_predict_pel: host arrays in, int32 blocks out, one synchronous call per batch)"; python3 tools/host_rate.py fc8 conv16 fc4 conv32 conv64 2>&1 | grep -v amdgpu.ids ) > $out/host_rate.txt
+( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
+[ -x build_tmp/f32_chain_probe ] && ( echo "# tools/f32_chain_probe.hip: one wave, one dependent accumulation chain per instruction form (cycles by s_memtime)"; ./build_tmp/f32_chain_probe ) > $out/f32_chain_probe.txt
+PNN_PRECISION=0 ./tools/batch1_kernels.sh $out/b1_f32 8 16 32 64 > /dev/null 2>&1
+for w in 8 16 32 64; do cp $out/b1_f32/b1_w${w}_timeline.txt $out/batch1_w${w}_f32_timeline.txt 2>/dev/null; done
+rm -rf $out/b1_f32
 rm -f $out/*_trace.log $out/*_pmc_p*.log
 ls -la $out
