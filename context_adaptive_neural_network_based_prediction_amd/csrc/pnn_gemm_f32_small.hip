@@ -205,38 +205,32 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // The next chunk's two reads sit BETWEEN this chunk's MFMAs (one behind the first, one behind the third): both in front of the
-    // four measured 170 cycles per chunk in tools/f32_chain_probe.hip, interleaved 146 (the bare chain: 128).
-    for (int s = 0; s < nst; s++) {
-        const int cb = c0 + s * CS;
+    // four measured 170 cycles per chunk in tools/f32_chain_probe.hip, interleaved 146 (the bare chain: 128).  And NO branch inside a
+    // stage: a chunk past the end of K (the tail of the last stage) holds zeros in both operands -- range misses of the loaders -- and
+    // fma(0, 0, acc) = acc exactly, so it is multiplied like any other instead of being skipped (with a liveness test per chunk the
+    // loop ran at 211 cycles per chunk, without at 165: PNN_F32S_DIAG).
+    auto chunk = [&](int k, const f32x4* nsrc, int kn, bool rd) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][0], fx[k][0], acc, 0, 0, 0);
+        if (rd) fw[kn] = nsrc[0];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][1], fx[k][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][2], fx[k][2], acc, 0, 0, 0);
+        if (rd) fx[kn] = nsrc[64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][3], fx[k][3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s + 1 < nst; s++) {              // every stage but the last: its last chunk fetches the next stage's first
+        const int nslot = slot + 1 == D ? 0 : slot + 1;
 #pragma unroll
-        for (int k = 0; k < CS; k++) {
-            constexpr int kLast = CS - 1;
-            const int kn = k == kLast ? 0 : k + 1;
-            bool rd = true;
-            const f32x4* nsrc = ring + (slot * CS + kn) * 128 + lane;
-            if (k == kLast) {
-                const int nslot = slot + 1 == D ? 0 : slot + 1;
-                rd = s + 1 < nst;
-                if (rd) __builtin_amdgcn_s_barrier();    // stage s + 1 is in the ring, the slot of stage s - 1 may be refilled
-                nsrc = ring + (nslot * CS) * 128 + lane;
-                slot = nslot;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (cb + k < c1) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][0], fx[k][0], acc, 0, 0, 0);
-                if (rd) fw[kn] = nsrc[0];
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][1], fx[k][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][2], fx[k][2], acc, 0, 0, 0);
-                if (rd) fx[kn] = nsrc[64];
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][3], fx[k][3], acc, 0, 0, 0);
-            } else if (rd) {
-                fw[kn] = nsrc[0]; fx[kn] = nsrc[64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int k = 0; k + 1 < CS; k++) chunk(k, ring + (slot * CS + k + 1) * 128 + lane, k + 1, true);
+        __builtin_amdgcn_s_barrier();                // stage s + 1 is in the ring, the slot of stage s - 1 may be refilled
+        chunk(CS - 1, ring + (nslot * CS) * 128 + lane, 0, true);
+        slot = nslot;
     }
+#pragma unroll
+    for (int k = 0; k + 1 < CS; k++) chunk(k, ring + (slot * CS + k + 1) * 128 + lane, k + 1, true);
+    chunk(CS - 1, ring, 0, false);
 #ifdef PNN_F32_DIAG
     if (p.Xlo && lane == 0) {
         unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((bz * gridDim.y + by) * gridDim.x + bx);
