@@ -180,27 +180,33 @@ __device__ __forceinline__ void tapgemm_small_body(CSmallParams& p, const int se
     };
     int slot = 0;
     read_chunk(0, 0);
-    for (int s = 0; s < nst; s++) {
-        const int cb = c0 + s * CS;                  // chunks past c1 (tail of the last stage) hold zeros: skipped, not multiplied
+    // No branch inside a stage (round 5, as in tapgemm_f32_small_kernel): the chunks past c1 (tail of the last stage) hold zeros in both
+    // operands -- range misses of the loaders -- and three MFMAs on zeros add exact zeros, so they are multiplied like any other instead
+    // of being tested for; the chain wave pays every branch on top of its MFMAs.
+    for (int s = 0; s + 1 < nst; s++) {              // every stage but the last
+        const int nslot = slot + 1 == D ? 0 : slot + 1;
 #pragma unroll
         for (int k = 0; k < CS; k++) {
             if (k + 1 < CS) {
                 read_chunk(slot, k + 1);
             } else {
-                const int nslot = slot + 1 == D ? 0 : slot + 1;
-                // the whole stage is in registers.  Through the builtin, not inline asm, and on both paths: the compiler's own
-                // wait insertion then knows that chunk CS - 1's registers are ready and does not wait for the NEXT stage's
-                // first reads in front of its MFMAs (it did: s_waitcnt lgkmcnt(1) there, the overlap gone)
+                // the whole stage is in registers.  Through the builtin, not inline asm: the compiler's own wait insertion then knows
+                // that chunk CS - 1's registers are ready and does not wait for the NEXT stage's first reads in front of its MFMAs
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched (gfx9 encoding)
-                if (s + 1 < nst) {
-                    __builtin_amdgcn_s_barrier();    // barrier s: stage s + 1 is in the ring, slot of stage s may be refilled
-                    read_chunk(nslot, 0);
-                }
-                slot = nslot;
+                __builtin_amdgcn_s_barrier();        // barrier s: stage s + 1 is in the ring, slot of stage s may be refilled
+                read_chunk(nslot, 0);
             }
             __builtin_amdgcn_sched_barrier(0);       // keep the requests in front of the MFMAs they hide under
-            if (cb + k < c1) mfma_chunk(k);
+            mfma_chunk(k);
         }
+        slot = nslot;
+    }
+#pragma unroll
+    for (int k = 0; k < CS; k++) {                   // the last stage: nothing behind it
+        if (k + 1 < CS) read_chunk(slot, k + 1);
+        else __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(k);
     }
     if (AF32) report_range(p.range_flag, amax_in);
 
