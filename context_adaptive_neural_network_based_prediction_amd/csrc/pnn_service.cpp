@@ -159,8 +159,8 @@ struct Server {
     // (3w^2 + 2w^2), -2 = no model for this width (every request is refused), -1 = unknown (generic backend: it validates).
     int kind[5] = {-1, -1, -1, -1, -1};
 
-    struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; };
-    struct Reply { uint64_t id; std::vector<char> bytes; };
+    struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; Clock::time_point t_in; };
+    struct Reply { uint64_t id; std::vector<char> bytes; Clock::time_point t_in; int k; };
     // Locks: one per worker queue (with its condition variable), one per I/O thread's reply / new-connection queues, one for
     // the peer accounting (only kept when a batching window is set) and the statistics.  (A single server-wide mutex was taken
     // five times per request by nine threads.)
@@ -188,89 +188,120 @@ struct Server {
     long served = 0, calls = 0, largest = 0;
     double busy_s[5] = {0, 0, 0, 0, 0};   // time inside the backend, per worker (PNN_SERVICE_DEBUG)
     long calls_w[5] = {0, 0, 0, 0, 0}, served_w[5] = {0, 0, 0, 0, 0};   // backend calls / requests per worker
+    // Where a request's time inside the server goes (PNN_SERVICE_DEBUG): from its last byte received to its batch taken by the worker
+    // (wait_s, under `mu`), and to its reply accepted by the socket (resident_s, per I/O thread: no lock).
+    double wait_s[5] = {0, 0, 0, 0, 0}, resident_s[kMaxIo][5] = {};
+    long resident_n[kMaxIo][5] = {};
 
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
     static int kServiceWidthsOf(int k) { return 4 << k; }
     int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
 
+    // One batch on its way through a worker: the requests and their inputs stacked.
+    struct Flight {
+        std::vector<Req> batch;
+        std::vector<float> above, left;
+        bool any_f32 = false, any_pel = false;
+        double waited = 0;                           // seconds the requests sat in the queue, summed
+    };
+    // one batch = requests of ONE width and ONE input kind, in arrival order; under qmu[k]
+    void take(int k, std::vector<Req>& batch)
+    {
+        batch.clear();
+        if (queue[k].empty()) return;
+        const int w = queue[k][0].width;
+        const bool has_left = !queue[k][0].left.empty();
+        for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
+            if (queue[k][i].width == w && !queue[k][i].left.empty() == has_left) {
+                batch.push_back(std::move(queue[k][i]));
+                queue[k].erase(queue[k].begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    void stage(Flight& f)
+    {
+        const size_t n = f.batch.size(), na = f.batch[0].above.size(), nl = f.batch[0].left.size();
+        f.any_f32 = f.any_pel = false;
+        f.above.resize(n * na); f.left.resize(n * nl);
+        const auto now = Clock::now();
+        f.waited = 0;
+        for (size_t i = 0; i < n; i++) {
+            memcpy(f.above.data() + i * na, f.batch[i].above.data(), na * 4);
+            if (nl) memcpy(f.left.data() + i * nl, f.batch[i].left.data(), nl * 4);
+            (f.batch[i].want_f32 ? f.any_f32 : f.any_pel) = true;
+            f.waited += std::chrono::duration<double>(now - f.batch[i].t_in).count();
+        }
+    }
+    // the replies of one finished batch to the I/O threads that own the connections, and the statistics
+    void reply(int k, Flight& f, int rc, const int32_t* dst, const float* out, double busy)
+    {
+        const size_t n = f.batch.size(), w2 = (size_t)f.batch[0].width * f.batch[0].width;
+        std::vector<Reply> replies(n);
+        for (size_t i = 0; i < n; i++) {
+            const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
+            replies[i].id = f.batch[i].id; replies[i].t_in = f.batch[i].t_in; replies[i].k = k;
+            const char* hp = reinterpret_cast<const char*>(&rh);
+            replies[i].bytes.assign(hp, hp + sizeof rh);
+            if (rc == 0) {
+                const char* pp = f.batch[i].want_f32 ? reinterpret_cast<const char*>(out + i * w2) : reinterpret_cast<const char*>(dst + i * w2);
+                replies[i].bytes.insert(replies[i].bytes.end(), pp, pp + w2 * 4);
+            }
+        }
+        bool woke[kMaxIo] = {false};
+        for (int t = 0; t < nio; t++) {          // replies to their owners, one lock per I/O thread that has any
+            bool any = false;
+            for (auto& r : replies) any |= (int)(r.id & 15) % nio == t;
+            if (!any) continue;
+            woke[t] = true;
+            std::lock_guard<std::mutex> lk(dmu[t]);
+            for (auto& r : replies) if ((int)(r.id & 15) % nio == t) done[t].push_back(std::move(r));
+        }
+        const char one = 1;
+        for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t][1], &one, 1);
+        std::lock_guard<std::mutex> lk(mu);
+        served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
+        ++calls_w[k]; served_w[k] += (long)n; busy_s[k] += busy; wait_s[k] += f.waited;
+    }
+    // Blocks until worker k has something to do (false: the server stops).  An idle worker gives stragglers a moment to join --
+    // unless every peer process already waits for an answer (an encoder is single-threaded and blocks on its request: nobody
+    // else can arrive).
+    bool wait_for_work(int k, std::vector<Req>& batch)
+    {
+        std::unique_lock<std::mutex> lk(qmu[k]);
+        cv[k].wait(lk, [&] { return quit_flag.load() || !queue[k].empty(); });
+        if (quit_flag.load()) return false;
+        if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers.load() < n_peers.load()) {
+            const auto until = Clock::now() + std::chrono::microseconds(window_us);
+            cv[k].wait_until(lk, until, [&] { return quit_flag.load() || (int)queue[k].size() >= max_batch || n_waiting_peers.load() >= n_peers.load(); });
+            if (quit_flag.load()) return false;
+        }
+        // the lock was released during the window: the I/O thread may have dropped the only queued request
+        // (an encoder killed or timed out mid-window) -- the batch is then empty
+        take(k, batch);
+        return true;
+    }
+
     void worker(int k, int r)
     {
         { char nm[16]; snprintf(nm, sizeof nm, "pnn-w%d", nworkers == 1 ? 0 : kServiceWidthsOf(k)); prctl(PR_SET_NAME, nm, 0, 0, 0); }   // (per-thread CPU accounting: campaign.py reads /proc/<pid>/task/*/stat)
         prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // the contexts' "wait_sleep" naps are tens of microseconds: not with the default 50 us of slack
-        std::vector<Req> batch;
-        std::vector<float> above, left, out;
+        Flight f;
+        std::vector<float> out;
         std::vector<int32_t> dst;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(qmu[k]);
-                cv[k].wait(lk, [&] { return quit_flag.load() || !queue[k].empty(); });
-                if (quit_flag.load()) return;
-                // an idle worker gives stragglers a moment to join -- unless every peer process already waits for an answer
-                // (an encoder is single-threaded and blocks on its request: nobody else can arrive)
-                if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers.load() < n_peers.load()) {
-                    const auto until = Clock::now() + std::chrono::microseconds(window_us);
-                    cv[k].wait_until(lk, until, [&] { return quit_flag.load() || (int)queue[k].size() >= max_batch || n_waiting_peers.load() >= n_peers.load(); });
-                    if (quit_flag.load()) return;
-                }
-                // the lock was released during the window: the I/O thread may have dropped the only queued request
-                // (an encoder killed or timed out mid-window)
-                if (queue[k].empty()) continue;
-                // one batch = requests of ONE width and ONE input kind, in arrival order
-                const int w = queue[k][0].width;
-                const bool has_left = !queue[k][0].left.empty();
-                batch.clear();
-                for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
-                    if (queue[k][i].width == w && !queue[k][i].left.empty() == has_left) {
-                        batch.push_back(std::move(queue[k][i]));
-                        queue[k].erase(queue[k].begin() + (long)i);
-                    } else {
-                        ++i;
-                    }
-                }
-            }
-            if (batch.empty()) continue;
-            const int w = batch[0].width;
-            const size_t n = batch.size(), w2 = (size_t)w * w, na = batch[0].above.size(), nl = batch[0].left.size();
-            bool any_f32 = false, any_pel = false;
-            above.resize(n * na); left.resize(n * nl);
-            for (size_t i = 0; i < n; i++) {
-                memcpy(above.data() + i * na, batch[i].above.data(), na * 4);
-                if (nl) memcpy(left.data() + i * nl, batch[i].left.data(), nl * 4);
-                (batch[i].want_f32 ? any_f32 : any_pel) = true;
-            }
-            if (any_pel) dst.resize(n * w2);
-            if (any_f32) out.resize(n * w2);
+            if (!wait_for_work(k, f.batch)) return;
+            if (f.batch.empty()) continue;
+            stage(f);
+            const int w = f.batch[0].width;
+            const size_t n = f.batch.size(), w2 = (size_t)w * w;
+            if (f.any_pel) dst.resize(n * w2);
+            if (f.any_f32) out.resize(n * w2);
             const auto tb0 = Clock::now();
-            const int rc = backend(users[nworkers == 1 ? 0 : k][r], w, above.data(), nl ? left.data() : nullptr, (int)n, any_pel ? dst.data() : nullptr,
-                                   any_f32 ? out.data() : nullptr);
-            const double busy = std::chrono::duration<double>(Clock::now() - tb0).count();
-            std::vector<Reply> replies(n);
-            for (size_t i = 0; i < n; i++) {
-                const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
-                replies[i].id = batch[i].id;
-                const char* hp = reinterpret_cast<const char*>(&rh);
-                replies[i].bytes.assign(hp, hp + sizeof rh);
-                if (rc == 0) {
-                    const char* pp = batch[i].want_f32 ? reinterpret_cast<const char*>(out.data() + i * w2) : reinterpret_cast<const char*>(dst.data() + i * w2);
-                    replies[i].bytes.insert(replies[i].bytes.end(), pp, pp + w2 * 4);
-                }
-            }
-            bool woke[kMaxIo] = {false};
-            for (int t = 0; t < nio; t++) {          // replies to their owners, one lock per I/O thread that has any
-                bool any = false;
-                for (auto& r : replies) any |= (int)(r.id & 15) % nio == t;
-                if (!any) continue;
-                woke[t] = true;
-                std::lock_guard<std::mutex> lk(dmu[t]);
-                for (auto& r : replies) if ((int)(r.id & 15) % nio == t) done[t].push_back(std::move(r));
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
-                ++calls_w[k]; served_w[k] += (long)n; busy_s[k] += busy;
-            }
-            const char one = 1;
-            for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t][1], &one, 1);
+            const int rc = backend(users[nworkers == 1 ? 0 : k][r], w, f.above.data(), f.left.empty() ? nullptr : f.left.data(), (int)n, f.any_pel ? dst.data() : nullptr,
+                                   f.any_f32 ? out.data() : nullptr);
+            reply(k, f, rc, dst.data(), out.data(), std::chrono::duration<double>(Clock::now() - tb0).count());
         }
     }
 
@@ -376,7 +407,7 @@ struct Server {
                             return flush(c);
                         }
                         Req r;
-                        r.id = id; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0;
+                        r.id = id; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0; r.t_in = Clock::now();
                         r.above.resize(h.n_above); r.left.resize(h.n_left);
                         memcpy(r.above.data(), c.rx.data() + sizeof h, (size_t)h.n_above * 4);
                         if (h.n_left) memcpy(r.left.data(), c.rx.data() + sizeof h + (size_t)h.n_above * 4, (size_t)h.n_left * 4);
@@ -457,6 +488,7 @@ struct Server {
                         }
                         if (!flush(c)) gone.push_back(rp.id);
                         else if (!c.tx.empty()) arm(rp.id, c);   // the socket took only part of it: wait for EPOLLOUT
+                        resident_s[t][rp.k] += std::chrono::duration<double>(Clock::now() - rp.t_in).count(); ++resident_n[t][rp.k];
                     }
                 } else {
                     auto it = clients.find(id);
@@ -542,8 +574,13 @@ struct Server {
         if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted.load(); }
         if (getenv("PNN_SERVICE_DEBUG"))
             for (int k = 0; k < nworkers; k++)
-                fprintf(stderr, "[pnn-service] worker %d: %.2f s inside the backend, %ld calls (%.1f us each), %ld requests (%.2f per call)\n", k, busy_s[k],
-                        calls_w[k], calls_w[k] ? busy_s[k] * 1e6 / calls_w[k] : 0.0, served_w[k], calls_w[k] ? (double)served_w[k] / calls_w[k] : 0.0);
+            {
+                double rs = 0; long rn = 0;
+                for (int t = 0; t < nio; t++) { rs += resident_s[t][k]; rn += resident_n[t][k]; }
+                fprintf(stderr, "[pnn-service] worker %d: %.2f s inside the backend, %ld calls (%.1f us each), %ld requests (%.2f per call); per request %.1f us queued before "
+                        "its batch is taken, %.1f us from last byte in to reply out\n", k, busy_s[k], calls_w[k], calls_w[k] ? busy_s[k] * 1e6 / calls_w[k] : 0.0, served_w[k],
+                        calls_w[k] ? (double)served_w[k] / calls_w[k] : 0.0, served_w[k] ? wait_s[k] * 1e6 / served_w[k] : 0.0, rn ? rs * 1e6 / rn : 0.0);
+            }
         return PNN_OK;
     }
 };

@@ -64,10 +64,13 @@ def _service_stats(stdout_text, stderr_text):
         req, calls, largest, clients = map(int, m.groups())
         out = {"requests": req, "backend_calls": calls, "largest_batch": largest, "mean_batch": round(req / max(calls, 1), 3), "clients": clients}
     workers = {}
-    for m in re.finditer(r"worker (\d+): ([0-9.]+) s inside the backend, (\d+) calls \(([0-9.]+) us each\), (\d+) requests", stderr_text):
+    for m in re.finditer(r"worker (\d+): ([0-9.]+) s inside the backend, (\d+) calls \(([0-9.]+) us each\), (\d+) requests"
+                         r"(?: \([0-9.]+ per call\); per request ([0-9.]+) us queued before its batch is taken, ([0-9.]+) us from last byte in to reply out)?", stderr_text):
         k = int(m.group(1))
         workers[(4, 8, 16, 32, 64)[k]] = {"backend_busy_s": float(m.group(2)), "calls": int(m.group(3)), "us_per_call": float(m.group(4)),
                                           "requests": int(m.group(5))}
+        if m.group(6):
+            workers[(4, 8, 16, 32, 64)[k]].update(queued_us_per_request=float(m.group(6)), in_server_us_per_request=float(m.group(7)))
     if workers:
         out["per_width"] = workers
     return out
@@ -224,6 +227,9 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
             log.seek(0)
             se = log.read()
             log.close()
+            for line in se.splitlines():               # whatever the service complained about goes to this process's stderr, not only into the statistics
+                if line.startswith("[pnn-service]") and "worker" not in line and "start-up" not in line:
+                    sys.stderr.write(line + "\n")
             stats.append(_service_stats(so or "", se or ""))
     calls = {}
     for side in ("enc_pnn", "dec_pnn"):
@@ -238,10 +244,16 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         for wd, v in s.get("per_width", {}).items():
             b = busy.setdefault(wd, {"backend_busy_s": 0.0, "calls": 0, "requests": 0})
             b["backend_busy_s"] += v["backend_busy_s"]; b["calls"] += v["calls"]; b["requests"] += v["requests"]
+            for key in ("queued_us_per_request", "in_server_us_per_request"):
+                if key in v:
+                    b[key] = b.get(key, 0.0) + v[key] * v["requests"]
     for wd, b in busy.items():
         b["blocks_per_s_inside_backend"] = round(b["requests"] / b["backend_busy_s"], 1) if b["backend_busy_s"] > 0 else None
         b["mean_batch"] = round(b["requests"] / max(b["calls"], 1), 3)
         b["backend_busy_s"] = round(b["backend_busy_s"], 3)
+        for key in ("queued_us_per_request", "in_server_us_per_request"):
+            if key in b:
+                b[key] = round(b[key] / max(b["requests"], 1), 1)
     out = {
         "config": cfg["baseline"], "variant": "hm_16_15_" + variant, "pictures": n, "picture_size": "%dx%d 4:0:0" % (w, h), "qp": qp,
         "picture_set": picture_set, "pnn_backend": backend,
