@@ -1,20 +1,20 @@
 #!/bin/bash
 # A/B of the working tree against a git revision ON ONE BOX (box-to-box variance is +-4 %, more than most single changes):
-#   here:        ./tools/ab.sh build [rev]      builds <rev> (default HEAD) into build_tmp/libpnn_hip_prev.so
+#   here:        ./tools/ab.sh build [rev]      builds <rev> (default HEAD) into tools/_bin/libpnn_hip_prev.so
 #   on the box:  gpurun -- './tools/ab.sh run [workload ...]'   alternates the two libraries, 3 rounds
 set -e
 if [ "$1" = "build" ]; then
   rev=${2:-HEAD}
-  rm -rf /tmp/pnn_prev && mkdir -p /tmp/pnn_prev build_tmp
+  rm -rf /tmp/pnn_prev && mkdir -p /tmp/pnn_prev tools/_bin
   git archive "$rev" context_adaptive_neural_network_based_prediction_amd/csrc include | tar -x -C /tmp/pnn_prev
   make -C /tmp/pnn_prev/context_adaptive_neural_network_based_prediction_amd/csrc > /dev/null
-  cp /tmp/pnn_prev/context_adaptive_neural_network_based_prediction_amd/libpnn_hip.so build_tmp/libpnn_hip_prev.so
-  echo "built $rev -> build_tmp/libpnn_hip_prev.so"
+  cp /tmp/pnn_prev/context_adaptive_neural_network_based_prediction_amd/libpnn_hip.so tools/_bin/libpnn_hip_prev.so
+  echo "built $rev -> tools/_bin/libpnn_hip_prev.so"
 else
   shift || true
   wls=${@:-fc8 conv16}
   for i in 1 2 3; do
-    for lib in build_tmp/libpnn_hip_prev.so context_adaptive_neural_network_based_prediction_amd/libpnn_hip.so; do
+    for lib in tools/_bin/libpnn_hip_prev.so context_adaptive_neural_network_based_prediction_amd/libpnn_hip.so; do
       for wl in $wls; do
         v=$(PNN_LIB_PATH=$PWD/$lib python3 bench.py --workload $wl --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4g blocks/s  %.4f ms' % (d['value'], d['ms_per_step']))")
         echo "$(basename $lib) $wl: $v"

@@ -1,7 +1,7 @@
 // Diagnostic (not part of the product): times convimg_sp_kernel on a synthetic 3x3 stride-1 convolution layer and prints
 // the coarse phase stamps of wave 0 (PNN_CI_DIAG).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPNN_CI_DIAG -Icontext_adaptive_neural_network_based_prediction_amd/csrc -Iinclude tools/convimg_prof.hip -o build_tmp/ci_prof
-//   ./build_tmp/ci_prof [images] [H] [W] [Cin] [Cout]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPNN_CI_DIAG -Icontext_adaptive_neural_network_based_prediction_amd/csrc -Iinclude tools/convimg_prof.hip -o tools/_bin/ci_prof
+//   ./tools/_bin/ci_prof [images] [H] [W] [Cin] [Cout]
 #include "pnn_convimg_sp.hip"
 namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; }
 #include <cstdio>

@@ -2,8 +2,8 @@
 // processor) or their WORK on the CUs?  One thread issues FC 4x4 calls of six blocks back to back (pnn_predict_f32_pel); a second thread
 // makes noise on its own stream: (1) empty kernels back to back -- launches, no work; (2) one long kernel per ~200 us that keeps N
 // workgroups busy with dependent MFMA chains and LDS traffic -- work, hardly any launch; (3) both.  Prints the FC call's time per mode.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/corun_noise.hip -o build_tmp/corun_noise -Lcontext_adaptive_neural_network_based_prediction_amd -lpnn_hip -Wl,-rpath,$PWD/context_adaptive_neural_network_based_prediction_amd
-//   build_tmp/corun_noise <model table> <seconds>
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/corun_noise.hip -o tools/_bin/corun_noise -Lcontext_adaptive_neural_network_based_prediction_amd -lpnn_hip -Wl,-rpath,$PWD/context_adaptive_neural_network_based_prediction_amd
+//   tools/_bin/corun_noise <model table> <seconds>
 #include <hip/hip_runtime.h>
 #include "pnn_hip.h"
 

@@ -1,6 +1,6 @@
 // Diagnostic (not part of the product): does a plain VALU kernel give repeatable results while a dense-MFMA kernel from
 // another host thread / stream shares the chip?  No code of the library is involved.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/corun_probe.hip -o build_tmp/corun_probe -lpthread
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/corun_probe.hip -o tools/_bin/corun_probe -lpthread
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

@@ -1,8 +1,8 @@
 // What the batching service's five width workers do to each other on ONE GPU, without sockets: one host thread and one context per width
 // (as pnn_service_run_table keeps them), each issuing back-to-back host calls (pnn_predict_f32_pel) of a typical campaign batch; per
 // width the time per call alone and with the other widths running.  tools/corun_threads.py builds the models and runs it.
-//   g++ -O2 -std=c++17 -Iinclude tools/corun_threads.cpp -o build_tmp/corun_threads -Lcontext_adaptive_neural_network_based_prediction_amd -lpnn_hip -lpthread
-//   build_tmp/corun_threads <model table> <precision 0|1> <seconds> [option=value ...]
+//   g++ -O2 -std=c++17 -Iinclude tools/corun_threads.cpp -o tools/_bin/corun_threads -Lcontext_adaptive_neural_network_based_prediction_amd -lpnn_hip -lpthread
+//   tools/_bin/corun_threads <model table> <precision 0|1> <seconds> [option=value ...]
 #include "pnn_hip.h"
 
 #include <atomic>

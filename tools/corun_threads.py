@@ -1,10 +1,10 @@
 """Builds seeded models in the reference's five architectures and runs tools/corun_threads.cpp on them (both arithmetics):
-    python tools/corun_threads.py [seconds] [option=value ...]         (GPU box; build_tmp/corun_threads is compiled here or travels)"""
+    python tools/corun_threads.py [seconds] [option=value ...]         (GPU box; tools/_bin/corun_threads is compiled here or travels)"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools", "hm"))
 import run_hm
-exe = os.path.join(ROOT, "build_tmp", "corun_threads")
+exe = os.path.join(ROOT, "tools", "_bin", "corun_threads")
 libdir = os.path.join(ROOT, "context_adaptive_neural_network_based_prediction_amd")
 if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(ROOT, "tools", "corun_threads.cpp")):
     os.makedirs(os.path.dirname(exe), exist_ok=True)

@@ -1,6 +1,6 @@
 // Round 5: what one dependent chain of v_mfma_f32_16x16x4_f32 costs per instruction on gfx950, alone and with the per-instruction work
 // of tapgemm_f32_small_kernel around it (operand selects on the VALU, LDS fragment reads): cycles by s_memtime, one wave.
-//   hipcc --offload-arch=gfx950 -O3 tools/f32_chain_probe.hip -o build_tmp/f32_chain_probe && gpurun -- ./build_tmp/f32_chain_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/f32_chain_probe.hip -o tools/_bin/f32_chain_probe && gpurun -- ./tools/_bin/f32_chain_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

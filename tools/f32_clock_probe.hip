@@ -4,7 +4,7 @@
 // operands that are random data instead of two constant registers (R).  Prints TFLOP/s and the in-kernel clock
 // (s_memtime / s_memrealtime x 100 MHz) per variant: the bench's exact-f32 FC kernel runs its loop at 0.976 of the matrix rate in
 // CYCLES while the SMU reports 2.4 GHz and 1160 W of a 1400 W cap, yet the cycles themselves come at 2.07 GHz.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/f32_clock_probe.hip -o build_tmp/f32_clock_probe && gpurun -- ./build_tmp/f32_clock_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/f32_clock_probe.hip -o tools/_bin/f32_clock_probe && gpurun -- ./tools/_bin/f32_clock_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 // Diagnostic (not part of the product): is a kernel's argument block stable for the whole life of the kernel when several
 // host threads launch on their own streams?  Every workgroup re-reads its 1 KiB argument block from memory (scalar cache
 // invalidated each round) and counts words that are not what the host passed.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kernarg_probe.hip -o build_tmp/kernarg_probe -lpthread
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kernarg_probe.hip -o tools/_bin/kernarg_probe -lpthread
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <thread>

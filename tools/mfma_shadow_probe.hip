@@ -1,6 +1,6 @@
 // Diagnostic (not part of the product): how many independent VALU instructions (v_fma_f32, optionally with LDS reads) fit into
 // the shadow of a wave's OWN back-to-back v_mfma_f32_32x32x16_f16 for free?  One or two waves per SIMD, every CU busy.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops tools/mfma_shadow_probe.hip -o build_tmp/mfma_shadow_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops tools/mfma_shadow_probe.hip -o tools/_bin/mfma_shadow_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -7,7 +7,7 @@
 // passes -- PROVIDED the references are scalar instructions: this file is built with packed-fp32 code generation, and
 // with __builtin_fmaf references the compiler packed pairs of THEM into form A; forms B, E, F, G then "failed" too (32 ...
 // 256 per run), which a first reading took for a wider erratum.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pkfma_probe.hip -o build_tmp/pkfma_probe -lpthread
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pkfma_probe.hip -o tools/_bin/pkfma_probe -lpthread
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <thread>

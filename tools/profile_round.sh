@@ -43,7 +43,7 @@ cp bench_detail.json $out/bench_default_detail.json
 ( echo "tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
 ( echo "# tools/host_rate.py on one MI355X: the batched HOST-array entry points (pnn_predict_pel: host arrays in, int32 blocks out, one synchronous call per batch)"; python3 tools/host_rate.py fc8 conv16 fc4 conv32 conv64 2>&1 | grep -v amdgpu.ids ) > $out/host_rate.txt
 ( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
-[ -x build_tmp/f32_chain_probe ] && ( echo "# tools/f32_chain_probe.hip: one wave, one dependent accumulation chain per instruction form (cycles by s_memtime)"; ./build_tmp/f32_chain_probe ) > $out/f32_chain_probe.txt
+[ -x tools/_bin/f32_chain_probe ] && ( echo "# tools/f32_chain_probe.hip: one wave, one dependent accumulation chain per instruction form (cycles by s_memtime)"; ./tools/_bin/f32_chain_probe ) > $out/f32_chain_probe.txt
 PNN_PRECISION=0 ./tools/batch1_kernels.sh $out/b1_f32 8 16 32 64 > /dev/null 2>&1
 for w in 8 16 32 64; do cp $out/b1_f32/b1_w${w}_timeline.txt $out/batch1_w${w}_f32_timeline.txt 2>/dev/null; done
 rm -rf $out/b1_f32

@@ -2,8 +2,8 @@
 // workgroups of ANOTHER kernel share its CUs?  Stream A runs the ring GEMM, stream B a "canary" kernel whose workgroups
 // fill their LDS with a pattern, keep verifying it for a while and count mismatches; the GEMM output is compared with a
 // run on the idle chip.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icontext_adaptive_neural_network_based_prediction_amd/csrc tools/ring_cores.hip -o build_tmp/ring_cores
-//   ./build_tmp/ring_cores [M] [K] [N] [canary LDS KB] [canary threads]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icontext_adaptive_neural_network_based_prediction_amd/csrc tools/ring_cores.hip -o tools/_bin/ring_cores
+//   ./tools/_bin/ring_cores [M] [K] [N] [canary LDS KB] [canary threads]
 #include "pnn_gemm_ring.hip"
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 // Diagnostic (not part of the product): times tapgemm_ring_kernel on a synthetic FC-shaped problem and prints the
 // per-phase cycle sums of wave 0 (PNN_RING_DIAG stamps).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPNN_RING_DIAG -Icontext_adaptive_neural_network_based_prediction_amd/csrc tools/ring_prof.hip -o build_tmp/ring_prof
-//   ./build_tmp/ring_prof [M] [K] [N]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPNN_RING_DIAG -Icontext_adaptive_neural_network_based_prediction_amd/csrc tools/ring_prof.hip -o tools/_bin/ring_prof
+//   ./tools/_bin/ring_prof [M] [K] [N]
 #include "pnn_gemm_ring.hip"
 #include <cstdio>
 #include <cstdlib>
