@@ -57,9 +57,11 @@ int fail(pnn_ctx* c, int code, const char* fmt, ...)
 
 namespace {
 
-void cache_clear(pnn_ctx* c)
+void cache_clear(pnn_ctx* c)                          // (every option change / model load: cached predictions and captured launch chains go)
 {
     for (auto& t : c->cache) { t.clear(); t.shrink_to_fit(); }
+    for (auto& kv : c->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    c->graphs.clear();
 }
 
 }  // namespace
@@ -240,6 +242,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_SPIN_WAIT")) c->opt_spin_wait = atol(e);
     if (const char* e = getenv("PNN_FLAG_WAIT")) c->opt_flag_wait = atol(e);
     if (const char* e = getenv("PNN_WAIT_SLEEP")) c->opt_wait_sleep = atol(e);
+    if (const char* e = getenv("PNN_GRAPHS")) c->opt_graphs = atol(e);
     if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
@@ -334,6 +337,7 @@ void pnn_destroy(pnn_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    cache_clear(c);
     for (Model*& m : c->models) { free_model(m); m = nullptr; }
     for (DevBuf& b : c->ws) if (b.p) (void)hipFree(b.p);
     for (DevBuf& b : c->stage_in) if (b.p) (void)hipFree(b.p);
@@ -398,6 +402,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "spin_wait")) c->opt_spin_wait = value;
     else if (!strcmp(name, "flag_wait")) c->opt_flag_wait = value;
     else if (!strcmp(name, "wait_sleep")) c->opt_wait_sleep = value;
+    else if (!strcmp(name, "graphs")) c->opt_graphs = value;
     else if (!strcmp(name, "stream_priority")) {
         // the context's own stream (the host entry points run on it) at the device's greatest (< 0), default (0) or least (> 0) priority
         HIPCHK(c, hipSetDevice(c->device));
@@ -669,8 +674,9 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         float* p_out = (float*)(hp + 2 * kPinIn);
         int32_t* p_dst = (int32_t*)(hp + 2 * kPinIn + kPinOut);
         const long pa = m->is_fc ? 5 * w2 : 3 * w2;
+        bool inline_input = true;                      // (not in a captured chain: the argument block is part of the graph)
         auto pass = [&](long b0, long nb) {
-            c->host_input = m->is_fc ? above + b0 * pa : nullptr;   // small inputs ride in the first kernel's argument block
+            c->host_input = (m->is_fc && inline_input) ? above + b0 * pa : nullptr;   // small inputs ride in the first kernel's argument block
             const int r = run_net(c, m, (const float*)hp + b0 * pa, pa, (const float*)(hp + kPinIn) + b0 * 2 * w2, 2 * w2, nb, p_out + b0 * w2,
                                   (dst || slot) ? p_dst + b0 * w2 : nullptr, s);
             c->host_input = nullptr;
@@ -681,7 +687,47 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht0);
         c->done_want = c->opt_flag_wait != 0;
         c->done_armed = false;
-        rc = pass(0, n);
+        // The chain as a graph (pnn_ctx::GraphEntry): first call of a shape as ever (it sizes the workspaces), second call captured, then replays.
+        pnn_ctx::GraphEntry* ge = nullptr;
+        if (c->opt_graphs && n <= 64 && !c->opt_time_launches && !host_trace) ge = &c->graphs[std::make_tuple((const void*)m, n, (dst || slot) ? 1 : 0)];
+        bool replay = false;
+        if (ge && !ge->failed && !ge->exec && ge->uses >= 1) {
+            inline_input = false;
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = pass(0, n);                          // nothing runs: the launches are recorded
+                e = hipStreamEndCapture(s, &g);
+                if (rc == PNN_OK && e == hipSuccess && g) e = hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+            }
+            if (rc != PNN_OK || e != hipSuccess || !ge->exec) {   // this shape stays on plain launches
+                (void)hipGetLastError();
+                if (ge->exec) { (void)hipGraphExecDestroy(ge->exec); ge->exec = nullptr; }
+                ge->failed = true;
+                inline_input = true;
+                c->done_armed = false;
+            } else {
+                ge->armed = c->done_armed; ge->seq = c->done_seq;
+                ge->stat_gemm_launches = c->stat_gemm_launches; ge->stat_launches = c->stat_launches;
+                ge->stat_gemm_flops = c->stat_gemm_flops; ge->stat_gemm_flops_skipped = c->stat_gemm_flops_skipped;
+            }
+            rc = PNN_OK;
+        }
+        if (ge && ge->exec) {
+            if (ge->armed) __atomic_store_n(reinterpret_cast<unsigned*>(c->h_range) + 1, 0u, __ATOMIC_RELEASE);   // the number this chain raises may still stand there
+            HIPCHK(c, hipGraphLaunch(ge->exec, s));
+            c->done_armed = ge->armed; c->done_seq = ge->seq;
+            c->stat_gemm_launches = ge->stat_gemm_launches; c->stat_launches = ge->stat_launches;
+            c->stat_gemm_flops = ge->stat_gemm_flops; c->stat_gemm_flops_skipped = ge->stat_gemm_flops_skipped;
+            replay = true;
+        }
+        if (!replay) {
+            reset_stats(c);
+            rc = pass(0, n);
+            if (ge) ge->uses++;
+        }
+        inline_input = true;                          // (the range fallback's passes are plain launches)
         c->done_want = false;
         if (rc) return rc;
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht1);

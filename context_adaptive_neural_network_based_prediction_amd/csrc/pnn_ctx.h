@@ -11,6 +11,7 @@
 
 #include <functional>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,21 @@ struct pnn_ctx {
     long opt_cache_mb = 0;                            // 0 = off
     long cache_hits = 0, cache_misses = 0;
     char* h_pin = nullptr;                            // pinned, device-visible staging of the single-block host calls (zero-copy)
+    // The launch chain of a small host call as a hipGraph (option "graphs", on by default): a single-block call is 4 (FC) to 20 (conv
+    // 64x64) dependent launches that differ from call to call only in the bytes of the pinned staging -- the third call of a shape
+    // (model, blocks, which results) replays the chain the second one captured with ONE hipGraphLaunch: 4-9 us of host time instead of
+    // 3.4-4 us per launch (tools/corun_noise.hip: 11 dependent launches 37 -> 9 us inside the launch calls, 51 -> 34 us until complete),
+    // and one submission instead of 4-20 for the other streams' launches to contend with.  Same kernels, same arguments: same bits.
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        int uses = 0;                                 // calls of this shape so far (0: run and size the buffers, 1: capture, then replay)
+        bool failed = false, armed = false;
+        unsigned seq = 0;                             // the completion number its last kernel raises
+        int stat_gemm_launches = 0, stat_launches = 0;
+        double stat_gemm_flops = 0, stat_gemm_flops_skipped = 0;
+    };
+    std::map<std::tuple<const void*, int, int>, GraphEntry> graphs;
+    long opt_graphs = 1;
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_max_chunk = 0;
     // One per-output summation order at every batch size, on either arithmetic: a block's prediction does not depend on the batch it
@@ -156,7 +172,8 @@ struct pnn_ctx {
     // workgroup counter; done_want = this pass is the last of a host call that will spin on the flag, done_armed = its last
     // kernel took the signal (kernels that cannot -- the exact-f32 FC output layer -- leave it unset: the call then waits for the stream)
     unsigned* d_done = nullptr;
-    unsigned done_seq = 0;
+    unsigned done_seq = 0;                            // the sequence number the running / last pass raises
+    unsigned done_seq_alloc = 0;                      // numbers handed out so far (a replayed graph raises the number it was captured with)
     bool done_want = false, done_last_chunk = true, done_armed = false;
     long opt_flag_wait = 1;
     // The host thread of a small call spins on the completion flag for as long as the device works: 45-400 us of a CPU per call, and the
@@ -204,7 +221,8 @@ inline DoneSignal take_done_signal(pnn_ctx* c)
 {
     if (!c->done_want || !c->done_last_chunk || !c->d_done) return DoneSignal{nullptr, nullptr, 0, 0};
     c->done_armed = true;
-    return DoneSignal{c->d_done, reinterpret_cast<unsigned*>(c->h_range) + 1, ++c->done_seq, 0};
+    c->done_seq = ++c->done_seq_alloc;
+    return DoneSignal{c->d_done, reinterpret_cast<unsigned*>(c->h_range) + 1, c->done_seq, 0};
 }
 int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const std::function<bool(int)>& legal,
               const std::function<hipError_t(int)>& launch, hipStream_t s, int* cfg, float* best_us);

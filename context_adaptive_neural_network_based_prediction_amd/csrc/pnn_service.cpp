@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <poll.h>
 #include <sys/epoll.h>
+#include <sys/eventfd.h>
 #include <sys/prctl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -173,7 +174,7 @@ struct Server {
     // ~120 k requests/s -- 24 and 100 HM encoders on one server ran at the same 119 k and 123 k requests/s, and two server
     // PROCESSES on the same GPU finished the 100-picture campaign in 8.9 s instead of 12.9 (profiles/r03_hm_runs.txt).  A
     // connection belongs to one I/O thread for its life (dealt round-robin at accept; the thread's index sits in the low bits
-    // of the client ID), the per-width workers hand a reply to the owner's queue and wake it through its own pipe.
+    // of the client ID), the per-width workers hand a reply to the owner's queue and wake it through its own eventfd.
     static constexpr int kMaxIo = 8;
     int nio = 1;
     std::vector<Reply> done[kMaxIo];
@@ -182,7 +183,7 @@ struct Server {
     std::atomic<bool> quit_flag{false};
     struct Peer { int conns = 0, in_flight = 0; };
     std::map<int, Peer> peers;       // under `mu`
-    int wake_fd[kMaxIo][2];          // workers (and the listener) -> I/O thread t
+    int wake_fd[kMaxIo];             // workers (and the listener) -> I/O thread t: an eventfd (one write to raise, ONE read to clear -- a pipe took two)
     std::atomic<uint64_t> next_seq{1};
     std::atomic<long> accepted{0}, refused{0};
     long served = 0, calls = 0, largest = 0;
@@ -258,8 +259,8 @@ struct Server {
             std::lock_guard<std::mutex> lk(dmu[t]);
             for (auto& r : replies) if ((int)(r.id & 15) % nio == t) done[t].push_back(std::move(r));
         }
-        const char one = 1;
-        for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t][1], &one, 1);
+        const uint64_t one = 1;
+        for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t], &one, 8);
         std::lock_guard<std::mutex> lk(mu);
         served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
         ++calls_w[k]; served_w[k] += (long)n; busy_s[k] += busy; wait_s[k] += f.waited;
@@ -324,7 +325,7 @@ struct Server {
 
     // One I/O thread: its share of the connections (receive, queue for the workers, reply); thread 0 also owns the listener.
     // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was what
-    // bounded the server; event data = client ID (0: listener, 1: this thread's wake pipe).
+    // bounded the server; event data = client ID (0: listener, 1: this thread's wake eventfd).
     void io_loop(const int t, const int lfd, const int ep)
     {
         if (t > 0) { char nm[16]; snprintf(nm, sizeof nm, "pnn-io%d", t); prctl(PR_SET_NAME, nm, 0, 0, 0); }
@@ -463,11 +464,11 @@ struct Server {
                         fresh[to].push_back(cfd);
                         woke[to] = true;
                     }
-                    const char one = 1;
-                    for (int o = 0; o < nio; o++) if (woke[o]) (void)!write(wake_fd[o][1], &one, 1);
+                    const uint64_t one = 1;
+                    for (int o = 0; o < nio; o++) if (woke[o]) (void)!write(wake_fd[o], &one, 8);
                 } else if (id == 1) {                         // new connections from the listener, replies from the workers
-                    char buf[256];
-                    while (read(wake_fd[t][0], buf, sizeof buf) > 0) {}
+                    uint64_t raised;
+                    (void)!read(wake_fd[t], &raised, 8);
                     std::vector<Reply> ready;
                     std::vector<int> mine;
                     {
@@ -530,26 +531,24 @@ struct Server {
         int made = 0;
         bool ok = bind(lfd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) == 0 && listen(lfd, 512) == 0;
         for (; ok && made < nio; made++) {
-            wake_fd[made][0] = wake_fd[made][1] = -1;
+            wake_fd[made] = -1;
             eps[made] = -1;
-            if (pipe(wake_fd[made]) < 0) { ok = false; break; }
+            if ((wake_fd[made] = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC)) < 0) { ok = false; break; }
             eps[made] = epoll_create1(0);
-            if (eps[made] < 0) { close(wake_fd[made][0]); close(wake_fd[made][1]); ok = false; break; }
+            if (eps[made] < 0) { close(wake_fd[made]); ok = false; break; }
         }
         if (!ok) {
-            for (int t = 0; t < made; t++) { close(eps[t]); close(wake_fd[t][0]); close(wake_fd[t][1]); }
+            for (int t = 0; t < made; t++) { close(eps[t]); close(wake_fd[t]); }
             close(lfd);
             unlink(socket_path);
             return PNN_E_IO;
         }
         set_nonblocking(lfd);
         for (int t = 0; t < nio; t++) {
-            set_nonblocking(wake_fd[t][0]);
-            set_nonblocking(wake_fd[t][1]);
             epoll_event ev;
             memset(&ev, 0, sizeof ev);
             ev.events = EPOLLIN; ev.data.u64 = 1;
-            epoll_ctl(eps[t], EPOLL_CTL_ADD, wake_fd[t][0], &ev);
+            epoll_ctl(eps[t], EPOLL_CTL_ADD, wake_fd[t], &ev);
         }
         {
             epoll_event ev;
@@ -568,7 +567,7 @@ struct Server {
         for (int t = 0; t < nio; t++) for (int cfd : fresh[t]) close(cfd);   // dealt but never adopted
         for (int k = 0; k < nworkers; k++) { std::lock_guard<std::mutex> lk(qmu[k]); cv[k].notify_all(); }
         for (auto& th : threads) th.join();
-        for (int t = 0; t < nio; t++) { close(eps[t]); close(wake_fd[t][0]); close(wake_fd[t][1]); }
+        for (int t = 0; t < nio; t++) { close(eps[t]); close(wake_fd[t]); }
         close(lfd);
         unlink(socket_path);
         if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted.load(); }
@@ -653,6 +652,11 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             rc = pnn_create_empty(&ctxs[k][r], mean, device);
             if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
             if (rc == PNN_OK && !getenv("PNN_WAIT_SLEEP")) pnn_set_option(ctxs[k][r], "wait_sleep", 1);   // five workers that spin would hold five CPUs for the length of a campaign
+            // Captured launch chains (option "graphs") pay for a thread that calls the library alone; behind five workers the runtime's graph
+            // launches contend like its kernel launches do and move their cost to a runtime thread: configs[3], same box, 6.07 / 6.19 s
+            // without against 6.02 / 6.27 s with, service CPU 24.4 / 24.8 -> 25.1 / 27.7 s (workers - 2.4 s, runtime thread + 4.7 s), a
+            // 16x16 call 174 -> 196 us.  Off here.
+            if (rc == PNN_OK && !getenv("PNN_GRAPHS")) pnn_set_option(ctxs[k][r], "graphs", 0);
             // Stream priorities per width: PNN_SERVICE_PRIORITIES = five of h / n / l (default: all normal).  Streams of one priority
             // share the runtime's few hardware queues and two busy widths on one queue serialise -- with the two FC widths on high-priority
             // streams a conv 16x16 / 32x32 call takes 114 / 198 us instead of 180 / 258 inside a configs[3] campaign, but a 4x4 call 68

@@ -109,10 +109,14 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "wait_sleep"           0   1: the thread of a small host call sleeps through the predictable part of its wait (running mean per batch
  *                              size, minus a margin) and spins only for the rest: the batching service's workers set it (two thirds of
  *                              their CPU time was that spin); a stand-alone codec keeps 0
+ *   "graphs"               1   small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
+ *                              on its second call and replayed with one hipGraphLaunch afterwards -- same kernels, same arguments,
+ *                              same bits; a single-block call 1-8 us shorter for a thread that calls alone; the batching service's
+ *                              width workers turn it off (no gain beside four other launching threads)
  *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
  */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
-/* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_AUTOTUNE, PNN_RING, PNN_CONVIMG,
+/* Environment variables read at pnn_create* (same meaning as the options): PNN_PRECISION, PNN_GRAPHS, PNN_AUTOTUNE, PNN_RING, PNN_CONVIMG,
  * PNN_SMALL, PNN_F32_SMALL, PNN_F32_SMALL_TILES, PNN_CACHE_MB, PNN_FC_OUT, PNN_SPIN_WAIT, PNN_FLAG_WAIT, PNN_FUSE_FIRST, PNN_FUSE_GATHER,
  * PNN_FUSE_TAIL, PNN_FUSE_LAST, PNN_RING_PM, PNN_BRANCH_STREAMS, PNN_MAX_CHUNK, PNN_F32_CFG, PNN_F32_OVERLAP, PNN_F32_SEG_MODE,
  * PNN_F32_PERSIST.  Diagnostics: PNN_DEBUG (kernel choice of every GEMM launch on stderr), PNN_DEBUG_TUNE, PNN_PROFILE (synchronous

@@ -427,6 +427,33 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
     net.close()
 
 
+@pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (16, False), (32, False), (64, False)])
+def test_small_calls_replayed_as_graphs(pnn, precision, w, is_fc):
+    """Option "graphs" (default on): the launch chain of a small host call is captured on the second call of a shape (model, blocks,
+    result kinds) and replayed afterwards with one hipGraphLaunch.  Every call -- first (plain launches), second (captured), later
+    (replayed), with new inputs each time and shapes interleaved -- gives the bits of the same call with the option off; an option
+    change drops the captured chains."""
+    params = util.make_params(w, is_fc, 811, out_gain=util.out_gain(w, is_fc))
+    net = pnn.PredictionNeuralNetwork(8, w, is_fc, params=params)
+    net.set_option("graphs", 0)
+    calls = []
+    for i, n in enumerate((1, 1, 3, 1, 3, 1, 3, 2, 1, 3, 7, 1)):
+        above, left = util.make_contexts(w, n, 820 + i)
+        ins = (util.flatten_fc(above, left),) if is_fc else (above, left)
+        calls.append((ins, net.predict(*ins).copy(), net.predict_pel(*ins).copy()))
+    launches_plain = net.last_call_stats()["launches"]
+    net.set_option("graphs", 1)
+    for rnd in range(2):
+        for i, (ins, want_f, want_p) in enumerate(calls):
+            assert np.array_equal(net.predict(*ins), want_f), "float result, call %d of round %d" % (i, rnd)
+            assert np.array_equal(net.predict_pel(*ins), want_p), "Pel result, call %d of round %d" % (i, rnd)
+    assert net.last_call_stats()["launches"] == launches_plain        # a replayed call reports the chain it stands for
+    net.set_option("cache_mb", 0)                                      # any option change: the chains are captured anew
+    for ins, want_f, want_p in calls[:6]:
+        assert np.array_equal(net.predict_pel(*ins), want_p)
+    net.close()
+
+
 def test_arithmetic_tag_names_the_summation_order(pnn):
     """pnn_arithmetic_tag: one string per arithmetic, the same for every context and width of a library build; it changes with the
     "precision" option and with nothing else -- what an encoder and its decoder compare once at start-up."""

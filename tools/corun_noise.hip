@@ -108,6 +108,41 @@ int main(int argc, char** argv)
         printf("4 dependent empty kernels + wait (%s): %5.1f us inside the launch calls, %5.1f us until complete, beside %d threads of empty kernels\n",
                api ? "hipModuleLaunchKernel" : "hipLaunchKernelGGL   ", in_launch / calls * 1e6, total / calls * 1e6, nthr);
     }
+    // The same chain as ONE hipGraphLaunch (captured once): does the runtime hand a whole chain to the queue cheaper than kernel by kernel,
+    // and does it suffer less from the other threads' launches?  11 dependent kernels = a single-block call of the 16x16 net.
+    for (int nk : {4, 11}) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipStreamBeginCapture(ps, hipStreamCaptureModeThreadLocal);
+        for (int i = 0; i < nk; i++) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, ps, (int*)nullptr);
+        if (hipStreamEndCapture(ps, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { printf("graph capture failed\n"); break; }
+        for (int use_graph = 0; use_graph < 2; use_graph++)
+        for (int nthr : {0, 4}) {
+            std::atomic<bool> stop{false};
+            std::vector<std::thread> noise;
+            std::vector<hipStream_t> extra;
+            for (int i = 0; i < nthr; i++) { hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking); extra.push_back(s2);
+                noise.emplace_back([&stop, s2] { while (!stop.load()) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s2, (int*)nullptr); hipStreamSynchronize(s2); }); }
+            double in_launch = 0, total = 0; long calls = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds * 0.5) {
+                const auto a = std::chrono::steady_clock::now();
+                if (use_graph) hipGraphLaunch(exec, ps);
+                else for (int i = 0; i < nk; i++) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, ps, (int*)nullptr);
+                const auto b = std::chrono::steady_clock::now();
+                while (hipStreamQuery(ps) == hipErrorNotReady) {}
+                const auto c = std::chrono::steady_clock::now();
+                in_launch += std::chrono::duration<double>(b - a).count(); total += std::chrono::duration<double>(c - a).count(); calls++;
+            }
+            stop = true;
+            for (auto& t : noise) t.join();
+            for (hipStream_t s2 : extra) hipStreamDestroy(s2);
+            printf("%2d dependent empty kernels (%s): %5.1f us inside the launch call(s), %5.1f us until complete, beside %d threads of empty kernels\n",
+                   nk, use_graph ? "one hipGraphLaunch   " : "kernel by kernel     ", in_launch / calls * 1e6, total / calls * 1e6, nthr);
+        }
+        hipGraphExecDestroy(exec);
+        hipGraphDestroy(graph);
+    }
     pnn_destroy(ctx);
     return 0;
 }
