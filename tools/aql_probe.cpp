@@ -75,8 +75,18 @@ int main(int argc, char** argv)
     };
     if (get("aql_empty.kd", k_empty) || get("aql_step.kd", k_step) || get("aql_busy.kd", k_busy)) return 1;
     printf("# kernarg segment: aql_empty %u bytes, aql_step %u bytes\n", k_empty.kernarg, k_step.kernarg);
+    // variants: AQL_QUEUE_MULTI=1 -> HSA_QUEUE_TYPE_MULTI; AQL_QUEUE_PRIORITY=high|low -> hsa_amd_queue_set_priority
+    static const hsa_queue_type32_t qtype = getenv("AQL_QUEUE_MULTI") ? HSA_QUEUE_TYPE_MULTI : HSA_QUEUE_TYPE_SINGLE;
+    static const char* qprio = getenv("AQL_QUEUE_PRIORITY");
+    auto tune_queue = [](hsa_queue_t* qq) {
+        if (qprio) hsa_amd_queue_set_priority(qq, !strcmp(qprio, "high") ? HSA_AMD_QUEUE_PRIORITY_HIGH : !strcmp(qprio, "low") ? HSA_AMD_QUEUE_PRIORITY_LOW : HSA_AMD_QUEUE_PRIORITY_NORMAL);
+    };
+    static const bool fence_none = getenv("AQL_FENCE_NONE") != nullptr;   // variant: no acquire / release fence on any packet but the chain's last (NOT a correct chain: a measurement of what the fences cost)
+    printf("# fences of the packets inside a chain: %s\n", fence_none ? "none" : "agent scope");
+    printf("# queues: %s, priority %s\n", qtype == HSA_QUEUE_TYPE_MULTI ? "HSA_QUEUE_TYPE_MULTI" : "HSA_QUEUE_TYPE_SINGLE", qprio ? qprio : "default");
     hsa_queue_t* q = nullptr;
-    HSACHK(hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+    HSACHK(hsa_queue_create(g_gpu, 1024, qtype, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+    tune_queue(q);
     char* kernarg = nullptr;
     HSACHK(hsa_amd_memory_pool_allocate(g_kernarg_pool, 64 * 1024, 0, (void**)&kernarg));
     HSACHK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, kernarg));
@@ -97,8 +107,8 @@ int main(int argc, char** argv)
         p->kernel_object = k.object; p->kernarg_address = ka; p->reserved2 = 0;
         p->completion_signal = last ? done : hsa_signal_t{0};
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                           (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-                                           ((last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+                                           ((fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                           ((last ? HSA_FENCE_SCOPE_SYSTEM : fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         __atomic_store_n((uint32_t*)p, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
         return idx;
@@ -173,7 +183,8 @@ int main(int argc, char** argv)
                 return;
             }
             hsa_queue_t* q2 = nullptr; hsa_signal_t d2; char* ka2 = nullptr;
-            if (hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q2) != HSA_STATUS_SUCCESS) return;
+            if (hsa_queue_create(g_gpu, 1024, qtype, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q2) != HSA_STATUS_SUCCESS) return;
+            tune_queue(q2);
             hsa_signal_create(1, 0, nullptr, &d2);
             hsa_amd_memory_pool_allocate(g_kernarg_pool, 4096, 0, (void**)&ka2);
             hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ka2);
@@ -191,8 +202,8 @@ int main(int argc, char** argv)
                     p->kernel_object = k_busy.object; p->kernarg_address = ka2 + 256 * i; p->reserved2 = 0;
                     p->completion_signal = i == 3 ? d2 : hsa_signal_t{0};
                     const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                                       (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-                                                       ((i == 3 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+                                                       ((fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                                       ((i == 3 ? HSA_FENCE_SCOPE_SYSTEM : fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
                     __atomic_store_n((uint32_t*)p, (uint32_t)header | ((uint32_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16), __ATOMIC_RELEASE);
                 }
                 hsa_signal_store_screlease(q2->doorbell_signal, (hsa_signal_value_t)idx);
