@@ -253,6 +253,10 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the completion counter failed");
     }
+    if (hipMalloc((void**)&c->d_seg_cnt, 2 * pnn_ctx::kSegCntTiles * 4) != hipSuccess || hipMemset(c->d_seg_cnt, 0, 2 * pnn_ctx::kSegCntTiles * 4) != hipSuccess) {
+        pnn_destroy(c);
+        return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the K-segment counters failed");
+    }
     if (hipMalloc(&c->d_zero, 4096) != hipSuccess || hipMemset(c->d_zero, 0, 4096) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the zero page failed");
@@ -346,6 +350,7 @@ void pnn_destroy(pnn_ctx* c)
     for (auto& b : c->seg_part) if (b.p) (void)hipFree(b.p);
     if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_done) (void)hipFree(c->d_done);
+    if (c->d_seg_cnt) (void)hipFree(c->d_seg_cnt);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -428,6 +433,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "f32_overlap")) c->opt_f32_overlap = value;
     else if (!strcmp(name, "f32_small")) c->opt_f32_small = value;
     else if (!strcmp(name, "fc_out_f32")) c->opt_fc_out_f32 = value;
+    else if (!strcmp(name, "seg_fold")) c->opt_seg_fold = value;
     else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;
     else if (!strcmp(name, "ws_cap_mb")) c->ws_cap_bytes = (size_t)value << 20;
     else return fail(c, PNN_E_ARG, "unknown option %s", name);

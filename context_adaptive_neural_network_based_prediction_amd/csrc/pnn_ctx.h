@@ -129,6 +129,11 @@ struct pnn_ctx {
     // fmaf chain on the 16x16x4 instruction (10 instead of 32 cycles per k of the dependent chain), pnn_gemm_f32_small.hip
     long opt_f32_small = 1;
     long opt_fc_out_f32 = 1;                          // 1: exact-f32 FC passes of <= 512 blocks run the output layer's K segments and their reduction as ONE launch
+    // 1: the K segments of a layer that runs on the small exact-f32 kernel are added up inside its launch (the last workgroup of a tile
+    // to arrive, see tapgemm_f32_small_body) instead of by a seg_reduce launch behind it: the same additions in the same order
+    long opt_seg_fold = 1;
+    unsigned* d_seg_cnt = nullptr;                    // the tiles' arrival counters: [2 branches][kSegCntTiles], zero between launches
+    static constexpr int kSegCntTiles = 2048;
     long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles
     long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for

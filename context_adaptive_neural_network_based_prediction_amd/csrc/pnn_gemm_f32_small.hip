@@ -64,7 +64,7 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 
 // INL: the f32 input rows of an FC net's first layer travel INSIDE the kernel-argument block (see tapgemm_small_inline_kernel).
 template <bool INL>
-__device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz)
+__device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz, const int gy)
 {
     constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, LA = kF32SmallLA, D = kF32SmallD;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
@@ -238,12 +238,54 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     }
 #endif
     // ---- epilogue: lane (q, l15) holds row m = l15, channels n0 + 4 q + r ----------------------------------------------------
-    if (!rowok) return;
     const int n = n0 + 4 * q;
-    if (n >= p.Cout) return;
     const int py = p.py[cls], px = p.px[cls];
     const int oy = ri * p.os + py, ox = rj * p.os + px;
     const size_t obase = (((size_t)rb * p.OH + oy) * p.OW + ox) * p.Cout;
+    if (!INL && nseg > 1 && p.seg_cnt) {
+        // K segments added up inside the launch.  This wave's raw sums go to plane `seg` WRITTEN THROUGH to memory (the tile's other
+        // segments ran on other XCDs, whose L2s this XCD's does not see); it then counts itself on the tile's counter (memory-side atomic),
+        // and the LAST of the tile's nseg waves to arrive reads all planes back PAST the caches, adds them in plane order -- the order of
+        // seg_reduce_kernel, whichever wave happens to be last --, applies bias and activation and stores the layer's output.  One launch
+        // instead of two per segmented layer of a single-block call (32x32 net: 6, 64x64 net: 9).
+        // The planes are TILE-major here ([segment][tile][lane] x 16 bytes, 1 KiB per (segment, tile), the wave's lanes side by side):
+        // every 128-byte line of them is written by ONE workgroup and read by one, so no XCD's L2 ever holds a line that another
+        // workgroup completes later (in the [pixel][channel] layout two 16-channel tiles share a line).
+        const bool ok = rowok && n < p.Cout;
+        const int gxs = (p.M + 15) >> 4, tile = (cls * gy + by) * gxs + bx;
+        const size_t plane_floats = (size_t)p.ncls * gy * gxs * 256;
+        float* const plane0 = p.Y + (size_t)tile * 256 + lane * 4;
+        store16_through(reinterpret_cast<f32x4*>(plane0 + (size_t)seg * plane_floats), acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // acknowledged: the plane's bytes are in memory
+        unsigned* const cnt = p.seg_cnt + tile;
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        if (old != (unsigned)nseg - 1u) return;
+        if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        if (!ok) return;
+        // (GemmLayer::nseg <= 8) all planes requested, one wait, then the additions in plane order.  Loads and wait are ONE asm block:
+        // the compiler must not touch a destination register (a copy, a select) while its load is in flight.  Planes past nseg: plane 0 again, unused.
+        f32x4 pl[8];
+        const f32x4* pa[8];
+#pragma unroll
+        for (int sgm = 0; sgm < 8; sgm++) pa[sgm] = reinterpret_cast<const f32x4*>(plane0 + (size_t)(sgm < nseg ? sgm : 0) * plane_floats);
+        asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\tglobal_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %3, %11, off sc0 sc1\n\tglobal_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(pl[0]), "=&v"(pl[1]), "=&v"(pl[2]), "=&v"(pl[3]), "=&v"(pl[4]), "=&v"(pl[5]), "=&v"(pl[6]), "=&v"(pl[7])
+                     : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7])
+                     : "memory");
+        f32x4 t = pl[0];
+#pragma unroll
+        for (int sgm = 1; sgm < 8; sgm++) if (sgm < nseg) t += pl[sgm];
+        f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+        *reinterpret_cast<f32x4*>(p.seg_Y + obase + n) = v;
+        return;
+    }
+    if (!rowok) return;
+    if (n >= p.Cout) return;
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
@@ -256,14 +298,14 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_kernel(const F32SmallAr
     touch_kernargs<sizeof(F32SmallArgs)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_f32_small_body<false>(k->p, blockIdx.x, blockIdx.y, blockIdx.z);
+    tapgemm_f32_small_body<false>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 __global__ __launch_bounds__(256) void tapgemm_f32_small_inline_kernel(const F32SmallArgsInline args)
 {
     touch_kernargs<sizeof(TapGemmParams)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) F32SmallArgsInline*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_f32_small_body<true>(k->p, blockIdx.x, blockIdx.y, blockIdx.z);
+    tapgemm_f32_small_body<true>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 
 // Two independent layers in ONE launch (the same layer of the two branches of a convolutional net), see tapgemm_small_pair_kernel.
@@ -279,7 +321,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32Sm
     const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
     const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
     const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
-    tapgemm_f32_small_body<false>(*p, r % gx, r / gx, bz);
+    tapgemm_f32_small_body<false>(*p, r % gx, r / gx, bz, gy);
 }
 
 size_t tapgemm_f32_small_lds_bytes() { return (size_t)kF32SmallD * kF32SmallCS * 128 * 16; }

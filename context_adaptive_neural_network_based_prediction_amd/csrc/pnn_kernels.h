@@ -49,6 +49,10 @@ struct TapGemmParams {
     union {
         struct { const float* W2p; int Npad2; int K2chunks; float* part; };
         struct { const float* W1; float* Y1; int32_t* Yi1; };
+        // tapgemm_f32_small_kernel, a K-segmented layer (nseg > 1) whose planes are added up INSIDE the launch (seg_cnt != NULL): the
+        // workgroup that is the last of a tile's nseg to arrive (a counter per tile in seg_cnt, zero between launches) adds the planes in
+        // order, + bias, activation, and stores the layer's real output seg_Y; `bias` and `act` are then the layer's own, Y the planes
+        struct { unsigned* seg_cnt; float* seg_Y; };
     };
     // convimg kernel, fused FIRST convolution of a branch (Cin = 1 -> this layer's Cin channels, stride s0, kernel k0 x k0,
     // SAME padding with pad0 before, LeakyReLU): X0 != NULL makes the kernel compute its input maps from the raw f32

@@ -63,6 +63,17 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
         TapGemmParams ps = p;
         ps.Wp = L.d_w_ch;                             // the same weights in the small kernel's lane order
+        // K segments: added up by the launch itself (the tile's last workgroup to arrive) when the tiles have counters
+        const long seg_tiles = nseg > 1 ? tapgemm_f32_small_tiles(p) / nseg : 0;
+        const bool fold = nseg > 1 && c->opt_seg_fold && c->d_seg_cnt && seg_tiles <= pnn_ctx::kSegCntTiles && !c->opt_time_launches;
+        if (fold) {
+            ps.seg_cnt = c->d_seg_cnt + ((c->side_stream && s == c->side_stream) ? pnn_ctx::kSegCntTiles : 0);
+            ps.seg_Y = Y; ps.bias = L.d_bias; ps.act = L.proto.act;
+            DevBuf& sb = c->seg_part[(c->side_stream && s == c->side_stream) ? 1 : 0];   // tile-major planes: 1 KiB per (segment, tile)
+            int rrc;
+            if ((rrc = dev_reserve(c, sb, (size_t)nseg * seg_tiles * 1024))) return rrc;
+            ps.Y = (float*)sb.p;
+        }
         if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d nseg=%d -> f32 small kernel (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, p.ncls, nseg, tapgemm_f32_small_tiles(p));
         if (profile || c->opt_time_launches) {
             pnn_ctx::LaunchRec r;
@@ -87,7 +98,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         } else {
             HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows));
         }
-        if (nseg > 1) {
+        if (nseg > 1 && !fold) {
             HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
             c->stat_launches++;
         }
@@ -752,6 +763,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             TapGemmParams q[2];
             float* dst[2];
             size_t out_floats[2];
+            bool folded[2] = {false, false};
             for (int br = 0; br < 2; br++) {
                 const GemmLayer& L = m->branch[br][i];
                 q[br] = L.proto;
@@ -766,6 +778,13 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
                     if ((rc = dev_reserve(c, sb, (size_t)L.nseg * out_floats[br] * 4))) return rc;
                     if (out_floats[br] >= 0xffffffffull) return fail(c, PNN_E_ARG, "batch too large for one pass");
                     q[br].Y = (float*)sb.p; q[br].bias = (const float*)c->d_zero; q[br].act = 0; q[br].nseg = L.nseg; q[br].seg_stride = (unsigned)out_floats[br];
+                    folded[br] = c->opt_seg_fold && c->d_seg_cnt && tapgemm_f32_small_tiles(q[br]) / L.nseg <= pnn_ctx::kSegCntTiles;
+                    if (folded[br]) {                 // ... or the launch adds the planes up itself (tapgemm_f32_small_body; tile-major planes)
+                        if ((rc = dev_reserve(c, sb, (size_t)tapgemm_f32_small_tiles(q[br]) * 1024))) return rc;
+                        q[br].Y = (float*)sb.p;
+                        q[br].seg_cnt = c->d_seg_cnt + br * pnn_ctx::kSegCntTiles;
+                        q[br].seg_Y = dst[br]; q[br].bias = L.d_bias; q[br].act = L.proto.act;
+                    }
                 }
                 c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
             }
@@ -775,7 +794,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             c->stat_gemm_launches++; c->stat_launches++;
             for (int br = 0; br < 2; br++) {
                 const GemmLayer& L = m->branch[br][i];
-                if (L.nseg <= 1) continue;
+                if (L.nseg <= 1 || folded[br]) continue;
                 HIPCHK(c, launch_seg_reduce(q[br].Y, L.nseg, out_floats[br], q[br].Cout, L.d_bias, L.proto.act, dst[br], s));
                 c->stat_launches++;
             }

@@ -109,6 +109,10 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "wait_sleep"           0   1: the thread of a small host call sleeps through the predictable part of its wait (running mean per batch
  *                              size, minus a margin) and spins only for the rest: the batching service's workers set it (two thirds of
  *                              their CPU time was that spin); a stand-alone codec keeps 0
+ *   "seg_fold"             1   exact f32, small calls: the K segments of a deep layer (32x32 / 64x64 nets) are added up inside the
+ *                              layer's launch by the last workgroup of each tile to arrive (planes written through, read back past
+ *                              the caches, added in plane order) instead of by a reduction launch behind it: 17 -> 11 / 20 -> 11
+ *                              launches per single-block call, the same bits
  *   "graphs"               1   small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
  *                              on its second call and replayed with one hipGraphLaunch afterwards -- same kernels, same arguments,
  *                              same bits; a single-block call 1-8 us shorter for a thread that calls alone; the batching service's

@@ -416,6 +416,16 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
             if m <= n:
                 assert np.array_equal(run(above[n - m:], left[n - m:]), want[n - m:]), "%d blocks, f32_small_max_tiles = %d" % (m, limit)
     pel = net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))
+    net.set_option("f32_small_max_tiles", 1024)
+    assert np.array_equal(run(above[:1], left[:1])[0], want[0])
+    launches = net.last_call_stats()["launches"]
+    net.set_option("seg_fold", 0)                                    # K-segmented layers (32x32 / 64x64 nets): planes + seg_reduce launch instead of the in-launch sum
+    assert np.array_equal(run(above, left), want)
+    assert np.array_equal(run(above[:1], left[:1])[0], want[0])
+    assert net.last_call_stats()["launches"] == launches + ({32: 6, 64: 9}.get(w, 0) if not is_fc else 0)   # what the in-launch sum saves per single-block call
+    net.set_option("seg_fold", 1)
+    for _ in range(3):                                               # the tiles' counters go back to zero: launch after launch
+        assert np.array_equal(run(above[:1], left[:1])[0], want[0])
     net.set_option("fc_out_f32", 0)                                  # FC: the output layer's K segments and their reduction as two launches
     assert np.array_equal(run(above, left), want)
     assert np.array_equal(net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left))), pel)
