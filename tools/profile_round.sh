@@ -40,11 +40,22 @@ python3 tools/f32_sweep.py fc8 conv16 fc4 conv32 conv64 > $out/f32_tile_sweep.tx
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 cp bench_detail.json $out/bench_default_detail.json
 # round 5: the single-block path on the reference's arithmetic, the host-array entry points, the width workers side by side
-( echo "tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
+( echo "# tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait); the library's defaults (option graphs = 1: captured launch chains)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids
+  echo "# the same with PNN_GRAPHS=0 (plain launches)"; PNN_GRAPHS=0 python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
 ( echo "# tools/host_rate.py on one MI355X: the batched HOST-array entry points (pnn_predict_pel: host arrays in, int32 blocks out, one synchronous call per batch)"; python3 tools/host_rate.py fc8 conv16 fc4 conv32 conv64 2>&1 | grep -v amdgpu.ids ) > $out/host_rate.txt
 ( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
 [ -x tools/_bin/f32_chain_probe ] && ( echo "# tools/f32_chain_probe.hip: one wave, one dependent accumulation chain per instruction form (cycles by s_memtime)"; ./tools/_bin/f32_chain_probe ) > $out/f32_chain_probe.txt
-PNN_PRECISION=0 ./tools/batch1_kernels.sh $out/b1_f32 8 16 32 64 > /dev/null 2>&1
+[ -x tools/_bin/corun_noise ] && python3 - > $out/corun_noise.txt 2>/dev/null <<'PY'
+import os, subprocess, sys, tempfile
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools", "hm"))
+import run_hm
+with tempfile.TemporaryDirectory() as d:
+    table, _ = run_hm.make_models(os.path.join(d, "models"))
+    print("# tools/corun_noise.hip (one MI355X box; FC 4x4 model of the campaigns, seeded random init)")
+    print(subprocess.run(["timeout", "120", "./tools/_bin/corun_noise", table, "1.0"], capture_output=True, text=True).stdout)
+PY
+[ -x tools/_bin/aql_probe ] && ( echo "# tools/aql_probe.cpp (one MI355X box)"; timeout 90 ./tools/_bin/aql_probe tools/_bin/aql_probe.hsaco 0.5 ) > $out/aql_probe.txt 2>&1
+PNN_PRECISION=0 PNN_GRAPHS=0 ./tools/batch1_kernels.sh $out/b1_f32 8 16 32 64 > /dev/null 2>&1
 for w in 8 16 32 64; do cp $out/b1_f32/b1_w${w}_timeline.txt $out/batch1_w${w}_f32_timeline.txt 2>/dev/null; done
 rm -rf $out/b1_f32
 rm -f $out/*_trace.log $out/*_pmc_p*.log
