@@ -152,7 +152,7 @@ struct Server {
     pnn_service_backend backend;
     static constexpr int kMaxRep = 4;
     void* users[5][kMaxRep];       // backend handle of worker k, replica r
-    int nrep = 1;                    // replicas per worker queue (pnn_service_run_table: contexts per width, PNN_SERVICE_REPLICAS)
+    int nrep[5] = {1, 1, 1, 1, 1};   // replicas per worker queue (pnn_service_run_table: contexts per width, PNN_SERVICE_REPLICAS)
     int nworkers;                    // 1: one worker serves every width (a single context is not shared between threads); 5: one per width
     int max_batch, window_us;
     volatile int* stop;
@@ -558,7 +558,7 @@ struct Server {
         }
         std::vector<std::thread> threads;
         for (int k = 0; k < nworkers; k++)
-            for (int r = 0; r < nrep; r++) threads.emplace_back([this, k, r] { worker(k, r); });
+            for (int r = 0; r < nrep[k]; r++) threads.emplace_back([this, k, r] { worker(k, r); });
         std::vector<std::thread> io;
         for (int t = 1; t < nio; t++) io.emplace_back([this, t, lfd, &eps] { io_loop(t, lfd, eps[t]); });
         io_loop(0, lfd, eps[0]);                     // the calling thread: listener + its share of the connections
@@ -634,8 +634,11 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     std::string dir(model_table_path);
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    int nrep = 1;
-    if (const char* e = getenv("PNN_SERVICE_REPLICAS")) nrep = std::max(1, std::min(Server::kMaxRep, atoi(e)));
+    int nrep[5] = {1, 1, 1, 1, 1};                   // PNN_SERVICE_REPLICAS = "R" (every width) or "R4,R8,R16,R32,R64"
+    if (const char* e = getenv("PNN_SERVICE_REPLICAS")) {
+        int v[5], got = sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+        for (int k = 0; k < 5; k++) nrep[k] = std::max(1, std::min(Server::kMaxRep, got == 5 ? v[k] : got >= 1 ? v[0] : 1));
+    }
     pnn_ctx* ctxs[5][Server::kMaxRep] = {};
     static const int kWidths[5] = {4, 8, 16, 32, 64};
     int rc = PNN_OK;
@@ -648,7 +651,7 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             FILE* f = fopen((dir + "/" + p).c_str(), "rb");
             if (f) { fclose(f); p = dir + "/" + p; }
         }
-        for (int r = 0; r < nrep && rc == PNN_OK; r++) {
+        for (int r = 0; r < nrep[k] && rc == PNN_OK; r++) {
             rc = pnn_create_empty(&ctxs[k][r], mean, device);
             if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
             if (rc == PNN_OK && !getenv("PNN_WAIT_SLEEP")) pnn_set_option(ctxs[k][r], "wait_sleep", 1);   // five workers that spin would hold five CPUs for the length of a campaign
@@ -671,10 +674,10 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     }
     if (rc == PNN_OK) {
         Server sv;
-        sv.backend = ctx_backend; sv.nworkers = 5; sv.nrep = nrep; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
+        sv.backend = ctx_backend; sv.nworkers = 5; for (int k = 0; k < 5; k++) sv.nrep[k] = nrep[k]; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
         sv.nio = 4;                                  // socket threads (PNN_SERVICE_IO_THREADS overrides)
         for (int k = 0; k < 5; k++) {
-            for (int r = 0; r < sv.nrep; r++) sv.users[k][r] = ctxs[k][r];
+            for (int r = 0; r < sv.nrep[k]; r++) sv.users[k][r] = ctxs[k][r];
             int is_fc = 0;
             sv.kind[k] = pnn_model_info(ctxs[k][0], kWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
         }
