@@ -624,6 +624,8 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     // ~45 us whatever its batch), measured, and left OFF: with 2 / 3 replicas a call takes 61 / 81 us instead of 43 (ten or fifteen host
     // threads launching tiny kernels contend in the runtime and on the device's queues) and the campaign 5.68 / 6.22 s instead of 5.12
     // (configs[4]: 6.97 / 8.07 instead of 5.69); same bitstreams in every case (a block's prediction does not depend on its batch).
+    // Round 5, float32, replicas for the busiest widths only ("2,1,1,1,1" / "2,2,1,1,1"): configs[3] 6.76 / 6.69 and 6.52 / 6.38 s against
+    // 6.25 / 5.89 s on the same box -- a 4x4 call 67-80 us instead of 52, and the requests of the other widths wait longer.
     int widths[64], pairs[64], chans[64];
     const char* paths[64];
     const int n = pnn_parse_model_table(model_table_path, widths, pairs, chans, paths, 64);
