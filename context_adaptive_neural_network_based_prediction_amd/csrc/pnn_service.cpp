@@ -151,7 +151,8 @@ namespace {
 struct Server {
     pnn_service_backend backend;
     static constexpr int kMaxRep = 4;
-    void* users[5][kMaxRep];       // backend handle of worker k, replica r
+    void* users[5][kMaxRep];       // backend handle for width index i (4, 8, 16, 32, 64), replica r
+    int group[5] = {0, 1, 2, 3, 4};  // worker thread that serves width index i (nworkers == 5; PNN_SERVICE_GROUPS folds widths onto fewer threads)
     int nrep[5] = {1, 1, 1, 1, 1};   // replicas per worker queue (pnn_service_run_table: contexts per width, PNN_SERVICE_REPLICAS)
     int nworkers;                    // 1: one worker serves every width (a single context is not shared between threads); 5: one per width
     int max_batch, window_us;
@@ -196,7 +197,7 @@ struct Server {
 
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
     static int kServiceWidthsOf(int k) { return 4 << k; }
-    int worker_of(int width) const { return nworkers == 1 ? 0 : widx(width); }
+    int worker_of(int width) const { return nworkers == 1 ? 0 : group[widx(width)]; }
 
     // One batch on its way through a worker: the requests and their inputs stacked.
     struct Flight {
@@ -300,7 +301,7 @@ struct Server {
             if (f.any_pel) dst.resize(n * w2);
             if (f.any_f32) out.resize(n * w2);
             const auto tb0 = Clock::now();
-            const int rc = backend(users[nworkers == 1 ? 0 : k][r], w, f.above.data(), f.left.empty() ? nullptr : f.left.data(), (int)n, f.any_pel ? dst.data() : nullptr,
+            const int rc = backend(users[widx(w)][r], w, f.above.data(), f.left.empty() ? nullptr : f.left.data(), (int)n, f.any_pel ? dst.data() : nullptr,
                                    f.any_f32 ? out.data() : nullptr);
             reply(k, f, rc, dst.data(), out.data(), std::chrono::duration<double>(Clock::now() - tb0).count());
         }
@@ -676,6 +677,13 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
     }
     if (rc == PNN_OK) {
         Server sv;
+        // PNN_SERVICE_GROUPS = "g4,g8,g16,g32,g64" (worker thread 0..4 per width; default 0,1,2,3,4: one thread per width): fewer launching
+        // threads contend less, the widths that share a thread wait for each other
+        if (const char* e = getenv("PNN_SERVICE_GROUPS")) {
+            int v[5];
+            if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+                for (int k = 0; k < 5; k++) { sv.group[k] = std::max(0, std::min(4, v[k])); nrep[k] = 1; }
+        }
         sv.backend = ctx_backend; sv.nworkers = 5; for (int k = 0; k < 5; k++) sv.nrep[k] = nrep[k]; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
         sv.nio = 4;                                  // socket threads (PNN_SERVICE_IO_THREADS overrides)
         for (int k = 0; k < 5; k++) {
