@@ -54,6 +54,8 @@ SIGNATURES = {
     "pnn_arithmetic_tag": (ci, [vp, ctypes.c_char_p, ctypes.c_size_t]),
     "pnn_host_alloc": (ci, [ctypes.POINTER(vp), ctypes.c_size_t]),
     "pnn_host_free": (None, [vp]),
+    "pnn_streams_on_distinct_queues": (ci, [ctypes.POINTER(vp), ci]),
+    "pnn_streams_release": (None, [ctypes.POINTER(vp), ci]),
     "pnn_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "pnn_predict_fc": (ci, [vp, ci, f32p, ci, f32p]),
     "pnn_predict_conv": (ci, [vp, ci, f32p, f32p, ci, f32p]),

@@ -356,7 +356,7 @@ void pnn_destroy(pnn_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_range) (void)hipHostFree(c->h_range);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->stream_owned) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -416,8 +416,16 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
         const int pr = value < 0 ? greatest : value > 0 ? least : (least + greatest) / 2;
         hipStream_t ns = nullptr;
         HIPCHK(c, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
-        if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-        c->stream = ns;
+        if (c->stream) { (void)hipStreamSynchronize(c->stream); if (c->stream_owned) (void)hipStreamDestroy(c->stream); }
+        c->stream = ns; c->stream_owned = true;
+    }
+    else if (!strcmp(name, "stream")) {
+        // the host entry points run on the caller's stream (a hipStream_t passed as the value; the caller keeps and destroys it) --
+        // what pnn_streams_on_distinct_queues is for
+        if (!value) return fail(c, PNN_E_ARG, "stream = NULL");
+        HIPCHK(c, hipSetDevice(c->device));
+        if (c->stream) { (void)hipStreamSynchronize(c->stream); if (c->stream_owned) (void)hipStreamDestroy(c->stream); }
+        c->stream = reinterpret_cast<hipStream_t>(value); c->stream_owned = false;
     }
     else if (!strcmp(name, "fuse_last")) c->opt_fuse_last = value;
     else if (!strcmp(name, "f32_seg_mode")) { c->opt_f32_seg_mode = value; c->tuned.clear(); c->tune_gen++; }
@@ -802,6 +810,34 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     HIPCHK(c, hipStreamSynchronize(s));
     if (slot) { slot->hash = hash; slot->valid = true; }
     return PNN_OK;
+}
+
+// `want` streams of the current device that sit on `want` DIFFERENT hardware queues (see probe_queue_shared, pnn_small.hip): streams are
+// created until enough pairwise-separate ones exist (at most 16 tries), the others are destroyed again.  Returns how many were found
+// (< want when the runtime has fewer queues); the caller hands them to contexts (option "stream") and releases them afterwards.
+int pnn_streams_on_distinct_queues(void** out, int want)
+{
+    if (!out || want < 1 || want > 8) return PNN_E_ARG;
+    std::vector<hipStream_t> keep, drop;
+    for (int tries = 0; tries < 16 && (int)keep.size() < want; tries++) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        bool clash = false;
+        for (hipStream_t k : keep) {
+            bool shared = false;
+            if (probe_queue_shared(k, s, &shared) != hipSuccess) { clash = true; break; }
+            if (shared) { clash = true; break; }
+        }
+        (clash ? drop : keep).push_back(s);
+    }
+    for (hipStream_t s : drop) (void)hipStreamDestroy(s);
+    for (size_t i = 0; i < keep.size(); i++) out[i] = keep[i];
+    return (int)keep.size();
+}
+
+void pnn_streams_release(void** streams, int n)
+{
+    for (int i = 0; streams && i < n; i++) if (streams[i]) { (void)hipStreamSynchronize((hipStream_t)streams[i]); (void)hipStreamDestroy((hipStream_t)streams[i]); }
 }
 
 int pnn_host_alloc(void** out, size_t bytes)

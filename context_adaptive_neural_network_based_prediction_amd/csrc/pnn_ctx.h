@@ -88,6 +88,7 @@ struct pnn_ctx {
     pnn::DevBuf ws[6];                                     // P0, P1, F0, F1 (FC uses P0, P1); P2, P3: the left branch's own pair when the branches overlap
     // Small conv passes (the in-loop single-block calls): the two branches are independent chains of 4-5 launches that
     // each fill a fraction of the chip; the left branch runs on a side stream, forked and joined by events.
+    bool stream_owned = true;                         // false: adopted through the "stream" option (the caller destroys it)
     long opt_branch_streams = 1;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

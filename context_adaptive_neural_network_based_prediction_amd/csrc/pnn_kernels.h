@@ -26,6 +26,8 @@ inline void pnn_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
 struct DeviceInfo { int cus = 256; size_t lds = (size_t)160 << 10; int dev = -1; };
 const DeviceInfo& device_info();
 
+hipError_t probe_queue_shared(hipStream_t a, hipStream_t b, bool* shared);   // pnn_small.hip: do two streams sit on one hardware queue?
+
 constexpr int kMaxTaps = 32;
 constexpr int kMaxClasses = 4;
 

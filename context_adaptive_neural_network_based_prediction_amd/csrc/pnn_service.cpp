@@ -643,6 +643,8 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
         for (int k = 0; k < 5; k++) nrep[k] = std::max(1, std::min(Server::kMaxRep, got == 5 ? v[k] : got >= 1 ? v[0] : 1));
     }
     pnn_ctx* ctxs[5][Server::kMaxRep] = {};
+    void* qs[4] = {nullptr, nullptr, nullptr, nullptr};   // streams on four different hardware queues (see below)
+    int nqs = 0;
     static const int kWidths[5] = {4, 8, 16, 32, 64};
     int rc = PNN_OK;
     for (int k = 0; k < 5 && rc == PNN_OK; k++) {
@@ -684,6 +686,24 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
                 for (int k = 0; k < 5; k++) { sv.group[k] = std::max(0, std::min(4, v[k])); nrep[k] = 1; }
         }
+        // One hardware queue per busy width.  The runtime deals its streams onto 4 hardware queues, and five contexts' streams (behind
+        // the null stream the start-up used) end up with the 16x16 and 32x32 workers on ONE queue and the 8x8 and 64x64 workers on
+        // another: their calls run in submission order, each waiting for the other's (tools/corun_threads.cpp: a 16x16 and a 32x32 call
+        // take 80 / 133 us alone and 273 us EACH side by side; more hardware queues are worse, GPU_MAX_HW_QUEUES = 8: a 4x4 call 248 us).
+        // So: four streams MEASURED to sit on four different queues (pnn_streams_on_distinct_queues), one each for the widths that carry
+        // the campaign (4, 8, 16), the fourth for 32 and 64 together -- on one worker thread, they would wait for each other anyway.
+        // PNN_SERVICE_QUEUES=0: every context on the stream it created, as before.
+        bool own_queues = true;
+        if (const char* e = getenv("PNN_SERVICE_QUEUES")) own_queues = atoi(e) != 0;
+        for (int k = 0; k < 5; k++) own_queues = own_queues && nrep[k] == 1;
+        own_queues = own_queues && !getenv("PNN_SERVICE_GROUPS") && !getenv("PNN_SERVICE_PRIORITIES");
+        if (own_queues) {
+            nqs = pnn_streams_on_distinct_queues(qs, 4);
+            if (nqs == 4) {
+                static const int kQueueOf[5] = {0, 1, 2, 3, 3};
+                for (int k = 0; k < 5; k++) { pnn_set_option(ctxs[k][0], "stream", (long)qs[kQueueOf[k]]); sv.group[k] = kQueueOf[k]; }
+            }
+        }
         sv.backend = ctx_backend; sv.nworkers = 5; for (int k = 0; k < 5; k++) sv.nrep[k] = nrep[k]; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
         sv.nio = 4;                                  // socket threads (PNN_SERVICE_IO_THREADS overrides)
         for (int k = 0; k < 5; k++) {
@@ -694,6 +714,7 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
         rc = sv.run(socket_path, stats);
     }
     for (auto& cr : ctxs) for (pnn_ctx* c : cr) if (c) pnn_destroy(c);
+    if (nqs > 0) pnn_streams_release(qs, nqs);
     return rc;
 }
 

@@ -8,6 +8,7 @@
 // TComPrediction.cpp:621-635 (epilogue).
 #include <algorithm>
 #include "pnn_kernels.h"
+#include <time.h>
 #include "pnn_device_common.h"
 
 namespace pnn {
@@ -795,6 +796,32 @@ hipError_t launch_block_cost(const BlockCostParams& p, hipStream_t s)
     else if (p.pel_bytes == 1) hipLaunchKernelGGL((block_cost_kernel<uint8_t, 4>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+// ---- which streams share a hardware queue? (pnn_streams_on_distinct_queues, pnn_abi.cpp) -------------------------------------------------
+// The runtime deals its streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4); two streams on one queue run their kernels in
+// submission order, so two width workers of the batching service whose streams share a queue wait for each other's whole calls.
+// A `busy_us` kernel goes to stream a and an empty one behind it to stream b: b finishing only after a = one queue.
+__global__ void queue_probe_busy_kernel(unsigned ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+__global__ void queue_probe_empty_kernel() {}
+
+hipError_t probe_queue_shared(hipStream_t a, hipStream_t b, bool* shared)
+{
+    constexpr double kBusyUs = 150.0;
+    hipLaunchKernelGGL(queue_probe_busy_kernel, dim3(1), dim3(64), 0, a, (unsigned)(kBusyUs * 100.0));
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    hipLaunchKernelGGL(queue_probe_empty_kernel, dim3(1), dim3(64), 0, b);
+    hipError_t e = hipStreamSynchronize(b);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const hipError_t e2 = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = e2;
+    *shared = ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3) > kBusyUs * 0.6;
+    return e;
 }
 
 }  // namespace pnn

@@ -106,6 +106,7 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "flag_wait"            1   a small host call ends when its LAST kernel raises a sequence number in pinned host memory (3-7 us earlier
  *                              than the runtime's completion signal); "spin_wait" (0): hipStreamQuery polling instead of hipStreamSynchronize
  *   "stream_priority"      0   < 0 / > 0: the context's own stream (host entry points) at the device's greatest / least priority
+ *   "stream"               -   a hipStream_t (cast to long): the context's host entry points run on the caller's stream from now on
  *   "wait_sleep"           0   1: the thread of a small host call sleeps through the predictable part of its wait (running mean per batch
  *                              size, minus a margin) and spins only for the rest: the batching service's workers set it (two thirds of
  *                              their CPU time was that spin); a stand-alone codec keeps 0
@@ -165,6 +166,14 @@ int pnn_predict_pel(pnn_ctx* ctx, int width, const float* above, const float* le
  * device-visible; any thread may free). */
 int pnn_host_alloc(void** out, size_t bytes);
 void pnn_host_free(void* p);
+
+/* The runtime deals HIP streams onto a few hardware queues (4 by default); streams that share one run their kernels in submission order,
+ * so two threads with a context each may find themselves waiting for each other's whole calls.  pnn_streams_on_distinct_queues creates
+ * `want` (<= 8) streams that were MEASURED to sit on different hardware queues and returns how many it found; give one to a context with
+ * pnn_set_option(ctx, "stream", (long) stream) -- its host entry points then run there -- and release them after the contexts.
+ * (The batching service does this for its width workers: pnn_service_run_table.) */
+int pnn_streams_on_distinct_queues(void** out_streams, int want);
+void pnn_streams_release(void** streams, int n);
 
 /* Both results of one pass: the float prediction (as pnn_predict_fc / pnn_predict_conv) into `out` [n][w][w] and the
  * HM-epilogue Pel values (as pnn_predict_pel, dense) into `dst` [n][w][w]; either may be NULL. */

@@ -42,6 +42,8 @@ int pnn_model_info(const pnn_ctx*, int width, int* is_fc, int*, long*)
 int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
 int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
 int pnn_set_option(pnn_ctx*, const char*, long) { return PNN_E_HIP; }
+int pnn_streams_on_distinct_queues(void**, int) { return 0; }
+void pnn_streams_release(void**, int) {}
 void pnn_destroy(pnn_ctx*) {}
 }
 namespace pnn { void set_create_error(const std::string&) {} }

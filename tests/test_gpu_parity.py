@@ -464,6 +464,33 @@ def test_small_calls_replayed_as_graphs(pnn, precision, w, is_fc):
     net.close()
 
 
+def test_streams_on_distinct_hardware_queues(pnn):
+    """pnn_streams_on_distinct_queues: four streams measured to sit on four different hardware queues (the runtime deals streams onto
+    four); a context that adopts one (option "stream") computes the same predictions there, before and after, and the streams outlive it."""
+    import ctypes
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    L = _lib.lib()
+    w = 8
+    params = util.make_params(w, True, 71, out_gain=util.out_gain(w, True))
+    above, left = util.make_contexts(w, 5, 72)
+    ctx = util.flatten_fc(above, left)
+    net = pnn.PredictionNeuralNetwork(5, w, True, params=params)
+    want = net.predict_pel(ctx).copy()
+    streams = (ctypes.c_void_p * 4)()
+    n = L.pnn_streams_on_distinct_queues(streams, 4)
+    assert n == 4 and len({int(s) for s in streams}) == 4
+    for s in streams:
+        net.set_option("stream", int(s))
+        for m in (1, 5):
+            assert np.array_equal(net.predict_pel(ctx[:m]), want[:m])
+    more = (ctypes.c_void_p * 8)()
+    assert 4 <= L.pnn_streams_on_distinct_queues(more, 8) <= 8          # (as many as the runtime has queues; never fewer than the four above)
+    L.pnn_streams_release(more, 8)
+    assert L.pnn_streams_on_distinct_queues(more, 0) == -1 and L.pnn_set_option(net.ctx, b"stream", 0) == -1
+    net.close()                                                         # the adopted stream is not the context's to destroy
+    L.pnn_streams_release(streams, 4)
+
+
 def test_arithmetic_tag_names_the_summation_order(pnn):
     """pnn_arithmetic_tag: one string per arithmetic, the same for every context and width of a library build; it changes with the
     "precision" option and with nothing else -- what an encoder and its decoder compare once at start-up."""

@@ -5,6 +5,7 @@
 //   tools/_bin/corun_threads <model table> <precision 0|1> <seconds> [option=value ...]
 #include "pnn_hip.h"
 
+#include <time.h>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -31,6 +32,7 @@ int main(int argc, char** argv)
     for (int i = 0; i < n; i++) for (int k = 0; k < 5; k++) if (widths[i] == kCases[k].w && !pairs[i] && !chans[i]) files[k] = paths[i];
     pnn_ctx* ctx[5];
     int is_fc[5];
+    double gap_spin_us = 0, gap_sleep_us = 0;
     for (int k = 0; k < 5; k++) {
         if (pnn_create_empty(&ctx[k], 117.8952234192841f, 0) || pnn_load_model_file(ctx[k], files[k].c_str())) { fprintf(stderr, "model %d: %s\n", kCases[k].w, pnn_last_error(ctx[k])); return 1; }
         pnn_set_option(ctx[k], "precision", precision);
@@ -38,6 +40,8 @@ int main(int argc, char** argv)
             std::string s(argv[a]);
             const size_t eq = s.find('=');
             if (s == "fcprio") { pnn_set_option(ctx[k], "stream_priority", k < 2 ? -1 : 1); continue; }   // widths 4 / 8 ahead of the conv widths
+            if (eq != std::string::npos && s.substr(0, eq) == "gap_us") { gap_spin_us = atof(s.c_str() + eq + 1); continue; }          // between two calls of a thread: busy-wait
+            if (eq != std::string::npos && s.substr(0, eq) == "gap_sleep_us") { gap_sleep_us = atof(s.c_str() + eq + 1); continue; }   // ... or nanosleep (the time of the CALLS is what is printed)
             if (eq != std::string::npos) pnn_set_option(ctx[k], s.substr(0, eq).c_str(), atol(s.c_str() + eq + 1));
         }
         pnn_model_info(ctx[k], kCases[k].w, &is_fc[k], nullptr, nullptr);
@@ -62,9 +66,16 @@ int main(int argc, char** argv)
                 ready++;
                 while (ready.load() < nt) pnn_predict_f32_pel(ctx[k], w, above.data(), is_fc[k] ? nullptr : left.data(), nb, nullptr, dst.data());
                 long calls = 0;
-                const auto t0 = std::chrono::steady_clock::now();
-                while (!stop.load()) { pnn_predict_f32_pel(ctx[k], w, above.data(), is_fc[k] ? nullptr : left.data(), nb, nullptr, dst.data()); calls++; }
-                us[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)std::max(calls, 1L) * 1e6;
+                double in_calls = 0;
+                while (!stop.load()) {
+                    const auto c0 = std::chrono::steady_clock::now();
+                    pnn_predict_f32_pel(ctx[k], w, above.data(), is_fc[k] ? nullptr : left.data(), nb, nullptr, dst.data());
+                    const auto c1 = std::chrono::steady_clock::now();
+                    in_calls += std::chrono::duration<double>(c1 - c0).count(); calls++;
+                    if (gap_spin_us > 0) while (std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count() * 1e6 < gap_spin_us) {}
+                    if (gap_sleep_us > 0) { timespec ts{0, (long)(gap_sleep_us * 1e3)}; nanosleep(&ts, nullptr); }
+                }
+                us[k] = in_calls / (double)std::max(calls, 1L) * 1e6;
             });
         }
         while (ready.load() < nt) std::this_thread::sleep_for(std::chrono::milliseconds(5));
