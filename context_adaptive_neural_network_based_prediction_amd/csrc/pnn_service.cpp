@@ -240,10 +240,11 @@ struct Server {
     void reply(int k, Flight& f, int rc, const int32_t* dst, const float* out, double busy)
     {
         const size_t n = f.batch.size(), w2 = (size_t)f.batch[0].width * f.batch[0].width;
+        const int wi = nworkers == 1 ? k : widx(f.batch[0].width);   // the statistics are kept per WIDTH (two widths may share a worker thread)
         std::vector<Reply> replies(n);
         for (size_t i = 0; i < n; i++) {
             const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
-            replies[i].id = f.batch[i].id; replies[i].t_in = f.batch[i].t_in; replies[i].k = k;
+            replies[i].id = f.batch[i].id; replies[i].t_in = f.batch[i].t_in; replies[i].k = wi;
             const char* hp = reinterpret_cast<const char*>(&rh);
             replies[i].bytes.assign(hp, hp + sizeof rh);
             if (rc == 0) {
@@ -264,7 +265,7 @@ struct Server {
         for (int t = 0; t < nio; t++) if (woke[t]) (void)!write(wake_fd[t], &one, 8);
         std::lock_guard<std::mutex> lk(mu);
         served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
-        ++calls_w[k]; served_w[k] += (long)n; busy_s[k] += busy; wait_s[k] += f.waited;
+        ++calls_w[wi]; served_w[wi] += (long)n; busy_s[wi] += busy; wait_s[wi] += f.waited;
     }
     // Blocks until worker k has something to do (false: the server stops).  An idle worker gives stragglers a moment to join --
     // unless every peer process already waits for an answer (an encoder is single-threaded and blocks on its request: nobody

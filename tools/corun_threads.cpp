@@ -46,6 +46,16 @@ int main(int argc, char** argv)
         }
         pnn_model_info(ctx[k], kCases[k].w, &is_fc[k], nullptr, nullptr);
     }
+    // "queues": as the batching service does -- four streams measured to sit on four hardware queues; 4, 8, 16 one each, 32 and 64 the fourth
+    void* qs[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool own_queues = false;
+    for (int a = 4; a < argc; a++) own_queues |= std::string(argv[a]) == "queues";
+    if (own_queues) {
+        if (pnn_streams_on_distinct_queues(qs, 4) != 4) { fprintf(stderr, "fewer than four hardware queues\n"); return 1; }
+        static const int kQueueOf[5] = {0, 1, 2, 3, 3};
+        for (int k = 0; k < 5; k++) pnn_set_option(ctx[k], "stream", (long)qs[kQueueOf[k]]);
+        printf("# contexts on streams measured to sit on different hardware queues (4, 8, 16: one each; 32 and 64 share the fourth)\n");
+    }
     auto run = [&](unsigned mask, double* us) {
         std::atomic<bool> stop{false};
         std::atomic<int> ready{0};
@@ -92,5 +102,6 @@ int main(int argc, char** argv)
         printf("%-5s width %2d %-4s %d blocks per call: alone %6.1f us | all five widths %6.1f us (x %.2f) | 4 + 8 only %6.1f | all but 64 %6.1f\n", precision ? "split" : "f32", kCases[k].w,
                is_fc[k] ? "FC" : "conv", kCases[k].n, alone[k], all[k], all[k] / alone[k], small[k], no64[k]);
     for (int k = 0; k < 5; k++) pnn_destroy(ctx[k]);
+    if (own_queues) pnn_streams_release(qs, 4);
     return 0;
 }

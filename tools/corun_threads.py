@@ -13,8 +13,8 @@ if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.j
 if "--build-only" in sys.argv:
     raise SystemExit(0)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-seconds = args[0] if args and "=" not in args[0] and args[0] != "fcprio" else "1.5"
-opts = [a for a in args if "=" in a or a == "fcprio"]
+seconds = args[0] if args and "=" not in args[0] and args[0] not in ("fcprio", "queues") else "1.5"
+opts = [a for a in args if "=" in a or a in ("fcprio", "queues")]
 with tempfile.TemporaryDirectory() as d:
     table, _ = run_hm.make_models(os.path.join(d, "models"))
     for precision in ("0", "1"):

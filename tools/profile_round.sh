@@ -43,7 +43,8 @@ cp bench_detail.json $out/bench_default_detail.json
 ( echo "# tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait); the library's defaults (option graphs = 1: captured launch chains)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids
   echo "# the same with PNN_GRAPHS=0 (plain launches)"; PNN_GRAPHS=0 python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
 ( echo "# tools/host_rate.py on one MI355X: the batched HOST-array entry points (pnn_predict_pel: host arrays in, int32 blocks out, one synchronous call per batch)"; python3 tools/host_rate.py fc8 conv16 fc4 conv32 conv64 2>&1 | grep -v amdgpu.ids ) > $out/host_rate.txt
-( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
+( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids; python3 tools/corun_threads.py 1.5 queues 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
+[ -x tools/_bin/hwq_probe ] && ( timeout 60 ./tools/_bin/hwq_probe 10 ) > $out/hwq_probe.txt 2>&1
 [ -x tools/_bin/f32_chain_probe ] && ( echo "# tools/f32_chain_probe.hip: one wave, one dependent accumulation chain per instruction form (cycles by s_memtime)"; ./tools/_bin/f32_chain_probe ) > $out/f32_chain_probe.txt
 [ -x tools/_bin/corun_noise ] && python3 - > $out/corun_noise.txt 2>/dev/null <<'PY'
 import os, subprocess, sys, tempfile
