@@ -133,6 +133,10 @@ struct pnn_ctx {
     // 1: the K segments of a layer that runs on the small exact-f32 kernel are added up inside its launch (the last workgroup of a tile
     // to arrive, see tapgemm_f32_small_body) instead of by a seg_reduce launch behind it: the same additions in the same order
     long opt_seg_fold = 1;
+    // The small exact-f32 kernel's weight ring, 6 or 12 stages ahead of the chain (pnn_gemm_f32_small.hip): 0 = always 6; 1 (default) = 12
+    // for the FC layers; 2 = 12 for every launch of at most one workgroup per CU (the batching service's contexts: inside a campaign the
+    // weights come from the MALL / HBM, not from L2, and the short ring does not cover that latency)
+    long opt_f32_small_deep = 1;
     unsigned* d_seg_cnt = nullptr;                    // the tiles' arrival counters: [2 branches][kSegCntTiles], zero between launches
     static constexpr int kSegCntTiles = 2048;
     long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles

@@ -63,10 +63,10 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 }  // namespace
 
 // INL: the f32 input rows of an FC net's first layer travel INSIDE the kernel-argument block (see tapgemm_small_inline_kernel).
-template <bool INL>
+template <bool INL, int LA>
 __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz, const int gy)
 {
-    constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, LA = kF32SmallLA, D = kF32SmallD;
+    constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, D = LA + 2;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
     const int lane = threadIdx.x & 63;
     // Which wave runs the MFMA chain rotates with the tile (role 0 = the chain, roles 1-3 = the loaders): a workgroup's wave i sits on
@@ -293,23 +293,33 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
 }
 
+// LA (stages of 3 chunks in flight ahead of the chain) is a template parameter: kF32SmallLA = 6 (48 KiB of ring: three workgroups per
+// CU) for launches of many tiles, kF32SmallLADeep = 12 (84 KiB: one per CU; the most the 6-bit vmcnt counts) for launches of at most one
+// workgroup per CU -- the FC layers' 75, the small conv layers.  The deep ring changes nothing for a call that runs alone, its weights
+// coming from L2 (37-39 us per FC call either way); inside a campaign five nets' weights (135 MB) take turns in 32 MB of L2 and arrive
+// from the MALL / HBM with a latency that 18 chunks of lookahead (1.1 us at the chain's pace) do not cover and 36 chunks do: a 4x4 / 8x8
+// call 55 -> 47 us inside configs[3], a 16x16 call 117 -> 107, the campaign 5.8-6.1 -> 5.5 s.  (Deep rings everywhere: conv 64x64 single
+// block 236 -> 259 us -- its 1024-tile layers then run in rounds.)
+template <int LA>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_kernel(const F32SmallArgs args)
 {
     touch_kernargs<sizeof(F32SmallArgs)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_f32_small_body<false>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+    tapgemm_f32_small_body<false, LA>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
+template <int LA>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_inline_kernel(const F32SmallArgsInline args)
 {
     touch_kernargs<sizeof(TapGemmParams)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) F32SmallArgsInline*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_f32_small_body<true>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+    tapgemm_f32_small_body<true, LA>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 
 // Two independent layers in ONE launch (the same layer of the two branches of a convolutional net), see tapgemm_small_pair_kernel.
 struct F32SmallArgs2 { TapGemmParams a, b; int na; };
+template <int LA>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32SmallArgs2 args)
 {
     touch_kernargs<sizeof(F32SmallArgs2)>();
@@ -321,10 +331,12 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32Sm
     const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
     const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
     const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
-    tapgemm_f32_small_body<false>(*p, r % gx, r / gx, bz, gy);
+    tapgemm_f32_small_body<false, LA>(*p, r % gx, r / gx, bz, gy);
 }
 
-size_t tapgemm_f32_small_lds_bytes() { return (size_t)kF32SmallD * kF32SmallCS * 128 * 16; }
+constexpr int kF32SmallLADeep = 12;
+static_assert(5 * kF32SmallCPL * kF32SmallLADeep < 64, "vmcnt is a 6-bit counter");
+size_t tapgemm_f32_small_lds_bytes(bool deep) { return (size_t)((deep ? kF32SmallLADeep : kF32SmallLA) + 2) * kF32SmallCS * 128 * 16; }
 
 long tapgemm_f32_small_tiles(const TapGemmParams& p)
 {
@@ -338,34 +350,42 @@ static hipError_t f32_small_attrs()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (done_for == dev) return hipSuccess;
-    const void* fns[3] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel), reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel),
-                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel)};
-    for (const void* f : fns)
-        if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes())) != hipSuccess) return e;
+    const void* fns[6] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLA>),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLADeep>),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLADeep>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLADeep>)};
+    for (int i = 0; i < 6; i++)
+        if ((e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes(i >= 3))) != hipSuccess) return e;
     done_for = dev;
     return hipSuccess;
 }
 
-hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input)
+// the deep ring for launches of at most one workgroup per CU (see the kernels' comment).  mode 0: never; 1: the FC layers only (nothing to
+// lose alone: 38 us either way; a conv 16x16 call alone 82 -> 87 us with it); 2: every such launch (the batching service's contexts)
+static bool f32_small_deep(long tiles, int mode, bool fc) { return mode > 0 && (mode > 1 || fc) && tiles <= (long)device_info().cus; }
+
+hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input, int deep_mode)
 {
     hipError_t e = f32_small_attrs();
     if (e != hipSuccess) return e;
     if (p.M <= 0) return hipSuccess;
     const dim3 grid((p.M + 15) / 16, (p.Cout + 15) / 16, (unsigned)(p.ncls * (p.nseg > 1 ? p.nseg : 1)));
+    const bool deep = f32_small_deep(tapgemm_f32_small_tiles(p), deep_mode, p.SH * p.SW == 1);
     const size_t nin = (size_t)p.M * p.IH * p.IW * p.Cin;
     if (host_input && p.SH * p.SW == 1 && nin <= (size_t)kF32SmallInlineFloats) {
         F32SmallArgsInline a;
         a.p = p;
         memcpy(a.in, host_input, nin * sizeof(float));
-        pnn_launch(tapgemm_f32_small_inline_kernel, grid, dim3(256), tapgemm_f32_small_lds_bytes(), s, a);
+        if (deep) pnn_launch(tapgemm_f32_small_inline_kernel<kF32SmallLADeep>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+        else pnn_launch(tapgemm_f32_small_inline_kernel<kF32SmallLA>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
         return hipGetLastError();
     }
     const F32SmallArgs a{p};
-    pnn_launch(tapgemm_f32_small_kernel, grid, dim3(256), tapgemm_f32_small_lds_bytes(), s, a);
+    if (deep) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLADeep>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+    else pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s)
+hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s, int deep_mode)
 {
     if (a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
     const hipError_t e = f32_small_attrs();
@@ -373,7 +393,9 @@ hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmPa
     F32SmallArgs2 args;
     args.a = a; args.b = b;
     args.na = (int)tapgemm_f32_small_tiles(a);
-    pnn_launch(tapgemm_f32_small_pair_kernel, dim3((unsigned)(args.na + tapgemm_f32_small_tiles(b))), dim3(256), tapgemm_f32_small_lds_bytes(), s, args);
+    const long total = args.na + tapgemm_f32_small_tiles(b);
+    if (f32_small_deep(total, deep_mode, false)) pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLADeep>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
+    else pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLA>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
     return hipGetLastError();
 }
 

@@ -170,8 +170,8 @@ hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStr
 // Small-M form of the same order on v_mfma_f32_16x16x4_f32 (pnn_gemm_f32_small.hip): one wave per 16 x 16 tile, K segments as grid z;
 // host_input (optional, FC layers): the same rows in HOST memory; when they fit they travel inside the argument block
 long tapgemm_f32_small_tiles(const TapGemmParams& p);
-hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input = nullptr);
-hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s);   // two independent layers, one launch
+hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input = nullptr, int deep_mode = 1);   // deep_mode: pnn_ctx::opt_f32_small_deep
+hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s, int deep_mode = 1);   // two independent layers, one launch
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
 hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);
 // ... and, for small M, the same segments AND their reduction (+ bias, HM epilogue) in one launch: fuse_reduce_kernel's bits

@@ -82,7 +82,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             r.kind = 6; r.flops = flops;
             const LaunchEvents ev{r.e0, r.e1};
             g_launch_events = &ev;
-            const hipError_t le = launch_tapgemm_f32_small(ps, s, host_rows);
+            const hipError_t le = launch_tapgemm_f32_small(ps, s, host_rows, (int)c->opt_f32_small_deep);
             g_launch_events = nullptr;
             HIPCHK(c, le);
             if (profile) {
@@ -96,7 +96,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
                 c->launch_recs.push_back(r);
             }
         } else {
-            HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows));
+            HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows, (int)c->opt_f32_small_deep));
         }
         if (nseg > 1 && !fold) {
             HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
@@ -109,7 +109,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             HIPCHK(c, hipMemset(c->stage_tbs.p, 0, (size_t)4 << 20));
             TapGemmParams q = ps;
             q.Xlo = c->stage_tbs.p;
-            HIPCHK(c, launch_tapgemm_f32_small(q, s, host_rows));
+            HIPCHK(c, launch_tapgemm_f32_small(q, s, host_rows, (int)c->opt_f32_small_deep));
             HIPCHK(c, hipStreamSynchronize(s));
             const size_t nwg = std::min<size_t>((size_t)tapgemm_f32_small_tiles(p), ((size_t)4 << 20) / 32);
             std::vector<unsigned long long> hbuf(4 * nwg);
@@ -790,7 +790,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             }
             static const bool dbg = getenv("PNN_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[pnn] f32 gemm pair: branch layer %zu, M = %d / %d -> one f32 small-kernel launch\n", i + 1, q[0].M, q[1].M);
-            HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s));
+            HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s, (int)c->opt_f32_small_deep));
             c->stat_gemm_launches++; c->stat_launches++;
             for (int br = 0; br < 2; br++) {
                 const GemmLayer& L = m->branch[br][i];

@@ -666,6 +666,9 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             // without against 6.02 / 6.27 s with, service CPU 24.4 / 24.8 -> 25.1 / 27.7 s (workers - 2.4 s, runtime thread + 4.7 s), a
             // 16x16 call 174 -> 196 us.  Off here.
             if (rc == PNN_OK && !getenv("PNN_GRAPHS")) pnn_set_option(ctxs[k][r], "graphs", 0);
+            // the deep weight ring for every small launch that fits one workgroup per CU: inside a campaign the weights arrive from the
+            // MALL / HBM (five nets take turns in L2), see pnn_gemm_f32_small.hip
+            if (rc == PNN_OK && !getenv("PNN_F32_SMALL_DEEP")) pnn_set_option(ctxs[k][r], "f32_small_deep", 2);
             // Stream priorities per width: PNN_SERVICE_PRIORITIES = five of h / n / l (default: all normal).  Streams of one priority
             // share the runtime's few hardware queues and two busy widths on one queue serialise -- with the two FC widths on high-priority
             // streams a conv 16x16 / 32x32 call takes 114 / 198 us instead of 180 / 258 inside a configs[3] campaign, but a 4x4 call 68

@@ -114,6 +114,10 @@ float pnn_mean(const pnn_ctx* ctx);
  *                              layer's launch by the last workgroup of each tile to arrive (planes written through, read back past
  *                              the caches, added in plane order) instead of by a reduction launch behind it: 17 -> 11 / 20 -> 11
  *                              launches per single-block call, the same bits
+ *   "f32_small_deep"       1   exact f32, small calls: the weight ring of the small kernel 12 instead of 6 stages ahead of the MFMA chain
+ *                              (84 instead of 48 KiB of LDS per workgroup) -- 0: never, 1: for the FC layers, 2: for every launch of at
+ *                              most one workgroup per CU (the batching service sets 2: inside a campaign the weights come from the
+ *                              MALL / HBM, a 4x4 call 55 -> 47 us; alone nothing changes for the FC nets, conv 16x16 82 -> 87 us)
  *   "graphs"               1   small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
  *                              on its second call and replayed with one hipGraphLaunch afterwards -- same kernels, same arguments,
  *                              same bits; a single-block call 1-8 us shorter for a thread that calls alone; the batching service's

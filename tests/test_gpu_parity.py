@@ -424,6 +424,10 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
     assert np.array_equal(run(above[:1], left[:1])[0], want[0])
     assert net.last_call_stats()["launches"] == launches + ({32: 6, 64: 9}.get(w, 0) if not is_fc else 0)   # what the in-launch sum saves per single-block call
     net.set_option("seg_fold", 1)
+    for deep in (0, 2, 1):                                           # the weight ring 6 or 12 stages ahead of the chain: the same sums
+        net.set_option("f32_small_deep", deep)
+        assert np.array_equal(run(above, left), want), "f32_small_deep = %d" % deep
+        assert np.array_equal(run(above[:1], left[:1])[0], want[0]), "f32_small_deep = %d, one block" % deep
     for _ in range(3):                                               # the tiles' counters go back to zero: launch after launch
         assert np.array_equal(run(above[:1], left[:1])[0], want[0])
     net.set_option("fc_out_f32", 0)                                  # FC: the output layer's K segments and their reduction as two launches
