@@ -71,6 +71,8 @@ namespace pnn {
 int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
 {
     if (b.bytes >= bytes) return PNN_OK;
+    // a buffer moves: every captured launch chain of this context carries the old address in its kernels' arguments
+    for (auto& kv : c->graphs) if (kv.second.exec) { (void)hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; kv.second.uses = 0; }
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr; b.bytes = 0;
     const size_t want = std::max(bytes, (size_t)1 << 20);
@@ -718,6 +720,14 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
                 if (g) (void)hipGraphDestroy(g);
             }
             if (rc != PNN_OK || e != hipSuccess || !ge->exec) {   // this shape stays on plain launches
+                static const bool debug = getenv("PNN_DEBUG") != nullptr;
+                if (debug) fprintf(stderr, "[pnn] capture of the launch chain failed (width %d, %d blocks): %s / %s -- plain launches for this shape\n", w, n,
+                                   rc != PNN_OK ? c->err.c_str() : "pass ok", hipGetErrorString(e));
+                // whatever went wrong must not leave a stream in capture mode: the plain pass below runs on them
+                for (hipStream_t st : {s, c->side_stream}) {
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t junk = nullptr; (void)hipStreamEndCapture(st, &junk); if (junk) (void)hipGraphDestroy(junk); }
+                }
                 (void)hipGetLastError();
                 if (ge->exec) { (void)hipGraphExecDestroy(ge->exec); ge->exec = nullptr; }
                 ge->failed = true;

@@ -39,7 +39,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSmallCS = 3;                         // chunks per stage = loader waves
-constexpr int kSmallLA = 4;                         // stages in flight ahead of the one being computed (8 stages / 108 KiB measured no
+#ifndef PNN_SMALL_LA
+#define PNN_SMALL_LA 4
+#endif
+constexpr int kSmallLA = PNN_SMALL_LA;                         // stages in flight ahead of the one being computed (8 stages / 108 KiB measured no
                                                     // faster: 9.0 vs 8.7 us per 1200-deep layer -- the loop is issue-bound, not latency-bound)
 constexpr int kSmallD = kSmallLA + 1;               // ring slots (stages): 5 x 12 KiB
 
