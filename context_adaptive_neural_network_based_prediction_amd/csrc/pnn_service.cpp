@@ -661,11 +661,9 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             rc = pnn_create_empty(&ctxs[k][r], mean, device);
             if (rc == PNN_OK) rc = pnn_load_model_file(ctxs[k][r], p.c_str());
             if (rc == PNN_OK && !getenv("PNN_WAIT_SLEEP")) pnn_set_option(ctxs[k][r], "wait_sleep", 1);   // five workers that spin would hold five CPUs for the length of a campaign
-            // Captured launch chains (option "graphs") pay for a thread that calls the library alone; behind five workers the runtime's graph
-            // launches contend like its kernel launches do and move their cost to a runtime thread: configs[3], same box, 6.07 / 6.19 s
-            // without against 6.02 / 6.27 s with, service CPU 24.4 / 24.8 -> 25.1 / 27.7 s (workers - 2.4 s, runtime thread + 4.7 s), a
-            // 16x16 call 174 -> 196 us.  Off here.
-            if (rc == PNN_OK && !getenv("PNN_GRAPHS")) pnn_set_option(ctxs[k][r], "graphs", 0);
+            // (Captured launch chains, option "graphs", are off by default and stay off here: behind five workers the runtime's graph
+            // launches contend like its kernel launches do and move their cost to a runtime thread -- configs[3], same box, 6.07 / 6.19 s
+            // without against 6.02 / 6.27 s with, service CPU 24.4 / 24.8 -> 25.1 / 27.7 s, a 16x16 call 174 -> 196 us.)
             // the deep weight ring for every small launch that fits one workgroup per CU: inside a campaign the weights arrive from the
             // MALL / HBM (five nets take turns in L2), see pnn_gemm_f32_small.hip
             if (rc == PNN_OK && !getenv("PNN_F32_SMALL_DEEP")) pnn_set_option(ctxs[k][r], "f32_small_deep", 2);

@@ -118,10 +118,10 @@ float pnn_mean(const pnn_ctx* ctx);
  *                              (84 instead of 48 KiB of LDS per workgroup) -- 0: never, 1: for the FC layers, 2: for every launch of at
  *                              most one workgroup per CU (the batching service sets 2: inside a campaign the weights come from the
  *                              MALL / HBM, a 4x4 call 55 -> 47 us; alone nothing changes for the FC nets, conv 16x16 82 -> 87 us)
- *   "graphs"               1   small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
+ *   "graphs"               0   1: small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
  *                              on its second call and replayed with one hipGraphLaunch afterwards -- same kernels, same arguments,
- *                              same bits; a single-block call 1-8 us shorter for a thread that calls alone; the batching service's
- *                              width workers turn it off (no gain beside four other launching threads)
+ *                              same bits; a single-block call 1-4 us shorter for a thread that calls alone, nothing behind the
+ *                              batching service.  Off by default (a rare capture failure inside an HM encoder, not yet explained)
  *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
  */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);

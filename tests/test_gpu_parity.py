@@ -443,7 +443,7 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
 
 @pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (16, False), (32, False), (64, False)])
 def test_small_calls_replayed_as_graphs(pnn, precision, w, is_fc):
-    """Option "graphs" (default on): the launch chain of a small host call is captured on the second call of a shape (model, blocks,
+    """Option "graphs" (opt-in): the launch chain of a small host call is captured on the second call of a shape (model, blocks,
     result kinds) and replayed afterwards with one hipGraphLaunch.  Every call -- first (plain launches), second (captured), later
     (replayed), with new inputs each time and shapes interleaved -- gives the bits of the same call with the option off; an option
     change drops the captured chains."""

@@ -40,8 +40,8 @@ python3 tools/f32_sweep.py fc8 conv16 fc4 conv32 conv64 > $out/f32_tile_sweep.tx
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 cp bench_detail.json $out/bench_default_detail.json
 # round 5: the single-block path on the reference's arithmetic, the host-array entry points, the width workers side by side
-( echo "# tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait); the library's defaults (option graphs = 1: captured launch chains)"; python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids
-  echo "# the same with PNN_GRAPHS=0 (plain launches)"; PNN_GRAPHS=0 python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
+( echo "# tools/batch1_latency.py, one MI355X (host call pnn_predict_pel at batch 1: staging + net + epilogue + wait); the library's defaults (plain launches)"; PNN_GRAPHS=0 python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids
+  echo "# the same with PNN_GRAPHS=1 (option graphs: the launch chain of a shape captured once, replayed with one hipGraphLaunch)"; PNN_GRAPHS=1 python3 tools/batch1_latency.py 2>&1 | grep -v amdgpu.ids ) > $out/batch1_latency.txt
 ( echo "# tools/host_rate.py on one MI355X: the batched HOST-array entry points (pnn_predict_pel: host arrays in, int32 blocks out, one synchronous call per batch)"; python3 tools/host_rate.py fc8 conv16 fc4 conv32 conv64 2>&1 | grep -v amdgpu.ids ) > $out/host_rate.txt
 ( echo "# tools/corun_threads.cpp: the batching service's five width workers as five host threads with one context each, configs[3]'s mean batches"; python3 tools/corun_threads.py 1.5 2>&1 | grep -v amdgpu.ids; python3 tools/corun_threads.py 1.5 queues 2>&1 | grep -v amdgpu.ids ) > $out/corun_widths.txt
 [ -x tools/_bin/hwq_probe ] && ( timeout 60 ./tools/_bin/hwq_probe 10 ) > $out/hwq_probe.txt 2>&1
