@@ -35,9 +35,11 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
  * header is dropped and the others go on. */
 int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int window_us, volatile int* stop, long* stats);
 /* The production form: the server creates its own contexts from the model table (selection rule of pnn_create:
- * TComPrediction.cpp:143-178) -- FIVE of them, one per width with that width's model only, each served by its own worker
- * thread and stream, so that passes of different widths overlap on the GPU and with the socket work.  While a worker is
- * busy the requests for its width accumulate: the next batch forms by itself.  Socket work (accept, receive, reply) is spread
+ * TComPrediction.cpp:143-178) -- FIVE of them, one per width with that width's model only.  The 4x4, 8x8 and 16x16 widths each
+ * have a worker thread and a stream on a HARDWARE QUEUE of their own (pnn_streams_on_distinct_queues: the runtime has four, and two
+ * busy streams on one queue wait for each other's whole calls); 32x32 and 64x64 share the fourth queue and a thread.  Passes of
+ * different widths overlap on the GPU and with the socket work; while a worker is busy the requests for its width accumulate:
+ * the next batch forms by itself.  ($PNN_SERVICE_QUEUES=0: every context on the stream it created, one thread per width.)  Socket work (accept, receive, reply) is spread
  * over 4 I/O threads, each owning its share of the connections ($PNN_SERVICE_IO_THREADS: 1 ... 8): one socket thread topped
  * out near 120 k requests/s, the ceiling of a server behind 24 or 100 HM encoders alike.  A request
  * whose shape (n_above, n_left) does not fit the kind of model loaded for its width is answered with PNN_E_ARG / PNN_E_MODEL
