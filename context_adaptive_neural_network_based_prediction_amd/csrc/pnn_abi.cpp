@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 
 using namespace pnn;
 
@@ -57,6 +58,13 @@ int fail(pnn_ctx* c, int code, const char* fmt, ...)
 
 namespace {
 
+// While ONE thread captures a launch chain (host_predict, option "graphs"), no other thread of the process may allocate, free or copy
+// synchronously: in this runtime such a call invalidates the capture whatever the capture mode (thread-local: one HM run in five,
+// relaxed: two in three -- the reference's HM loads its five graphs on five threads while the main thread is already predicting).
+// Everything of that kind that this library does takes the lock; a capture holds it from begin to end.
+std::recursive_mutex& unsafe_calls_lock() { static std::recursive_mutex m; return m; }
+#define PNN_UNSAFE_CALLS_GUARD std::lock_guard<std::recursive_mutex> unsafe_guard_(unsafe_calls_lock())
+
 void cache_clear(pnn_ctx* c)                          // (every option change / model load: cached predictions and captured launch chains go)
 {
     for (auto& t : c->cache) { t.clear(); t.shrink_to_fit(); }
@@ -71,6 +79,7 @@ namespace pnn {
 int dev_reserve(pnn_ctx* c, DevBuf& b, size_t bytes)
 {
     if (b.bytes >= bytes) return PNN_OK;
+    PNN_UNSAFE_CALLS_GUARD;
     // a buffer moves: every captured launch chain of this context carries the old address in its kernels' arguments
     for (auto& kv : c->graphs) if (kv.second.exec) { (void)hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; kv.second.uses = 0; }
     if (b.p) HIPCHK(c, hipFree(b.p));
@@ -209,6 +218,7 @@ extern "C" {
 
 int pnn_create_empty(pnn_ctx** out, float mean, int device)
 {
+    PNN_UNSAFE_CALLS_GUARD;
     if (!out) return fail(nullptr, PNN_E_ARG, "`out` is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -270,6 +280,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
 
 int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params, size_t n)
 {
+    PNN_UNSAFE_CALLS_GUARD;
     if (!c || !params) return fail(c, PNN_E_ARG, "NULL argument");
     const int idx = width_index(width);
     if (idx < 0) return fail(c, PNN_E_ARG, "width %d is not in {4, 8, 16, 32, 64}", width);
@@ -286,6 +297,7 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
 
 int pnn_load_model_file(pnn_ctx* c, const char* path)
 {
+    PNN_UNSAFE_CALLS_GUARD;
     if (!c || !path) return fail(c, PNN_E_ARG, "NULL argument");
     std::vector<char> data;
     if (!read_file(path, &data)) return fail(c, PNN_E_IO, "The model file at \"%s\" cannot be loaded.", path);
@@ -342,6 +354,7 @@ int pnn_create(pnn_ctx** out, const char* table_path, int use_pair, float mean, 
 void pnn_destroy(pnn_ctx* c)
 {
     if (!c) return;
+    PNN_UNSAFE_CALLS_GUARD;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     cache_clear(c);
@@ -394,6 +407,7 @@ int pnn_num_f32_configs(void) { return tapgemm_f32_num_cfgs(); }
 int pnn_set_option(pnn_ctx* c, const char* name, long value)
 {
     if (!c || !name) return PNN_E_ARG;
+    PNN_UNSAFE_CALLS_GUARD;
     if (!strcmp(name, "max_chunk")) c->opt_max_chunk = value;
     else if (!strcmp(name, "canonical_order")) {       // kept as a name: one summation order at every batch size is the only mode since round 5
         if (value != 1) return fail(c, PNN_E_ARG, "canonical_order = %ld: the kernels with another summation order were removed; 1 is the only mode", value);
@@ -685,7 +699,7 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     // than H2D + D2H copies; at these sizes the PCIe reads hide under the weight stream).
     constexpr size_t kPinIn = 64 << 10, kPinOut = 64 << 10;
     if (in_a <= kPinIn && in_l <= kPinIn && (size_t)n * w2 * 4 <= kPinOut) {
-        if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 2 * kPinIn + 2 * kPinOut, hipHostMallocDefault));
+        if (!c->h_pin) { PNN_UNSAFE_CALLS_GUARD; HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 2 * kPinIn + 2 * kPinOut, hipHostMallocDefault)); }
         char* hp = c->h_pin;
         memcpy(hp, above, in_a);
         if (in_l) memcpy(hp + kPinIn, left, in_l);
@@ -712,6 +726,14 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         if (ge && !ge->failed && !ge->exec && ge->uses >= 1) {
             inline_input = false;
             hipGraph_t g = nullptr;
+            // The stream must be IDLE when the capture begins: a host call returns when its last kernel has raised the completion flag,
+            // which is before the runtime has retired that kernel (or the previous shape's graph launch) -- and a capture begun in that
+            // window came back "invalidated" once in a few hundred HM encodes (tests/test_hm.py under PNN_GRAPHS=1), leaving the stream
+            // unusable for plain launches too.
+            (void)hipStreamSynchronize(s);
+            if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+            // (thread-local mode; the other threads' allocations and copies are kept out by the lock, see unsafe_calls_lock)
+            std::lock_guard<std::recursive_mutex> capture_guard(unsafe_calls_lock());
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 rc = pass(0, n);                          // nothing runs: the launches are recorded
@@ -854,6 +876,7 @@ void pnn_streams_release(void** streams, int n)
 
 int pnn_host_alloc(void** out, size_t bytes)
 {
+    PNN_UNSAFE_CALLS_GUARD;
     if (!out || !bytes) return PNN_E_ARG;
     *out = nullptr;
     if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc(%zu) failed", bytes); }
@@ -862,6 +885,7 @@ int pnn_host_alloc(void** out, size_t bytes)
 
 void pnn_host_free(void* p)
 {
+    PNN_UNSAFE_CALLS_GUARD;
     if (p) (void)hipHostFree(p);
 }
 

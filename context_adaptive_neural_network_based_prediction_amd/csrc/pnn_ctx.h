@@ -115,9 +115,11 @@ struct pnn_ctx {
         double stat_gemm_flops = 0, stat_gemm_flops_skipped = 0;
     };
     std::map<std::tuple<const void*, int, int>, GraphEntry> graphs;
-    // Off by default: the gain is 1-4 us of a 38-233 us call for a thread that calls alone and nothing behind the batching service, and
-    // one run of the GPU test suite in five saw a capture invalidated inside an HM encoder ("operation failed due to a previous error
-    // during capture", tests/test_hm.py::test_hm_with_the_trained_checkpoints; not reproduced in isolation).
+    // Off by default: the gain is 2-5 us of a 38-235 us call for a thread that calls alone and nothing behind the batching service, and
+    // in this runtime a capture is INVALIDATED -- and its stream left unusable -- when any other thread of the process allocates, frees or
+    // copies synchronously meanwhile, whatever the capture mode (the reference's HM loads its graphs on threads of their own: one HM run in
+    // five failed).  The library's own such calls take a process-wide lock that a capture holds (unsafe_calls_lock, pnn_abi.cpp: 80 HM
+    // runs without a failure); a host application's own HIP calls on other threads are not covered, hence opt-in.
     long opt_graphs = 0;
     void* d_zero = nullptr;                           // 4 KiB of zeros: padding source of the LDS-DMA ring GEMM
     long opt_max_chunk = 0;

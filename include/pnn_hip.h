@@ -121,7 +121,9 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "graphs"               0   1: small host calls (<= 64 blocks): the launch chain of a shape (model, blocks, result kinds) is captured
  *                              on its second call and replayed with one hipGraphLaunch afterwards -- same kernels, same arguments,
  *                              same bits; a single-block call 1-4 us shorter for a thread that calls alone, nothing behind the
- *                              batching service.  Off by default (a rare capture failure inside an HM encoder, not yet explained)
+ *                              batching service.  Off by default: in this runtime a capture is invalidated when ANOTHER thread of the
+ *                              process allocates / frees / copies synchronously meanwhile; the library's own such calls are
+ *                              serialised against captures, a host application's own HIP calls are not
  *   "max_chunk" 0 (blocks per pass, 0 = by workspace), "ws_cap_mb" 8192, "time_launches" 0 (HIP events around every tap-GEMM launch)
  */
 int pnn_set_option(pnn_ctx* ctx, const char* name, long value);
