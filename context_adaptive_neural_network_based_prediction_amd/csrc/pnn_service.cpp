@@ -119,7 +119,7 @@ int ctx_backend(void* user, int width, const float* above, const float* left, in
 struct ClientCacheEntry { uint64_t hash = 0; bool valid = false; std::vector<char> in, vals; };
 struct pnn_client {
     int fd;
-    std::vector<char> buf;
+    std::vector<char> buf, rbuf;                      // request / reply bytes
     size_t cache_bytes = 0;                           // 0 = off
     std::vector<ClientCacheEntry> cache[5][2];
     long hits = 0, misses = 0;
@@ -764,11 +764,23 @@ static int client_call(pnn_client* c, int width, const float* above, const float
         ++c->misses;
     }
     if (!write_all(c->fd, c->buf.data(), c->buf.size())) return PNN_E_IO;
+    // the reply in ONE recv where the kernel has it whole (the server sends header and values with one send; an error reply is the
+    // header alone, so the first recv must not insist on more than a header).  Its own buffer: `buf` still holds the request's bytes,
+    // which become the cache entry's key below.
     RspHeader r;
-    if (!read_all(c->fd, &r, sizeof r)) return PNN_E_IO;
+    c->rbuf.resize(sizeof r + (size_t)w2 * 4);
+    size_t got = 0;
+    while (got < sizeof r) {
+        const ssize_t k = recv(c->fd, c->rbuf.data() + got, c->rbuf.size() - got, 0);
+        if (k == 0) return PNN_E_IO;
+        if (k < 0) { if (errno == EINTR) continue; return PNN_E_IO; }
+        got += (size_t)k;
+    }
+    memcpy(&r, c->rbuf.data(), sizeof r);
     if (r.rc != 0) return r.rc;
     if (r.n_vals != w2) return PNN_E_IO;
-    if (!read_all(c->fd, vals, (size_t)w2 * 4)) return PNN_E_IO;
+    if (got < c->rbuf.size() && !read_all(c->fd, c->rbuf.data() + got, c->rbuf.size() - got)) return PNN_E_IO;
+    memcpy(vals, c->rbuf.data() + sizeof r, (size_t)w2 * 4);
     if (slot) {
         slot->in.assign(in, in + in_bytes);
         slot->vals.assign(static_cast<const char*>(vals), static_cast<const char*>(vals) + (size_t)w2 * 4);
