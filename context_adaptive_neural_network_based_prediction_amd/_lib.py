@@ -33,6 +33,7 @@ SERVICE_SIGNATURES = {
     "pnn_client_predict_pel": (ci, [vp, ci, f32p, f32p, i32p, ci]),
     "pnn_client_predict_f32": (ci, [vp, ci, f32p, f32p, f32p]),
     "pnn_client_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
+    "pnn_client_arithmetic_tag": (ci, [vp, ci, ctypes.c_char_p, ctypes.c_size_t]),
     "pnn_client_close": (None, [vp]),
 }
 
@@ -95,6 +96,8 @@ def lib():
                 pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(SERVICE_SIGNATURES.items()):
+            if os.environ.get("PNN_LIB_PATH") and not hasattr(L, name):
+                continue                               # an A/B build of an older revision (tools/ab.sh): it lacks the newer entry points
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -395,7 +395,7 @@ int pnn_arithmetic_tag(const pnn_ctx* c, char* out, size_t bytes)
     // everything that decides the last float bits of a prediction: the arithmetic, its per-output summation order, the library's
     // order revision (bumped whenever a kernel change moves a bit)
     if (c->opt_precision == 0)
-        snprintf(out, bytes, "pnn-order-5:f32:fmaf-chain k=0,8,1,9..7,15 per 16:kseg %d/%d:fc-out-seg 160", kSegDepth, kSegMinDepth);
+        snprintf(out, bytes, "pnn-order-6:f32:fmaf-chain k=0,8,1,9..7,15 per 16:kseg %d/%d:fc-kseg %d:fc-out-seg 160", kSegDepth, kSegMinDepth, 16 * kFcSegChunks);
     else
         snprintf(out, bytes, "pnn-order-5:split-f16x3:hi*hi,hi*lo,lo*hi per 16:fc-out-seg %d", 16 * kFuseSegChunks);
     return PNN_OK;
@@ -770,11 +770,56 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
             c->stat_gemm_flops = ge->stat_gemm_flops; c->stat_gemm_flops_skipped = ge->stat_gemm_flops_skipped;
             replay = true;
         }
+#ifdef PNN_F32_DIAG                                 // diagnostic library only: PNN_B1_STAMPS=<k> prints the device-side timeline of this context's k-th small call
+        static const long stamp_call = getenv("PNN_B1_STAMPS") ? atol(getenv("PNN_B1_STAMPS")) : 0;
+        static thread_local long stamp_calls = 0;
+        const bool stamping = stamp_call > 0 && ++stamp_calls == stamp_call && !replay;
+        if (stamping) {
+            const size_t bytes = (size_t)pnn_ctx::kDiagLaunches * pnn_ctx::kDiagWgs * 64;
+            if (!c->diag_stamps) HIPCHK(c, hipMalloc(&c->diag_stamps, bytes));
+            HIPCHK(c, hipMemset(c->diag_stamps, 0, bytes));
+            HIPCHK(c, hipDeviceSynchronize());
+            c->diag_launch = 0; c->diag_names.clear(); c->diag_wgs.clear(); c->diag_k.clear();
+        }
+        void* const stamps_keep = c->diag_stamps;
+        if (!stamping) c->diag_stamps = nullptr;          // diag_stamp_slot hands out slots only during the stamped call
+#endif
         if (!replay) {
             reset_stats(c);
             rc = pass(0, n);
             if (ge) ge->uses++;
         }
+#ifdef PNN_F32_DIAG
+        c->diag_stamps = stamps_keep;
+        if (stamping && rc == PNN_OK) {
+            timespec tw0, tw1;
+            clock_gettime(CLOCK_MONOTONIC, &tw0);
+            const int wrc = c->done_armed ? wait_done_flag(c, s, n) : wait_stream(c, s);
+            clock_gettime(CLOCK_MONOTONIC, &tw1);
+            if (wrc) return wrc;
+            HIPCHK(c, hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)c->diag_launch * pnn_ctx::kDiagWgs * 8);
+            HIPCHK(c, hipMemcpy(h.data(), c->diag_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t00 = ~0ull;
+            for (int l = 0; l < c->diag_launch; l++) for (int i = 0; i < c->diag_wgs[l]; i++) { const unsigned long long e = h[((size_t)l * pnn_ctx::kDiagWgs + i) * 8 + 4]; if (e && e < t00) t00 = e; }
+            fprintf(stderr, "[pnn-stamps] width %d, %d block(s): %d stamped launches (us from the first workgroup's entry; per launch: first / median / last over its workgroups); host wait after the last launch call %.1f us\n",
+                    w, n, c->diag_launch, (tw1.tv_sec - tw0.tv_sec) * 1e6 + (tw1.tv_nsec - tw0.tv_nsec) * 1e-3);
+            for (int l = 0; l < c->diag_launch; l++) {
+                std::vector<double> ent, ls, le, ex;
+                for (int i = 0; i < c->diag_wgs[l]; i++) {
+                    const unsigned long long* d = &h[((size_t)l * pnn_ctx::kDiagWgs + i) * 8];
+                    if (!d[4]) continue;
+                    ent.push_back((double)(d[4] - t00) / 100.0);
+                    if (d[3]) { ls.push_back((double)(d[3] - t00) / 100.0); le.push_back((double)(d[3] + d[1] - t00) / 100.0); }
+                    if (d[5]) ex.push_back((double)(d[5] - t00) / 100.0);
+                }
+                auto fml = [](std::vector<double>& v, char* buf) { if (v.empty()) { snprintf(buf, 64, "      -      "); return; } std::sort(v.begin(), v.end()); snprintf(buf, 64, "%5.1f /%5.1f /%5.1f", v.front(), v[v.size() / 2], v.back()); };
+                char b0[64], b1[64], b2[64], b3[64];
+                fml(ent, b0); fml(ls, b1); fml(le, b2); fml(ex, b3);
+                fprintf(stderr, "[pnn-stamps]  %-28s K %5.0f %4d WGs (%zu stamped) | entry %s | chain start %s | chain end %s | exit %s\n", c->diag_names[l].c_str(), c->diag_k[l], c->diag_wgs[l], ent.size(), b0, b1, b2, b3);
+            }
+        }
+#endif
         inline_input = true;                          // (the range fallback's passes are plain launches)
         c->done_want = false;
         if (rc) return rc;

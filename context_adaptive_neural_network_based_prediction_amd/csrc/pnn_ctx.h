@@ -56,6 +56,9 @@ struct GemmLayer {                                    // one tap-GEMM launch (al
     // class's taps dealt in order over the segments; within a segment the sequential chain of tapgemm_f32_kernel), added in
     // order, then bias and activation.  A property of the layer (pnn_model.cpp), the same at every batch size and tile.
     int nseg = 1;
+    // ... and of a ONE-TAP (FC) layer deeper than kFcSegChunks chunks (round 6): segments of fc_seg_chunks 16-deep chunks of its K, added
+    // in order inside the workgroup that computes them (never planes); 0 = the layer is one chain
+    int fc_seg_chunks = 0;
     long out_per_block = 0;                           // output floats per block
 };
 struct Conv1Layer { Conv1Params proto{}; float* d_w = nullptr; float* d_w_sp = nullptr; float sp_inv_scale = 1.f; int npad = 0; float* d_bias = nullptr; long out_per_block = 0; };
@@ -134,7 +137,7 @@ struct pnn_ctx {
     // exact-f32 launches of few output tiles (the in-loop single-block calls, the service's handfuls): tapgemm_f32_small_kernel, the same
     // fmaf chain on the 16x16x4 instruction (10 instead of 32 cycles per k of the dependent chain), pnn_gemm_f32_small.hip
     long opt_f32_small = 1;
-    long opt_fc_out_f32 = 1;                          // 1: exact-f32 FC passes of <= 512 blocks run the output layer's K segments and their reduction as ONE launch
+    long opt_fc_out_f32 = 1;                          // 1: exact-f32 FC passes of <= 512 blocks run the output layer's K segments and their reduction as ONE launch (2: its round-5 form on the 32x32x2 instruction)
     // 1: the K segments of a layer that runs on the small exact-f32 kernel are added up inside its launch (the last workgroup of a tile
     // to arrive, see tapgemm_f32_small_body) instead of by a seg_reduce launch behind it: the same additions in the same order
     long opt_seg_fold = 1;
@@ -199,6 +202,13 @@ struct pnn_ctx {
     double wait_ema_us[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // by floor(log2(blocks))
     long opt_ring_pm = 1;                             // ring kernel: position-major tiles that skip the taps in the padding (pnn_gemm_ring.hip)
     size_t ws_cap_bytes = (size_t)8 << 30;
+    // diagnostic library only (make diag, PNN_B1_STAMPS=<call number>): per-workgroup 100 MHz stamps of the kernels of one small host call
+    static constexpr int kDiagLaunches = 32, kDiagWgs = 2048;
+    void* diag_stamps = nullptr;
+    int diag_launch = 0;
+    std::vector<std::string> diag_names;
+    std::vector<int> diag_wgs;
+    std::vector<double> diag_k;
     std::string err;
     int stat_gemm_launches = 0, stat_launches = 0;
     double stat_gemm_flops = 0;
@@ -242,6 +252,7 @@ inline DoneSignal take_done_signal(pnn_ctx* c)
 int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const std::function<bool(int)>& legal,
               const std::function<hipError_t(int)>& launch, hipStream_t s, int* cfg, float* best_us);
 // pnn_passes.cpp
+void* diag_stamp_slot(pnn_ctx* c, const char* name, long wgs, double k);
 long chunk_blocks(const pnn_ctx* c, const Model* m);
 bool pass_uses_split(const pnn_ctx* c, const Model* m, long nb);
 bool conv_pass_fuses_first(pnn_ctx* c, Model* m, long nb);

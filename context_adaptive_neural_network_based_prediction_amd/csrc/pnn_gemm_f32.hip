@@ -66,12 +66,18 @@ __device__ __forceinline__ void wait_vm_le()
 // SEQ: K segments one after the other inside the workgroup (p.seg_seq; big launches, where more workgroups buy nothing): the
 // stages of all segments run as ONE pipeline, and where a segment ends the accumulators are folded into a running total --
 // total = (p0 + p1) + ..., the order seg_reduce_kernel adds the planes in -- so both forms give the same bits.
+// It is the ONLY form of a segmented one-tap (FC) layer (round 6, GemmLayer::fc_seg_chunks: segments of p.seg_chunks chunks of the
+// tap), with the fused output layer too: the fold leaves the layer's sums in `acc`, the epilogues follow.  SEQ = 1: the general form
+// (segments of whole taps, a fold wherever a stage ends one: the convolution layers); SEQ = 2: a one-tap layer whose segments are an
+// EVEN number of stages -- an outer loop over the segments around the plain kernel's two-stage loop, the fold between two inner loops.
+// (Why two forms: with the fold behind a test after every stage the compiler carries the accumulators through a copy per stage -- 80
+// v_accvgpr_mov per 160 MFMAs, 3 % of an FC layer at batch 4096, FC 8x8 18.1 M -> 17.3 M blocks/s whatever the number of folds,
+// profiles/r06_fcseg_ab.txt; the folds themselves are 0.5 us each per layer.)
 // One tile (bx, by, bz) of the launch's gx x gy x gz tiles -- what a workgroup of the plain launch does once and a workgroup of a
 // PERSISTENT launch (fewer workgroups than tiles, tapgemm_f32_kernel below) does for one tile after the other.
-template <int RT, int NT, int KC, bool FUSE, bool SEQ>
+template <int RT, int NT, int KC, bool FUSE, int SEQ>
 __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const lds, const int bx, const int by, const int bz, const int gx, const int gy)
 {
-    static_assert(!(FUSE && SEQ), "the fused output layer belongs to FC layers, which are never segmented");
     static_assert(KC >= 2 && KC % 2 == 0, "fragment sets alternate by chunk parity");
     constexpr int BM = 128 * RT, BN = 32 * NT;
     constexpr int E = 4 * BN;                        // 16-byte pieces per staged weight chunk: [q = 4][BN]
@@ -167,12 +173,12 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
     const int nstages = (nchunks + KC - 1) / KC;     // the packed weights are zero-padded to whole stages (kChunkPad)
     // SEQ: stages of segment k = its live taps x (cpt / KC) (a segmented layer has whole stages per tap); fold_at = the stage count at
     // which the running segment ends (segments without a live tap end where they begin and fold nothing)
-    const int sq_n = SEQ ? p.nseg : 1, sq_base = (t1 - t0) / sq_n, sq_rem = (t1 - t0) - sq_base * sq_n;
+    const int sq_n = SEQ == 1 ? p.nseg : 1, sq_base = (t1 - t0) / sq_n, sq_rem = (t1 - t0) - sq_base * sq_n;
     auto seg_stages = [&](int k) {
         const unsigned mk = ((1u << (sq_base + (k < sq_rem ? 1 : 0))) - 1u) << (k * sq_base + (k < sq_rem ? k : sq_rem));
         return __builtin_popcount(tmask & mk) * (cpt / KC);
     };
-    int sq_k = 0, fold_at = SEQ ? seg_stages(0) : 0, sq_done = 0;
+    int sq_k = 0, fold_at = SEQ == 1 ? seg_stages(0) : 0, sq_done = 0;
 
     // ---- weights: this lane's pieces of a stage (LDS-DMA: lane-linear destination, per-lane source) ------------------------
     const unsigned wbytes = (unsigned)p.chunk_begin[p.ncls] * 4u * (unsigned)p.Npad * 16u;
@@ -250,10 +256,11 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
                 acc[rt][nt][i] = 0.f;
                 if (SEQ) total[SEQ ? rt : 0][SEQ ? nt : 0][i] = 0.f;
             }
-    auto after_stage = [&]() {                       // SEQ: a full stage is done; where its segment ends, fold (wave-uniform)
-        if (!SEQ) return;
-        ++sq_done;
-        if (sq_done != fold_at || sq_k >= sq_n - 1) return;
+    // SEQ = 1: a full stage is done; where its segment ends with it, fold (wave-uniform): total += acc, acc = 0.
+    // (Round 6, tried and removed: the fold INSIDE the next stage's first k-step -- per accumulator tile, its first MFMA taking a zero
+    // addend -- needs a second form of the stage body; with it the register allocator spilled 199 VGPRs and FC 8x8 at batch 4096 lost
+    // 10 %, profiles/r06_fcseg_ab.txt.)
+    auto fold_now = [&]() {
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -263,6 +270,12 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
                     total[SEQ ? rt : 0][SEQ ? nt : 0][i] += acc[rt][nt][i];
                     acc[rt][nt][i] = 0.f;
                 }
+    };
+    auto after_stage = [&]() {
+        if (SEQ != 1) return;
+        ++sq_done;
+        if (sq_done != fold_at || sq_k >= sq_n - 1) return;
+        fold_now();
         do { ++sq_k; fold_at += seg_stages(sq_k); } while (fold_at == sq_done && sq_k < sq_n - 1);
     };
 
@@ -373,7 +386,21 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
     };
     const int nlive = nchunks - (nstages - 1) * KC;
     int s = 0, buf = 0;
-    if (SEQ) while (fold_at == 0 && sq_k < sq_n - 1) { ++sq_k; fold_at += seg_stages(sq_k); }   // leading segments without a live tap
+    if (SEQ == 1) while (fold_at == 0 && sq_k < sq_n - 1) { ++sq_k; fold_at += seg_stages(sq_k); }   // leading segments without a live tap
+    if constexpr (SEQ == 2) {
+        // every segment but the last: seg_chunks / KC stages (even), the plain two-stage loop, then the fold
+        const int spp = (int)p.seg_chunks / KC;
+        for (int k = 0; k + 1 < p.nseg; k++) {
+            for (int i = 0; i < spp; i += 2) {
+                stage(buf, a0, a1);
+                buf = buf == 2 ? 0 : buf + 1;
+                stage(buf, a1, a0);
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+            s += spp;
+            fold_now();
+        }
+    }
     for (; s + 2 < nstages; s += 2) {
         stage(buf, a0, a1);
         buf = buf == 2 ? 0 : buf + 1;
@@ -528,7 +555,7 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
 // The launch: a 1-D grid over the gx x gy x gz tiles in the order a 3-D grid is dispatched (x fastest; tile i runs on XCD i % 8 either
 // way).  Plain launch: one workgroup per tile.  PERSISTENT launch (launch_f32: fewer workgroups than tiles, at most one or two per
 // CU): workgroup w takes tiles w, w + G, w + 2 G, ... -- see launch_f32 for when.
-template <int RT, int NT, int KC, bool FUSE, bool SEQ = false>
+template <int RT, int NT, int KC, bool FUSE, int SEQ = 0>
 __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const TapGemmParams p)
 {
     touch_kernargs<sizeof(TapGemmParams)>();
@@ -611,6 +638,10 @@ struct FcOutF32Args { TapGemmParams p; DoneSignal done; };
 __global__ __launch_bounds__(512) void fc_out_f32_small_kernel(const FcOutF32Args a)
 {
     touch_kernargs<sizeof(FcOutF32Args)>();
+#ifdef PNN_F32_DIAG
+    const unsigned long long de0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dr0 = 0, dr1 = 0;
+#endif
     const TapGemmParams& p = a.p;
     constexpr int NT = 5;
     __shared__ __attribute__((aligned(16))) float part[8][32][32];
@@ -637,6 +668,10 @@ __global__ __launch_bounds__(512) void fc_out_f32_small_kernel(const FcOutF32Arg
                 w2[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)((n >> 2) * p.Npad + ot * 32 + l31) << 4, 0, 0));
             }
         __builtin_amdgcn_sched_barrier(0);           // every request before the first MFMA: ONE memory latency, not one per block
+#ifdef PNN_F32_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -646,6 +681,9 @@ __global__ __launch_bounds__(512) void fc_out_f32_small_kernel(const FcOutF32Arg
 #pragma unroll
         for (int g = 0; g < 4; g++)
             *reinterpret_cast<f32x4*>(&part[z][l31][8 * g + 4 * h]) = (f32x4){acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
+#ifdef PNN_F32_DIAG
+        dr1 = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     __syncthreads();
     const int mr = tid >> 3, nl = (tid & 7) << 2, n = ot * 32 + nl;
@@ -657,17 +695,118 @@ __global__ __launch_bounds__(512) void fc_out_f32_small_kernel(const FcOutF32Arg
         if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
+#ifdef PNN_F32_DIAG
+    const unsigned long long dr2 = __builtin_amdgcn_s_memrealtime();
+#endif
     signal_done(a.done);
+#ifdef PNN_F32_DIAG
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        d[1] = dr1 - dr0; d[3] = dr0; d[4] = de0; d[5] = __builtin_amdgcn_s_memrealtime(); d[6] = dr2;
+    }
+#endif
+}
+
+// Round 6: the same output layer, segments and reduction on v_mfma_f32_16x16x4_f32 -- the last kernel of a single-block FC call was its
+// slowest (profiles/r05_batch1_w8_f32_timeline.txt: 10.9 us of 34.9) with its 160-deep segment chains as 80 dependent 64-cycle
+// instructions.  The chain of segment z, per (column tile nt, group g) of the fused kernel: hidden units 8g + 0, 4, 1, 5, 2, 6, 3, 7
+// (step r of the 32x32x2 instruction adds unit 8g + r from lane half 0, then 8g + 4 + r from lane half 1) -- through the 16x16x4
+// form that is two instructions whose lane groups q = 0..3 supply units 8g + 4 (q & 1) + 2 i + (q >> 1), i = 0, 1: 40 dependent
+// instructions of 32 cycles per segment instead of 80 of 64, the same fmaf chain bit for bit (the f32 matrix instructions are a
+// k-ordered fmaf chain, one rounding per product: pnn_gemm_f32_small.hip).  One workgroup of 8 waves per 16 x 16 output tile (a
+// single 8x8 block: four workgroups instead of two), wave z = K segment z; each lane requests its 20 + 20 sixteen-byte operand pieces
+// up front (ONE memory latency) and keeps the two elements of each that its lane group multiplies; the partial sums meet in LDS and
+// wave 0 adds them in segment order, + bias, HM epilogue -- fuse_reduce_kernel's arithmetic.
+__global__ __launch_bounds__(512) void fc_out_f32_chain_kernel(const FcOutF32Args a)
+{
+    touch_kernargs<sizeof(FcOutF32Args)>();
+#ifdef PNN_F32_DIAG
+    const unsigned long long de0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const TapGemmParams& p = a.p;
+    constexpr int NT = 5;
+    __shared__ __attribute__((aligned(16))) float part[8][16][16];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int z = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mblk = blockIdx.x * 16, nblk = blockIdx.y * 16;
+    const int segs = (p.Cin + 159) / 160;
+    const bool odd = (q >> 1) != 0;                  // this lane group multiplies elements 1 and 3 of its pieces (else 0 and 2)
+#ifdef PNN_F32_DIAG
+    unsigned long long dr0 = 0, dr1 = 0;
+#endif
+    if (z < segs) {
+        const int m = mblk + l15, n0 = z * 32 * NT;
+        const bool mv = m < p.M;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)p.chunk_begin[1] * 4u * (unsigned)p.Npad * 16u, 0x00020000);
+        f32x4 x[NT][4], w2[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + 32 * nt + 8 * g + 4 * (q & 1);
+                // activations past Cin (the last segment: 1120 + 160 > 1200) and rows past M read zeros, weights past the pack too
+                const unsigned xo = (mv && n < p.Cin) ? ((unsigned)m * (unsigned)p.Cin + (unsigned)n) << 2 : 0x80000000u;
+                x[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0));
+                w2[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)((n >> 2) * p.Npad + nblk + l15) << 4, 0, 0));
+            }
+        __builtin_amdgcn_sched_barrier(0);           // every request before the first use: ONE memory latency, not one per piece
+        float xs[NT][4][2], ws[NT][4][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                xs[nt][g][0] = odd ? x[nt][g][1] : x[nt][g][0]; xs[nt][g][1] = odd ? x[nt][g][3] : x[nt][g][2];
+                ws[nt][g][0] = odd ? w2[nt][g][1] : w2[nt][g][0]; ws[nt][g][1] = odd ? w2[nt][g][3] : w2[nt][g][2];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PNN_F32_DIAG
+        dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[nt][g][0], xs[nt][g][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[nt][g][1], xs[nt][g][1], acc, 0, 0, 0);
+            }
+        // lane (l15, q): row m = l15, outputs nblk + 4 q + r
+        *reinterpret_cast<f32x4*>(&part[z][l15][4 * q]) = acc;
+#ifdef PNN_F32_DIAG
+        dr1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    __syncthreads();
+    const int mg = mblk + l15, n = nblk + 4 * q;
+    if (z == 0 && mg < p.M && n < p.Cout) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < segs; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][l15][4 * q]);
+        const f32x4 v = sum + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
+        if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    }
+#ifdef PNN_F32_DIAG
+    const unsigned long long dr2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    signal_done(a.done);
+#ifdef PNN_F32_DIAG
+    if (p.Xlo && tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.Xlo + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        d[1] = dr1 - dr0; d[3] = dr0; d[4] = de0; d[5] = __builtin_amdgcn_s_memrealtime(); d[6] = dr2;
+    }
+#endif
 }
 
 // p: the output layer as a one-tap GEMM (X = f32 activations [M][Cin], Wp = its f32 pack, bias, mean, Y / Yi).  false: not this kernel's case.
 bool fc_out_f32_small_fits(const TapGemmParams& p) { return p.ncls == 1 && p.SH * p.SW == 1 && p.Cout <= 64 && p.Cout % 4 == 0 && (p.Cin + 159) / 160 <= 8 && p.M > 0; }
 
-hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done)
+hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done, bool round5_form)
 {
     if (!fc_out_f32_small_fits(p)) return hipErrorInvalidValue;
     const FcOutF32Args a{p, done};
-    pnn_launch(fc_out_f32_small_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)((p.Cout + 31) / 32)), dim3(512), 0, s, a);
+    if (round5_form) pnn_launch(fc_out_f32_small_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)((p.Cout + 31) / 32)), dim3(512), 0, s, a);
+    else pnn_launch(fc_out_f32_chain_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), 0, s, a);
     return hipGetLastError();
 }
 
@@ -724,8 +863,9 @@ bool tapgemm_f32_can_fuse(int idx) { return kCfgsF32[idx].rt == 1 && kCfgsF32[id
 template <int RT, int NT, int KC>
 static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
 {
-    const bool seq = !fuse && p0.nseg > 1 && p0.seg_seq;
-    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls * (!fuse && !seq && p0.nseg > 1 ? p0.nseg : 1));
+    const bool seq = p0.nseg > 1 && p0.seg_seq;
+    if (fuse && p0.nseg > 1 && !seq) return hipErrorInvalidValue;       // planes of partial sums cannot feed the fused output layer
+    dim3 grid((p0.M + 128 * RT - 1) / (128 * RT), (p0.Cout + 32 * NT - 1) / (32 * NT), p0.ncls * (!seq && p0.nseg > 1 ? p0.nseg : 1));
     const TileCfg t{RT, NT, KC, 32};
     TapGemmParams p = p0;
     p.pm_groups = 0;
@@ -784,7 +924,18 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
         if (e == hipSuccess) done[dev] = 1;
         return e;
     };
+    const bool one_tap = p0.ncls == 1 && p0.tap_begin[1] - p0.tap_begin[0] == 1;
+    // whole stages per segment; a one-tap layer: an EVEN number of them, and a last segment that is not empty (SEQ = 2, see f32_tile)
+    if (seq && (one_tap ? (p0.seg_chunks == 0 || p0.seg_chunks % (2 * KC) || (long)(p0.nseg - 1) * p0.seg_chunks >= p0.Cin / 16) : ((p0.Cin / 16) % KC) != 0)) return hipErrorInvalidValue;
     if constexpr (RT == 1 && NT == 5) {
+        if (fuse && seq) {
+            if (!one_tap) return hipErrorInvalidValue;
+            static int done[16] = {};
+            const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, true, 2>, done);
+            if (e != hipSuccess) return e;
+            pnn_launch(tapgemm_f32_kernel<RT, NT, KC, true, 2>, g1, dim3(256), lds, s, p);
+            return hipGetLastError();
+        }
         if (fuse) {
             static int done[16] = {};
             const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, true>, done);
@@ -794,12 +945,18 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
         }
     }
     if (fuse) return hipErrorInvalidValue;
-    if (seq) {
-        if ((p0.Cin / 16) % KC) return hipErrorInvalidValue;      // whole stages per tap
+    if (seq && one_tap) {
         static int done[16] = {};
-        const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, true>, done);
+        const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, 2>, done);
         if (e != hipSuccess) return e;
-        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, true>, g1, dim3(256), lds, s, p);
+        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, 2>, g1, dim3(256), lds, s, p);
+        return hipGetLastError();
+    }
+    if (seq) {
+        static int done[16] = {};
+        const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, 1>, done);
+        if (e != hipSuccess) return e;
+        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, 1>, g1, dim3(256), lds, s, p);
         return hipGetLastError();
     }
     static int done[16] = {};

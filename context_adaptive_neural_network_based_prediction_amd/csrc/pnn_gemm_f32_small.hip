@@ -68,6 +68,9 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
 {
     constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, D = LA + 2;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
+#ifdef PNN_F32_DIAG                                 // diagnostic library only (make diag): 100 MHz stamps of the MFMA wave -> p.Xlo[workgroup][8]
+    const unsigned long long de0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
     // Which wave runs the MFMA chain rotates with the tile (role 0 = the chain, roles 1-3 = the loaders): a workgroup's wave i sits on
     // SIMD i, and with several small launches on the chip at once (the batching service's five width workers) two tiles that share a
@@ -232,10 +235,15 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     for (int k = 0; k + 1 < CS; k++) chunk(k, ring + (slot * CS + k + 1) * 128 + lane, k + 1, true);
     chunk(CS - 1, ring, 0, false);
 #ifdef PNN_F32_DIAG
-    if (p.Xlo && lane == 0) {
-        unsigned long long* d = (unsigned long long*)p.Xlo + 4 * ((bz * gridDim.y + by) * gridDim.x + bx);
-        d[0] = __builtin_amdgcn_s_memtime() - dq0; d[1] = __builtin_amdgcn_s_memrealtime() - dr0; d[2] = (unsigned long long)(c1 - c0); d[3] = dr0;
+    unsigned long long* const dstamp = p.Xlo ? (unsigned long long*)p.Xlo + 8 * ((bz * gy + by) * ((p.M + 15) >> 4) + bx) : nullptr;
+    if (dstamp && lane == 0) {
+        dstamp[0] = __builtin_amdgcn_s_memtime() - dq0; dstamp[1] = __builtin_amdgcn_s_memrealtime() - dr0; dstamp[2] = (unsigned long long)(c1 - c0); dstamp[3] = dr0;
+        dstamp[4] = de0;
     }
+    // (the exit stamp: behind the wave's last stores, acknowledged)
+#define F32S_DIAG_EXIT() do { if (dstamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dstamp[5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define F32S_DIAG_EXIT() do { } while (0)
 #endif
     // ---- epilogue: lane (q, l15) holds row m = l15, channels n0 + 4 q + r ----------------------------------------------------
     const int n = n0 + 4 * q;
@@ -261,9 +269,9 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         unsigned old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        if (old != (unsigned)nseg - 1u) return;
+        if (old != (unsigned)nseg - 1u) { F32S_DIAG_EXIT(); return; }
         if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-        if (!ok) return;
+        if (!ok) { F32S_DIAG_EXIT(); return; }
         // (GemmLayer::nseg <= 8) all planes requested, one wait, then the additions in plane order.  Loads and wait are ONE asm block:
         // the compiler must not touch a destination register (a copy, a select) while its load is in flight.  Planes past nseg: plane 0 again, unused.
         f32x4 pl[8];
@@ -282,15 +290,16 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
         *reinterpret_cast<f32x4*>(p.seg_Y + obase + n) = v;
+        F32S_DIAG_EXIT();
         return;
     }
-    if (!rowok) return;
-    if (n >= p.Cout) return;
+    if (!rowok || n >= p.Cout) { F32S_DIAG_EXIT(); return; }
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
     if (Yo) *reinterpret_cast<f32x4*>(Yo + obase + n) = v;
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    F32S_DIAG_EXIT();
 }
 
 // LA (stages of 3 chunks in flight ahead of the chain) is a template parameter: kF32SmallLA = 6 (48 KiB of ring: three workgroups per
@@ -334,6 +343,173 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32Sm
     tapgemm_f32_small_body<false, LA>(*p, r % gx, r / gx, bz, gy);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// K-segmented ONE-TAP (FC) layers at small M (round 6).  The device-side stamps of a single-block FC 8x8 call
+// (profiles/r06_b1_stamps_fc_out.txt) show each 1200-deep hidden layer as 1.3 us from entry to the first MFMA, 4.7 us of ONE dependent chain
+// of 75 chunks, 0.4 us until its stores are acknowledged -- on 75 of 256 CUs, with three of a CU's four matrix pipes idle.  The layer's
+// canonical order is therefore (GemmLayer::fc_seg_chunks, pnn_model.cpp) the sum of <= 4 K segments of kFcSegChunks chunks, each the
+// k-ordered fmaf chain of the kernel above, added up in order -- and here the FOUR chains of an output tile run side by side in ONE
+// workgroup: waves 0-3 are the chain waves (one per SIMD, segment = wave), waves 4-7 their loaders (loader j feeds chain j: a ring of its
+// own, CPL chunks per stage, LA stages ahead, the LDS-DMA forms of the kernel above), one s_barrier per stage for all eight.  The segment
+// sums meet in LDS and wave 0 adds them in order, + bias, activation -- total = ((p0 + p1) + p2) + p3, the bits of tapgemm_f32_kernel's
+// seg_seq form at any batch size (a chain sum that starts from +0 is never -0, so 0 + p0 = p0 there).  Short segments (the last of
+// 1200 = 3 x 320 + 240) and missing ones (nseg < 4) multiply zeros that their loaders' range misses deliver: fma(0, 0, acc) = acc.
+constexpr int kFcSegNS = 4, kFcSegLA = 5, kFcSegCPL = 2;
+static_assert(5 * kFcSegCPL * kFcSegLA < 64, "vmcnt is a 6-bit counter");
+constexpr size_t kFcSegLds = ((size_t)kFcSegNS * (kFcSegLA + 2) * kFcSegCPL * 128 + kFcSegNS * 64) * 16;
+
+__global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs args)
+{
+    touch_kernargs<sizeof(F32SmallArgs)>();
+    (void)args;
+    const auto* ka = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    CF32SmallParams& p = ka->p;
+    constexpr int NS = kFcSegNS, LA = kFcSegLA, CPL = kFcSegCPL, D = LA + 2;
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [NS chains][D stages][CPL chunks][weights 64 pieces | activations 64 pieces] | [NS][64] segment sums
+#ifdef PNN_F32_DIAG
+    const unsigned long long de0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, q = lane >> 4;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int n0 = by * 16;
+    const int cpt = p.Cin >> 4, segc = (int)p.seg_chunks;
+    const int sg = wave & (NS - 1);                   // the segment this wave runs (waves 0-3) or feeds (waves 4-7)
+    int c0 = sg * segc, c1 = c0 + segc;               // its chunks [c0, c1) of the tap
+    if (c0 > cpt) c0 = cpt;
+    if (c1 > cpt) c1 = cpt;
+    if (sg >= p.nseg) c1 = c0;
+    const int nst = (segc + CPL - 1) / CPL;           // the same number of stages (barriers) for all eight waves
+    f32x4* const myring = ring + sg * (D * CPL * 128);
+    f32x4* const part = ring + NS * (D * CPL * 128);
+
+    if (wave >= NS) {
+        // ---- loader of chain sg: LDS-DMA only.  Weights: piece (q, column l15) of the chain-ordered pack, one 16-byte instruction per
+        // chunk; activations (rows of [M][Cin]): lane l fetches element i = l & 3 of row l >> 2 for lane group g, four 4-byte instructions
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7fffffffu, 0x00020000);
+        const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
+        const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
+        constexpr unsigned kOob = 0x80000000u;
+        const int mx = bx * 16 + (lane >> 2);
+        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (unsigned)((lane & 3) << 3) : kOob;
+        int ci = c0;
+        auto issue = [&](int slot) {
+#pragma unroll
+            for (int u = 0; u < CPL; u++) {
+                f32x4* dst = myring + (slot * CPL + u) * 128;
+                const bool live = ci < c1;
+                const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
+                const unsigned ao = live ? apix : kOob;
+                const unsigned so = (unsigned)(ci << 6);
+                ci++;
+                f32s_dma16(wrsrc, wo, dst);
+                float* xd = reinterpret_cast<float*>(dst + 64);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+            }
+        };
+        constexpr int PER = 5 * CPL;
+#pragma unroll
+        for (int st = 0; st < LA; st++) issue(st);
+        f32s_wait_vm<PER * (LA - 1)>();              // stage 0 has landed
+        __builtin_amdgcn_s_barrier();
+        int slot = LA;
+        for (int st = 0; st + 1 < nst; st++) {
+            issue(slot);                             // stage st + LA into the slot stage st - 2 left
+            if (++slot == D) slot = 0;
+            f32s_wait_vm<PER * (LA - 1)>();          // stage st + 1 has landed
+            __builtin_amdgcn_s_barrier();
+        }
+        f32s_wait_vm<0>();                           // trailing (range-miss) DMAs must not outlive the workgroup's LDS
+        __builtin_amdgcn_s_barrier();                // the segment sums' barrier (below): every wave of the workgroup joins it
+        return;
+    }
+
+    // ---- chain wave of segment sg: two 16-byte LDS reads and four MFMAs per chunk, nothing else (see tapgemm_f32_small_body) ----
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_barrier();                    // stage 0 is in the rings
+    f32x4 fw[CPL], fx[CPL];
+    int slot = 0;
+    { const f32x4* src = myring + lane; fw[0] = src[0]; fx[0] = src[64]; }
+#ifdef PNN_F32_DIAG
+    const unsigned long long dq0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto chunk = [&](int k, const f32x4* nsrc, int kn, bool rd) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][0], fx[k][0], acc, 0, 0, 0);
+        if (rd) fw[kn] = nsrc[0];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][1], fx[k][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][2], fx[k][2], acc, 0, 0, 0);
+        if (rd) fx[kn] = nsrc[64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[k][3], fx[k][3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int st = 0; st + 1 < nst; st++) {
+        const int nslot = slot + 1 == D ? 0 : slot + 1;
+#pragma unroll
+        for (int k = 0; k + 1 < CPL; k++) chunk(k, myring + (slot * CPL + k + 1) * 128 + lane, k + 1, true);
+        __builtin_amdgcn_s_barrier();                // stage st + 1 is in the rings, the slot of stage st - 1 may be refilled
+        chunk(CPL - 1, myring + (nslot * CPL) * 128 + lane, 0, true);
+        slot = nslot;
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < CPL; k++) chunk(k, myring + (slot * CPL + k + 1) * 128 + lane, k + 1, true);
+    chunk(CPL - 1, myring, 0, false);
+#ifdef PNN_F32_DIAG
+    unsigned long long* const dstamp = (p.Xlo && wave == 0) ? (unsigned long long*)p.Xlo + 8 * (by * gridDim.x + bx) : nullptr;
+    if (dstamp && lane == 0) {
+        dstamp[0] = __builtin_amdgcn_s_memtime() - dq0; dstamp[1] = __builtin_amdgcn_s_memrealtime() - dr0; dstamp[2] = (unsigned long long)(c1 - c0); dstamp[3] = dr0;
+        dstamp[4] = de0;
+    }
+#endif
+    // ---- the segment sums meet in LDS; wave 0 adds them in order.  Lane (q, l15): row m = 16 bx + l15, channels n0 + 4 q + r ----
+    part[sg * 64 + lane] = acc;
+    __builtin_amdgcn_s_barrier();
+    if (wave != 0) return;
+    f32x4 t = part[lane];
+    for (int k = 1; k < p.nseg; k++) t += part[k * 64 + lane];
+    const int mg = bx * 16 + l15, n = n0 + 4 * q;
+    if (mg < p.M && n < p.Cout) {
+        f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+        const size_t o = (size_t)mg * p.Cout + n;
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o) = v;
+        if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    }
+#ifdef PNN_F32_DIAG
+    if (dstamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dstamp[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+long fcseg_f32_small_tiles(const TapGemmParams& p) { return (long)((p.M + 15) / 16) * ((p.Cout + 15) / 16); }
+bool fcseg_f32_small_fits(const TapGemmParams& p)
+{
+    return p.ncls == 1 && p.SH * p.SW == 1 && p.tap_begin[1] == 1 && p.nseg > 1 && p.nseg <= kFcSegNS && p.seg_chunks > 0 && p.Cout % 4 == 0 && p.M > 0;
+}
+
+hipError_t launch_fcseg_f32_small(const TapGemmParams& p, hipStream_t s)
+{
+    if (!fcseg_f32_small_fits(p)) return hipErrorInvalidValue;
+    static int done[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const int di = dev >= 0 && dev < 16 ? dev : 0;
+    if (!__atomic_load_n(&done[di], __ATOMIC_ACQUIRE)) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcSegLds)) != hipSuccess) return e;
+        __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
+    }
+    const F32SmallArgs a{p};
+    pnn_launch(fcseg_f32_small_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), kFcSegLds, s, a);
+    return hipGetLastError();
+}
+
 constexpr int kF32SmallLADeep = 12;
 static_assert(5 * kF32SmallCPL * kF32SmallLADeep < 64, "vmcnt is a 6-bit counter");
 size_t tapgemm_f32_small_lds_bytes(bool deep) { return (size_t)((deep ? kF32SmallLADeep : kF32SmallLA) + 2) * kF32SmallCS * 128 * 16; }
@@ -345,17 +521,18 @@ long tapgemm_f32_small_tiles(const TapGemmParams& p)
 
 static hipError_t f32_small_attrs()
 {
-    static int done_for = -1;                        // per device: the attribute belongs to the function ON a device
-    int dev = 0;
+    static int done[16] = {};                        // per device: the attribute belongs to the function ON a device (several contexts, several
+    int dev = 0;                                     // threads: an acquire / release flag each -- setting an attribute twice is harmless)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (done_for == dev) return hipSuccess;
+    const int di = dev >= 0 && dev < 16 ? dev : 0;
+    if (__atomic_load_n(&done[di], __ATOMIC_ACQUIRE)) return hipSuccess;
     const void* fns[6] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLA>),
                           reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLADeep>),
                           reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLADeep>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLADeep>)};
     for (int i = 0; i < 6; i++)
         if ((e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes(i >= 3))) != hipSuccess) return e;
-    done_for = dev;
+    __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
     return hipSuccess;
 }
 

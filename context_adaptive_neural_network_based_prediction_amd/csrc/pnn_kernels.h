@@ -105,7 +105,9 @@ struct TapGemmParams {
     // tapgemm_f32_kernel, K segments (nseg > 1, see GemmLayer::nseg): grid z = class * nseg + segment; a workgroup walks only its
     // segment's share of the class's taps and stores its sums at Y + segment * seg_stride (floats) -- the caller passes a zero
     // bias and act = 0 and finishes with launch_seg_reduce
-    int nseg; unsigned seg_stride;
+    // ONE-TAP layers (FC, round 6; GemmLayer::fc_seg_chunks): segments of seg_chunks 16-deep chunks of the tap, always folded inside the
+    // workgroup (seg_seq = 1 in tapgemm_f32_kernel; fcseg_f32_small_kernel runs them as parallel chains of one workgroup) -- seg_stride's bytes
+    int nseg; union { unsigned seg_stride; unsigned seg_chunks; };
     // seg_seq = 1: the segments one after the other inside each workgroup instead (grid z = class), folded into a running total in
     // the same order -- same bits, no partial planes, no second launch; the caller passes the real Y, bias and act
     int seg_seq;
@@ -118,6 +120,7 @@ inline int pack_tap(int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsi
 
 constexpr int kChunkPad = 4;   // packed weights: every class is zero-padded to a multiple of 4 chunks
 constexpr int kSegDepth = 1600, kSegMinDepth = 2304;   // K segments of the exact-f32 summation order, see finish_gemm_layer (pnn_model.cpp)
+constexpr int kFcSegChunks = 20;                       // ... of a one-tap (FC) layer deeper than this many 16-deep chunks: segments of 320 inputs
 struct TileCfg { int rt, nt, kc, mf, wm = 4, d = 2; };   // a tile configuration of one of the tap-GEMM kernel families (mf: rows of the MFMA shape)
 int tapgemm_sp_num_cfgs();
 TileCfg tapgemm_sp_cfg(int idx);
@@ -172,11 +175,16 @@ hipError_t launch_tapgemm_f32(const TapGemmParams& p, int idx, bool fuse, hipStr
 long tapgemm_f32_small_tiles(const TapGemmParams& p);
 hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const float* host_input = nullptr, int deep_mode = 1);   // deep_mode: pnn_ctx::opt_f32_small_deep
 hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmParams& b, hipStream_t s, int deep_mode = 1);   // two independent layers, one launch
+// A K-segmented one-tap (FC) layer at small M: one workgroup per 16 x 16 output tile runs the layer's <= 4 segments as 4 chains side by
+// side and adds them up in order (p.nseg, p.seg_chunks; the bits of tapgemm_f32_kernel's seg_seq form)
+long fcseg_f32_small_tiles(const TapGemmParams& p);
+bool fcseg_f32_small_fits(const TapGemmParams& p);
+hipError_t launch_fcseg_f32_small(const TapGemmParams& p, hipStream_t s);
 // the same output layer from stored activations p.X [M][Cin], in the fused kernel's order: p.part[segment of 160][M][64]
 hipError_t launch_fc_out_f32(const TapGemmParams& p, hipStream_t s, int* segments);
 // ... and, for small M, the same segments AND their reduction (+ bias, HM epilogue) in one launch: fuse_reduce_kernel's bits
 bool fc_out_f32_small_fits(const TapGemmParams& p);
-hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0});
+hipError_t launch_fc_out_f32_small(const TapGemmParams& p, hipStream_t s, const DoneSignal& done = DoneSignal{nullptr, nullptr, 0, 0}, bool round5_form = false);
 
 // Cin == 1 forward convolution (first layer of each branch): direct VALU kernel.
 struct Conv1Params {

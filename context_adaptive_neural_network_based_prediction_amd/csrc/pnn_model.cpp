@@ -146,7 +146,7 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
     // K segments of the exact-f32 order (GemmLayer::nseg): a class deeper than kSegMinDepth is summed in segments of at most
     // kSegDepth (a 1600-deep chain of v_mfma_f32_32x32x2_f32 is 51 k cycles = 21 us; the 6400-deep third layer of the 64x64 net
     // as ONE chain left a quarter of the chip idle at batch 64 and took 171 us at batch 1), whole taps, never more segments than
-    // the shallowest class has taps.  One-tap layers (FC) are never segmented.
+    // the shallowest class has taps.
     {
         // The segment layout DEFINES the exact-f32 summation order -- the bits an encoder and its decoder must share -- so in the shipped
         // library it is the pair of constants (reported by pnn_arithmetic_tag); only the diagnostic build (make diag) reads the A/B variables.
@@ -165,6 +165,15 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
         if (seg_depth > 0 && tmax > 1 && (long)tmax * p.Cin >= seg_min)
             L->nseg = (int)std::min<long>(std::min(tmin, 8), ((long)tmax * p.Cin + seg_depth - 1) / seg_depth);
         if (L->nseg < 1) L->nseg = 1;
+        // One-tap layers (FC, round 6): a 1200-deep hidden layer is ONE chain of 75 chunks per output -- 4.7 us of a single-block call's
+        // 7.8 us kernel whatever the batch (profiles/r06_b1_stamps.txt).  Deeper than kFcSegChunks chunks it is summed in segments of
+        // kFcSegChunks chunks (1200: 320 + 320 + 320 + 240), folded in order INSIDE the workgroup: four chains side by side at small M
+        // (fcseg_f32_small_kernel), one after the other into a running total at batch (tapgemm_f32_kernel, seg_seq).
+        L->fc_seg_chunks = 0;
+        if (tmax == 1 && p.ncls == 1 && p.SH * p.SW == 1 && p.Cin / 16 > kFcSegChunks) {
+            L->fc_seg_chunks = kFcSegChunks;
+            L->nseg = (p.Cin / 16 + kFcSegChunks - 1) / kFcSegChunks;
+        }
     }
     return PNN_OK;
 }

@@ -12,6 +12,18 @@
 #include <vector>
 
 namespace pnn {
+
+// Diagnostic library only (make diag) under PNN_B1_STAMPS: the next kernel's slot of per-workgroup 100 MHz stamps (host_predict prints
+// them), or null.  64 bytes per workgroup: [3] loop start, [4] entry, [5] exit (behind the acknowledged stores), [1] loop ticks.
+void* diag_stamp_slot(pnn_ctx* c, const char* name, long wgs, double k)
+{
+    if (!c->diag_stamps || c->diag_launch >= pnn_ctx::kDiagLaunches || wgs > pnn_ctx::kDiagWgs) return nullptr;
+    c->diag_names.push_back(name);
+    c->diag_wgs.push_back((int)wgs);
+    c->diag_k.push_back(k);
+    return (char*)c->diag_stamps + (size_t)c->diag_launch++ * pnn_ctx::kDiagWgs * 64;
+}
+
 namespace {
 
 // Exact-f32 launch.  `next` (optional): the net's output layer (<= 64 outputs) applied to this layer's activated tile inside the
@@ -39,9 +51,13 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     p.pm_groups = c->opt_ring_pm == 0 ? -1 : c->opt_ring_pm == 2 ? 1 : 0;   // position-major tiles: never / whenever possible / by the planner's model (launch_tapgemm_f32)
     // K segments (GemmLayer::nseg, the canonical order of the deep conv layers): the launch leaves nseg planes of partial sums, a
     // second launch adds them in order, + bias, activation
-    const int nseg = (f32k && !next && !Yi && L.nseg > 1) ? L.nseg : 1;
+    // A segmented ONE-TAP layer (FC, GemmLayer::fc_seg_chunks) is folded inside the workgroups at every batch size -- no planes, so it may
+    // carry the fused output layer or the HM epilogue: four chains side by side at small M, one after the other into a running total at batch
+    const bool fcseg = f32k && L.fc_seg_chunks > 0 && L.nseg > 1;
+    const int nseg = (f32k && !fcseg && !next && !Yi && L.nseg > 1) ? L.nseg : 1;
     const size_t out_floats = (size_t)nblocks * (size_t)L.out_per_block;
-    if (f32k && L.nseg > 1 && nseg == 1) return fail(c, PNN_E_ARG, "a K-segmented layer cannot carry the HM epilogue or a fused output layer");
+    if (f32k && !fcseg && L.nseg > 1 && nseg == 1) return fail(c, PNN_E_ARG, "a K-segmented layer cannot carry the HM epilogue or a fused output layer");
+    if (fcseg) { p.nseg = L.nseg; p.seg_chunks = (unsigned)L.fc_seg_chunks; p.seg_seq = 1; }
     // Two forms with the same bits: PARALLEL segments (grid z = class x segment, planes of partial sums + seg_reduce_kernel: more,
     // shorter workgroups -- what a launch that does not fill the chip needs) and SEQUENTIAL ones (each workgroup runs its segments
     // one after the other and folds them into a running total: no planes, no second launch -- what a big launch wants).
@@ -60,7 +76,39 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     // Few output tiles (the in-loop single-block calls, the batching service's handfuls): the same fmaf chain per output on the 16x16x4
     // instruction, one wave per 16 x 16 tile over all CUs (pnn_gemm_f32_small.hip) -- bit-identical, 3.2 x shorter dependent chain
     static const bool big_diag = getenv("PNN_F32_DIAG") != nullptr;
-    if (f32k && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
+    if (fcseg && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && fcseg_f32_small_fits(p) && fcseg_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
+        TapGemmParams ps = p;
+        ps.Wp = L.d_w_ch;                             // the weights in the chain waves' lane order
+        if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d nseg=%d -> f32 small kernel, %d K segments side by side (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, L.nseg, L.nseg, fcseg_f32_small_tiles(p));
+        if (void* slot = diag_stamp_slot(c, "fcseg_f32_small", fcseg_f32_small_tiles(p), L.k_total)) ps.Xlo = slot;   // (diagnostic library, PNN_B1_STAMPS)
+        if (profile || c->opt_time_launches) {
+            pnn_ctx::LaunchRec r;
+            HIPCHK(c, hipEventCreate(&r.e0));
+            HIPCHK(c, hipEventCreate(&r.e1));
+            r.kind = 6; r.flops = flops;
+            const LaunchEvents ev{r.e0, r.e1};
+            g_launch_events = &ev;
+            const hipError_t le = launch_fcseg_f32_small(ps, s);
+            g_launch_events = nullptr;
+            HIPCHK(c, le);
+            if (profile) {
+                HIPCHK(c, hipEventSynchronize(r.e1));
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+                fprintf(stderr, "[pnn-prof] M=%ld K=%.0f N=%d nseg=%d f32-small-fcseg us=%.1f tflops=%.2f\n", M, L.k_total, p.Cout, L.nseg, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+                (void)hipEventDestroy(r.e0);
+                (void)hipEventDestroy(r.e1);
+            } else {
+                c->launch_recs.push_back(r);
+            }
+        } else {
+            HIPCHK(c, launch_fcseg_f32_small(ps, s));
+        }
+        c->stat_gemm_launches++; c->stat_launches++;
+        c->stat_gemm_flops += flops;
+        return PNN_OK;
+    }
+    if (f32k && !fcseg && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
         TapGemmParams ps = p;
         ps.Wp = L.d_w_ch;                             // the same weights in the small kernel's lane order
         // K segments: added up by the launch itself (the tile's last workgroup to arrive) when the tiles have counters
@@ -75,6 +123,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             ps.Y = (float*)sb.p;
         }
         if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d ncls=%d nseg=%d -> f32 small kernel (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, p.ncls, nseg, tapgemm_f32_small_tiles(p));
+        if (void* slot = diag_stamp_slot(c, "tapgemm_f32_small", tapgemm_f32_small_tiles(p), L.k_total)) ps.Xlo = slot;   // (diagnostic library, PNN_B1_STAMPS)
         if (profile || c->opt_time_launches) {
             pnn_ctx::LaunchRec r;
             HIPCHK(c, hipEventCreate(&r.e0));
@@ -111,12 +160,12 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             q.Xlo = c->stage_tbs.p;
             HIPCHK(c, launch_tapgemm_f32_small(q, s, host_rows, (int)c->opt_f32_small_deep));
             HIPCHK(c, hipStreamSynchronize(s));
-            const size_t nwg = std::min<size_t>((size_t)tapgemm_f32_small_tiles(p), ((size_t)4 << 20) / 32);
-            std::vector<unsigned long long> hbuf(4 * nwg);
+            const size_t nwg = std::min<size_t>((size_t)tapgemm_f32_small_tiles(p), ((size_t)4 << 20) / 64);
+            std::vector<unsigned long long> hbuf(8 * nwg);
             HIPCHK(c, hipMemcpy(hbuf.data(), c->stage_tbs.p, hbuf.size() * 8, hipMemcpyDeviceToHost));
             double cyc = 0, ticks = 0, chunks = 0;
             unsigned long long r0 = ~0ull, r1 = 0;
-            for (size_t i = 0; i < nwg; i++) { cyc += (double)hbuf[4 * i]; ticks += (double)hbuf[4 * i + 1]; chunks += (double)hbuf[4 * i + 2]; r0 = std::min(r0, hbuf[4 * i + 3]); r1 = std::max(r1, hbuf[4 * i + 3] + hbuf[4 * i + 1]); }
+            for (size_t i = 0; i < nwg; i++) { cyc += (double)hbuf[8 * i]; ticks += (double)hbuf[8 * i + 1]; chunks += (double)hbuf[8 * i + 2]; r0 = std::min(r0, hbuf[8 * i + 3]); r1 = std::max(r1, hbuf[8 * i + 3] + hbuf[8 * i + 1]); }
             fprintf(stderr, "[pnn-f32s-diag] M=%ld K=%.0f N=%d ncls=%d nseg=%d: %zu WGs, loop %.0f cycles for %.0f chunks = %.0f cycles per chunk (160 = the chain), %.2f us, clock %.0f MHz; first loop start -> last loop end %.1f us\n",
                     M, L.k_total, p.Cout, p.ncls, nseg, nwg, cyc / nwg, chunks / nwg, cyc / std::max(1.0, chunks), ticks / nwg / 100.0, cyc / std::max(1.0, ticks) * 100.0, (double)(r1 - r0) / 100.0);
         }
@@ -130,20 +179,29 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             if (code >= ntile && (nseg == 1 || c->opt_f32_seg_mode == 0)) return false;
             if (code < ntile && nseg > 1 && c->opt_f32_seg_mode == 1) return false;
             const TileCfg t = tapgemm_f32_cfg(code % ntile);
+            if (fcseg && L.fc_seg_chunks % (2 * t.kc)) return false;  // an even number of whole stages per segment (tapgemm_f32_kernel, SEQ = 2)
+            if (fcseg && t.rt * t.nt >= 8) return false;              // ... and room for the running total beside the accumulators (the 256 x 128 tile spills)
             return (one_tap || cpt % t.kc == 0) && (!next || tapgemm_f32_can_fuse(code % ntile));
         };
         float* const Yreal = Y;
         const float* const bias_real = L.d_bias;
         const int act_real = L.proto.act;
-        launch = [&, p, pseq, Yreal, bias_real, act_real](int code) {
+        launch = [&, p, pseq, Yreal, bias_real, act_real, fcseg](int code) {
             if (code >= ntile) return launch_tapgemm_f32(pseq, code - ntile, false, s);
             const hipError_t e = launch_tapgemm_f32(p, code, next != nullptr, s);
-            if (e != hipSuccess || p.nseg <= 1) return e;
+            if (e != hipSuccess || p.nseg <= 1 || fcseg) return e;
             return launch_seg_reduce(p.Y, p.nseg, out_floats, p.Cout, bias_real, act_real, Yreal, s);
         };
         double cost_par = 0, cost_seq = 0;
         cfg = choose_cfg_f32(c, M, p.Cout, p.ncls * nseg, p.Cin, L.k_total, next != nullptr, &cost_par);
         if (cfg < 0) return fail(c, PNN_E_ARG, "no tapgemm_f32 tile fits a layer with %d-deep taps", p.Cin);
+        if (fcseg && !legal(cfg)) {                   // the rule knows nothing of the segments' stage count: the same tile with the legal stage depth, else any legal one
+            const TileCfg want = tapgemm_f32_cfg(cfg);
+            int alt = -1;
+            for (int i = 0; i < ntile; i++) if (legal(i) && (alt < 0 || (tapgemm_f32_cfg(i).rt == want.rt && tapgemm_f32_cfg(i).nt == want.nt))) alt = i;
+            if (alt < 0) return fail(c, PNN_E_ARG, "no tapgemm_f32 tile fits K segments of %d chunks", L.fc_seg_chunks);
+            cfg = alt;
+        }
         if (nseg > 1) {
             // the planes cost a write and a read of nseg x the output and a launch (in cycles at 2.4 GHz, ~4 TB/s through L2 / MALL)
             cost_par += (double)(nseg + 1) * (double)out_floats * 4.0 / 4.0e12 * 2.4e9 + 9000.0;
@@ -637,7 +695,8 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
                 TapGemmParams r = q;
                 r.part = nullptr; r.bias = m->fc[3].d_bias; r.mean = c->mean; r.Y = d_out; r.Yi = d_dst;
                 if (fc_out_f32_small_fits(r)) {
-                    HIPCHK(c, launch_fc_out_f32_small(r, s, take_done_signal(c)));
+                    if (void* slot = diag_stamp_slot(c, c->opt_fc_out_f32 == 2 ? "fc_out_f32_small (32x32x2)" : "fc_out_f32_chain", (long)((nb + 15) / 16) * ((n_out + 15) / 16), 1200.0)) r.Xlo = slot;
+                    HIPCHK(c, launch_fc_out_f32_small(r, s, take_done_signal(c), c->opt_fc_out_f32 == 2));
                     c->stat_gemm_launches++; c->stat_launches++;
                     c->stat_gemm_flops += 2.0 * (double)nb * m->fc[3].k_total * n_out;
                     return PNN_OK;

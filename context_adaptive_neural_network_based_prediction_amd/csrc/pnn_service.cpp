@@ -36,6 +36,8 @@ namespace {
 
 constexpr uint32_t kMagic = 0x324e4e50u;   // "PNN2"
 constexpr uint32_t kWantF32 = 1u;          // flags bit 0: reply with the float prediction (frozen-graph output) instead of Pel
+constexpr uint32_t kWantTag = 2u;          // flags bit 1: no inputs; reply = the arithmetic tag of the context that serves `width` (pnn_arithmetic_tag)
+constexpr size_t kTagBytes = 256;          // a tag reply's payload: the string, zero-padded
 constexpr long kStallMs = 5000;            // a reply that cannot be delivered for this long drops its client
 struct ReqHeader { uint32_t magic; int32_t width; uint32_t n_above, n_left, flags; };   // followed by the floats
 struct RspHeader { int32_t rc; uint32_t n_vals; };                                       // followed by n_vals int32 / float
@@ -69,7 +71,8 @@ bool valid_width(int w) { return w == 4 || w == 8 || w == 16 || w == 32 || w == 
 
 bool valid_header(const ReqHeader& h)
 {
-    if (h.magic != kMagic || !valid_width(h.width) || (h.flags & ~kWantF32)) return false;
+    if (h.magic != kMagic || !valid_width(h.width) || (h.flags & ~(kWantF32 | kWantTag))) return false;
+    if (h.flags & kWantTag) return h.flags == kWantTag && h.n_above == 0 && h.n_left == 0;
     const uint32_t w2 = (uint32_t)(h.width * h.width);
     return (h.n_above == 5 * w2 && h.n_left == 0) || (h.n_above == 3 * w2 && h.n_left == 2 * w2);
 }
@@ -160,6 +163,10 @@ struct Server {
     // Per width: 1 = the loaded model is fully-connected (requests must carry n_above = 5w^2, n_left = 0), 0 = convolutional
     // (3w^2 + 2w^2), -2 = no model for this width (every request is refused), -1 = unknown (generic backend: it validates).
     int kind[5] = {-1, -1, -1, -1, -1};
+    // The arithmetic tag of what serves width index i (pnn_arithmetic_tag of its context; a generic backend: $PNN_SERVICE_TAG or
+    // "backend:unspecified"): a client asks for it once (pnn_client_arithmetic_tag) and compares it with its decoder's -- an encoder
+    // behind a service on one arithmetic and a stand-alone decoder on another drift apart silently.  Read-only after start.
+    std::string tag[5];
 
     struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; Clock::time_point t_in; };
     struct Reply { uint64_t id; std::vector<char> bytes; Clock::time_point t_in; int k; };
@@ -396,6 +403,19 @@ struct Server {
                     if (c.rx.size() > want) return false;     // bytes of a second request behind an unanswered one
                     if (c.rx.size() == want) {
                         if (c.in_flight) return false;        // one outstanding request per client
+                        if (h.flags & kWantTag) {             // answered here, by the I/O thread: never queued
+                            const RspHeader rh{0, (uint32_t)(kTagBytes / 4)};
+                            char body[kTagBytes];
+                            memset(body, 0, sizeof body);
+                            const std::string& tg = tag[widx(h.width)];
+                            memcpy(body, tg.data(), std::min(tg.size(), kTagBytes - 1));
+                            const char* hp = reinterpret_cast<const char*>(&rh);
+                            if (c.tx.empty()) c.tx_since = Clock::now();
+                            c.tx.insert(c.tx.end(), hp, hp + sizeof rh);
+                            c.tx.insert(c.tx.end(), body, body + kTagBytes);
+                            c.rx.clear();
+                            return flush(c);
+                        }
                         const int kd = kind[widx(h.width)];
                         if (kd == -2 || (kd >= 0 && (kd == 1) != (h.n_left == 0))) {
                             // well-formed, but not the input shape of the model loaded for this width (e.g. an encoder whose
@@ -598,6 +618,7 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     sv.backend = backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
     for (auto& ur : sv.users) for (void*& u : ur) u = user;
     sv.nio = 2;
+    { const char* e = getenv("PNN_SERVICE_TAG"); for (auto& t : sv.tag) t = e ? e : "backend:unspecified"; }
     return sv.run(socket_path, stats);
 }
 
@@ -612,6 +633,8 @@ int pnn_service_run(const char* socket_path, pnn_ctx* ctx, int max_batch, int wi
     for (int k = 0; k < 5; k++) {
         int is_fc = 0;
         sv.kind[k] = pnn_model_info(ctx, kServiceWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
+        char tg[kTagBytes];
+        sv.tag[k] = pnn_arithmetic_tag(ctx, tg, sizeof tg) == PNN_OK ? tg : "unknown";
     }
     return sv.run(socket_path, stats);
 }
@@ -712,6 +735,8 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
             for (int r = 0; r < sv.nrep[k]; r++) sv.users[k][r] = ctxs[k][r];
             int is_fc = 0;
             sv.kind[k] = pnn_model_info(ctxs[k][0], kWidths[k], &is_fc, nullptr, nullptr) == PNN_OK ? (is_fc ? 1 : 0) : -2;
+            char tg[kTagBytes];
+            sv.tag[k] = pnn_arithmetic_tag(ctxs[k][0], tg, sizeof tg) == PNN_OK ? tg : "unknown";
         }
         rc = sv.run(socket_path, stats);
     }
@@ -804,6 +829,22 @@ int pnn_client_predict_f32(pnn_client* c, int width, const float* above, const f
 {
     if (!c || !above || !out || !valid_width(width)) return PNN_E_ARG;
     return client_call(c, width, above, left, kWantF32, out);
+}
+
+int pnn_client_arithmetic_tag(pnn_client* c, int width, char* out, size_t bytes)
+{
+    if (!c || !out || bytes == 0 || !valid_width(width)) return PNN_E_ARG;
+    const ReqHeader h{kMagic, width, 0u, 0u, kWantTag};
+    if (!write_all(c->fd, &h, sizeof h)) return PNN_E_IO;
+    RspHeader r;
+    if (!read_all(c->fd, &r, sizeof r)) return PNN_E_IO;
+    if (r.rc != 0) return r.rc;
+    if (r.n_vals != kTagBytes / 4) return PNN_E_IO;
+    char body[kTagBytes];
+    if (!read_all(c->fd, body, sizeof body)) return PNN_E_IO;
+    body[kTagBytes - 1] = 0;
+    snprintf(out, bytes, "%s", body);
+    return PNN_OK;
 }
 
 int pnn_client_cache_stats(const pnn_client* c, long* hits, long* misses)

@@ -106,6 +106,14 @@ class Client:
             raise _lib.PnnError("service returned %d" % rc)
         return out
 
+    def arithmetic_tag(self, width):
+        """`pnn_arithmetic_tag` of the server context that serves `width` (compare with the decoder's: INTEGRATION.md)."""
+        buf = ctypes.create_string_buffer(256)
+        rc = self._L.pnn_client_arithmetic_tag(self._c, width, buf, 256)
+        if rc != 0:
+            raise _lib.PnnError("service returned %d" % rc)
+        return buf.value.decode()
+
     def close(self):
         if self._c:
             self._L.pnn_client_close(self._c)

@@ -56,6 +56,11 @@ int pnn_client_predict_pel(pnn_client* c, int width, const float* above, const f
 /* == Session::Run on the server: the float prediction [w][w] (what the TensorFlow look-alike of pnn_tf_compat.h binds when
  * PNN_SERVICE_SOCKET is set, so that an UNMODIFIED HM process is served by the batching service). */
 int pnn_client_predict_f32(pnn_client* c, int width, const float* above, const float* left, float* out);
+/* The arithmetic tag (pnn_arithmetic_tag, pnn_hip.h) of the server context that answers requests of `width`: everything that decides
+ * the last float bits of its predictions.  An encoder behind the service and the decoder of its bitstream predict identically iff
+ * their tags are equal -- ask once at start-up and compare (the TensorFlow look-alike does, against $PNN_EXPECT_TAG).
+ * A server with a generic backend answers $PNN_SERVICE_TAG of its process, or "backend:unspecified". */
+int pnn_client_arithmetic_tag(pnn_client* c, int width, char* out, size_t bytes);
 /* Repeated requests (same width, same input bytes -- HM's RD search re-asks) are answered from a
  * client-side cache of $PNN_CACHE_MB MiB (default 64, 0 = off) without a round trip; hits / misses so far. */
 int pnn_client_cache_stats(const pnn_client* c, long* hits, long* misses);

@@ -73,6 +73,8 @@ template <typename... Args>
 inline Status InvalidArgument(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Invalid argument: " + os.str()); }
 template <typename... Args>
 inline Status Internal(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Internal: " + os.str()); }
+template <typename... Args>
+inline Status FailedPrecondition(const Args&... args) { std::ostringstream os; pnn_append(os, args...); return Status(false, "Failed precondition: " + os.str()); }
 }  // namespace errors
 
 class TensorShape {
@@ -177,9 +179,21 @@ public:
         const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "PNNW", 4);
         std::fclose(f);
         if (!ok) return errors::InvalidArgument(graph.pnn_model_path, " is not a PNNW file");
+        // The arithmetic contract: an encoder and the decoder of its bitstream must predict with the same last float
+        // bits.  $PNN_EXPECT_TAG = the tag the other side reported (pnn_arithmetic_tag; tools/hm/campaign.py records and passes it):
+        // this session fails Create() when whatever will answer its Run() calls -- the batching service or the local context --
+        // computes on another arithmetic or summation order, instead of decoding a drifting picture.  $PNN_PRINT_TAG=1 prints it.
+        const char* expect = std::getenv("PNN_EXPECT_TAG");
         if (const char* sock = std::getenv("PNN_SERVICE_SOCKET")) {   // served remotely: nothing else is needed here
             if (pnn_client_connect(&client_, sock) != PNN_OK) return errors::Internal("no PNN batching service at ", sock);
             width_ = (int)h.width; is_fc_ = (int)h.is_fc;
+            if (expect || std::getenv("PNN_PRINT_TAG")) {
+                char tag[256];
+                if (pnn_client_arithmetic_tag(client_, width_, tag, sizeof tag) != PNN_OK) return errors::Internal("the PNN batching service at ", sock, " does not report its arithmetic tag");
+                if (std::getenv("PNN_PRINT_TAG")) std::fprintf(stderr, "[pnn] arithmetic tag, width %d (service): %s\n", width_, tag);
+                if (expect && std::strcmp(expect, tag))
+                    return errors::FailedPrecondition("arithmetic mismatch for width ", width_, ": the batching service computes on \"", tag, "\", expected \"", expect, "\"");
+            }
             return Status::OK();
         }
         int dev = opts_.pnn_device;
@@ -189,6 +203,13 @@ public:
         long cache_mb = opts_.pnn_cache_mb;
         if (cache_mb < 0) { const char* e = std::getenv("PNN_CACHE_MB"); cache_mb = e ? std::atol(e) : 64; }
         width_ = (int)h.width; is_fc_ = (int)h.is_fc;
+        if (expect || std::getenv("PNN_PRINT_TAG")) {                  // (the tag depends on the context's options, not on the model: no need to wait for the load)
+            char tag[256];
+            if (pnn_arithmetic_tag(ctx_, tag, sizeof tag) != PNN_OK) return errors::Internal("pnn_arithmetic_tag failed");
+            if (std::getenv("PNN_PRINT_TAG")) std::fprintf(stderr, "[pnn] arithmetic tag, width %d (local context): %s\n", width_, tag);
+            if (expect && std::strcmp(expect, tag))
+                return errors::FailedPrecondition("arithmetic mismatch for width ", width_, ": this process computes on \"", tag, "\", expected \"", expect, "\"");
+        }
         // Reading, packing and uploading the weights (0.02 ... 0.2 s per model, 0.5 s for HM's five) runs in a thread of its own:
         // HM creates its five sessions one after the other and needs none of them before the first intra block, so the five
         // loads overlap each other and the rest of the codec's start-up.  The first Run() (or the destructor) joins.

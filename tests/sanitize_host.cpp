@@ -39,6 +39,7 @@ int pnn_model_info(const pnn_ctx*, int width, int* is_fc, int*, long*)
     return PNN_OK;
 }
 // ... and the context calls of pnn_service_run_table (not exercised here: they need the GPU)
+int pnn_arithmetic_tag(const pnn_ctx*, char* out, size_t bytes) { snprintf(out, bytes, "stand-in-context:f32"); return PNN_OK; }
 int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
 int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
 int pnn_set_option(pnn_ctx*, const char*, long) { return PNN_E_HIP; }
@@ -149,6 +150,11 @@ static void service_cases(const char* dir)
                     if (pel[(size_t)y * (w + 3) + x] != (x < w ? (int32_t)s + y * w + x : -1)) bad++;
             for (int i = 0; i < w2; i++) if (f32[i] != s + 0.5f * i) bad++;
             if (it % 10 == 9 && pnn_client_predict_f32(c, w, a.data(), conv ? l.data() : nullptr, f32.data()) != 0) bad++;   // cache hit
+            if (it % 15 == 3) {                       // the arithmetic tag between two requests (answered by the I/O thread, never queued)
+                char tag[64], tiny[4];
+                if (pnn_client_arithmetic_tag(c, w, tag, sizeof tag) != 0 || strcmp(tag, "backend:unspecified")) bad++;
+                if (pnn_client_arithmetic_tag(c, w, tiny, sizeof tiny) != 0 || strcmp(tiny, "bac")) bad++;
+            }
         }
         long hits = 0, misses = 0;
         pnn_client_cache_stats(c, &hits, &misses);
@@ -197,6 +203,11 @@ static void service_kind_and_window_cases(const char* dir)
     for (int t = 0; t < 500 && pnn_client_connect(&c, sock.c_str()) != 0; t++) usleep(2000);
     CHECK(c != nullptr);
     std::vector<float> a(5 * 64 * 64, 1.f), l(2 * 64 * 64, 2.f), out(64 * 64);
+    {
+        char tag[64];
+        CHECK(pnn_client_arithmetic_tag(c, 64, tag, sizeof tag) == PNN_OK && !strcmp(tag, "stand-in-context:f32"));   // the context's tag, whatever the width holds
+        CHECK(pnn_client_arithmetic_tag(c, 7, tag, sizeof tag) == PNN_E_ARG);
+    }
     CHECK(pnn_client_predict_f32(c, 8, a.data(), l.data(), out.data()) == PNN_E_ARG);       // conv-shaped request, FC model
     CHECK(pnn_client_predict_f32(c, 16, a.data(), nullptr, out.data()) == PNN_E_ARG);      // FC-shaped request, conv model
     CHECK(pnn_client_predict_f32(c, 64, a.data(), l.data(), out.data()) == PNN_E_MODEL);   // no model for that width

@@ -473,6 +473,54 @@ def test_batching_service_survives_bad_clients(tmp_path):
         s.close()
 
 
+def test_arithmetic_tag_travels_through_the_service_and_the_session_checks_it(tmp_path, monkeypatch):
+    """The arithmetic contract, enforced: the batching service reports the tag of what answers a width
+    (pnn_client_arithmetic_tag: a flag in the request header, answered by the I/O thread), and the TensorFlow look-alike's
+    Session::Create fails with a clean "arithmetic mismatch" when $PNN_EXPECT_TAG names another one -- instead of a decoder that
+    drifts from its encoder.  No GPU: a stand-in backend behind the real server, the call-site sample program as the HM side."""
+    from context_adaptive_neural_network_based_prediction_amd import service, weights as wts
+    from tests import util
+
+    def backend(width, above, left):
+        s = above.sum(axis=1) + (left.sum(axis=1) if left is not None and left.size else 0.0)
+        f32 = np.tile(s.astype(np.float32)[:, None, None], (1, width, width))
+        return np.clip(np.round(f32), 0, 255).astype(np.int32), f32
+
+    monkeypatch.setenv("PNN_SERVICE_TAG", "stand-in:f32:test order 7")
+    sock = str(tmp_path / "pnn.sock")
+    srv = service.serve_in_thread(sock, backend=backend, max_batch=8, window_us=0)
+    cl = service.Client(sock)
+    for w in (4, 8, 16, 32, 64):
+        assert cl.arithmetic_tag(w) == "stand-in:f32:test order 7"
+    a = np.arange(80, dtype=np.float32)
+    assert np.array_equal(cl.predict_f32(4, a), np.full((4, 4), a.sum(), np.float32))       # a tag request leaves the connection usable
+    assert cl.arithmetic_tag(4) == "stand-in:f32:test order 7"
+    buf = ctypes.create_string_buffer(8)                                                        # a short buffer gets a truncated, terminated string
+    assert _lib.lib().pnn_client_arithmetic_tag(cl._c, 4, buf, 8) == 0 and buf.value == b"stand-i"
+    assert _lib.lib().pnn_client_arithmetic_tag(cl._c, 5, buf, 8) == -1                     # PNN_E_ARG
+    cl.close()
+    # the HM side: Session::Create behind the service, with and without the expectation
+    wts.save_pnnw(str(tmp_path / "fc8.pnnw"), util.make_params(8, True, 41), 8, True)
+    wts.save_pnnw(str(tmp_path / "conv16.pnnw"), util.make_params(16, False, 42), 16, False)
+    inc = ["-I" + os.path.join(ROOT, "include", "tf_compat"), "-I" + os.path.join(ROOT, "include")]
+    exe = str(tmp_path / "hm_sample")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall"] + inc + [os.path.join(ROOT, "tests", "hm_callsite_sample.cpp"), "-o", exe,
+                           "-L" + libdir, "-lpnn_hip", "-Wl,-rpath," + libdir])
+    argv = [exe, str(tmp_path / "fc8.pnnw"), "8", str(tmp_path / "conv16.pnnw"), "16"]
+    env = dict(os.environ, PNN_SERVICE_SOCKET=sock, PNN_CACHE_MB="0")
+    ok = subprocess.run(argv, env=dict(env, PNN_EXPECT_TAG="stand-in:f32:test order 7", PNN_PRINT_TAG="1"), capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0, ok.stderr
+    assert "arithmetic tag, width 8 (service): stand-in:f32:test order 7" in ok.stderr
+    plain = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=60)             # no expectation: nothing is asked, nothing fails
+    assert plain.returncode == 0 and plain.stdout == ok.stdout
+    bad = subprocess.run(argv, env=dict(env, PNN_EXPECT_TAG="pnn-order-6:f32:something else"), capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and bad.stdout == ""
+    assert "arithmetic mismatch for width 8" in bad.stderr and "stand-in:f32:test order 7" in bad.stderr and "something else" in bad.stderr
+    stats = srv.stop()
+    assert srv.rc == 0 and stats["requests"] == 1 + 2 * 2                                       # tag requests never reach the backend
+
+
 def test_batching_service_many_clients_over_io_threads(tmp_path, monkeypatch):
     """The server's socket side runs on several I/O threads (a connection belongs to one of them for life; the workers hand a
     reply to the owner's queue): 48 clients on 4 I/O threads, 60 requests each over the five widths and both input shapes -- every

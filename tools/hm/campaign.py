@@ -174,7 +174,7 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
         env["PNN_SERVICE_PARENT"] = str(os.getpid())
         servers.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True))
         socks.append(sock)
-    results, stats, spot = [], [], {}
+    results, stats, spot, tags = [], [], {}, []
     try:
         import select
         for srv, log in zip(servers, logs):            # the start-up line, with a deadline
@@ -184,10 +184,21 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
                 log.seek(0)
                 raise RuntimeError("batching service did not start: %r %s" % (line, log.read()[-2000:]))
         t_up = time.time() - t_start
+        # The arithmetic contract: every service is asked for the tag of each width's context before the first encode;
+        # the encoders run behind it, and every DECODER gets that tag as $PNN_EXPECT_TAG -- one that would be answered on another
+        # arithmetic or summation order refuses to start (run_hm.ArithmeticMismatch) instead of decoding a picture that drifts.
+        from context_adaptive_neural_network_based_prediction_amd import service as svc_mod
+        for k, sock in enumerate(socks):
+            cl = svc_mod.Client(sock)
+            per_width = {wd: cl.arithmetic_tag(wd) for wd in (4, 8, 16, 32, 64)}
+            cl.close()
+            if len(set(per_width.values())) != 1:
+                raise RuntimeError("service %d serves its widths on different arithmetics: %r" % (k, per_width))
+            tags.append(per_width[4])
 
         def job(j):
             return run_hm.encode_decode(variant, frames[j], qp, table, mean_path, os.path.join(work, "enc"), tag=str(j),
-                                        env={"PNN_SERVICE_SOCKET": socks[j % len(socks)]}, timeout=timeout)
+                                        env={"PNN_SERVICE_SOCKET": socks[j % len(socks)]}, timeout=timeout, expect_tag=tags[j % len(socks)])
         cg0 = _cgroup_cpu()
         t0 = time.time()
         with ThreadPoolExecutor(in_flight) as ex:
@@ -275,6 +286,10 @@ def run_campaign(config, work, devices=(0,), pictures=None, in_flight=None, qp=3
                     "largest_batch": max([s.get("largest_batch", 0) for s in stats] or [0]), "per_service": stats, "per_width": busy,
                     "pnn_blocks_per_s_over_the_wall": round(requests / wall, 1)},
         "every_decode_equals_its_encoder": bool(all(r["decoder_equals_encoder"] and not r["decoder_hash_error"] for r in results)),
+        # pnn_arithmetic_tag of what answered the encoders (asked through each service's socket before the first encode) and of what
+        # answered the decoders: here the same services, and every decoder ran with $PNN_EXPECT_TAG = its encoder's tag (it refuses to
+        # start on a mismatch, include/pnn_tf_compat.h)
+        "arithmetic_tags": {"encoder_side": tags, "decoder_side": tags, "decoders_checked_expect_tag": True},
     }
     if yardstick and binaries_present(("regular",)):
         def ref_job(j):

@@ -30,6 +30,7 @@ def main():
     args = ap.parse_args()
     threads = args.threads or min(8, os.cpu_count() or 8)
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ.setdefault("PNN_SERVICE_TAG", "cpu-oracle:f32:plain C loops (oracle/pnn_oracle.c)")   # what pnn_client_arithmetic_tag reports for this backend
     import numpy as np
     from context_adaptive_neural_network_based_prediction_amd import _lib, service, weights as wts
     _lib.SKIP_TORCH = True
