@@ -33,10 +33,11 @@ RAMP_SECONDS = 0.4          # untimed device ramp-up before the warm-up steps (s
 REPEATS = 5                 # timed regions of K steps each; value = the median region
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak (the roof a single-block call's parameter stream is priced against)
 SUSTAIN_SECONDS = 2.0       # --sustained: one region of back-to-back steps per (workload, arithmetic), clocks sampled meanwhile
 LINE_LIMIT = 4096           # the driver keeps the tail of stdout: the line must fit with room to spare
 DTYPE = {0: "f32",
-         1: "f32-class split: 2 x f16 per operand (22-bit significand), 3 f16-MFMA products, f32 accumulate"}
+         1: "f32-class split: 2 x f16 per operand, 3 f16-MFMA products, f32 accumulate"}
 DTYPE_LONG = {1: "f32 emulated: 2 x f16 per operand (hi + lo, 22-bit significand), 3 of the 4 partial products on f16 MFMA "
                  "(lo*lo dropped), f32 accumulate",
               0: "f32 (IEEE float32 operands on f32 MFMA, f32 accumulate: the reference's arithmetic)"}
@@ -279,6 +280,43 @@ def measure(wl, precision, steps, warmup, dist, repeats=REPEATS, check=True, sus
                                     "and the Kodak / BSDS pictures are not in the reference checkout, so the paper's pred-PSNR cannot be reproduced here"}
     net.close()
     return res
+
+
+def single_block_calls(names, device, precision=0, calls=300, warm=80):
+    """The reference's own call shape (freezing_graph_pnn.py:100-102, TComPrediction.cpp:572-579,601-608): ONE block per call through the
+    host-array entry point HM's Session::Run look-alike binds (pnn_predict_fc / pnn_predict_conv at n = 1: staging, net, wait, copy
+    out).  Per workload name: median microseconds of `calls` calls after `warm`, the blocks/s that is, and the parameter stream it
+    amounts to (a single-block call is bound by streaming the net's parameters) against the 8 TB/s HBM roof."""
+    from context_adaptive_neural_network_based_prediction_amd import PredictionNeuralNetwork, _lib
+    from tests import util
+    L = _lib.lib()
+    out = {}
+    for name in names:
+        w, fc, _, _ = WORKLOADS[name]
+        params = util.make_params(w, fc, 1, out_gain=util.out_gain(w, fc))
+        net = PredictionNeuralNetwork(1, w, fc, params=params, device=device)
+        net.set_option("precision", precision)
+        a, l = util.make_contexts(w, 1, 2)
+        x = np.ascontiguousarray(util.flatten_fc(a, l) if fc else a, np.float32)
+        l = np.ascontiguousarray(l, np.float32)
+        y = np.zeros((w, w), np.float32)
+        xp, lp, yp = x.ctypes.data_as(_lib.f32p), l.ctypes.data_as(_lib.f32p), y.ctypes.data_as(_lib.f32p)
+        call = (lambda: L.pnn_predict_fc(net.ctx, w, xp, 1, yp)) if fc else (lambda: L.pnn_predict_conv(net.ctx, w, xp, lp, 1, yp))
+        for _ in range(warm):
+            if call():
+                raise RuntimeError(L.pnn_last_error(net.ctx))
+        ts = np.empty(calls)
+        for i in range(calls):
+            t0 = time.perf_counter()
+            call()
+            ts[i] = time.perf_counter() - t0
+        us = float(np.median(ts)) * 1e6
+        out[name] = {"us": us, "us_p10": float(np.percentile(ts, 10)) * 1e6, "us_p90": float(np.percentile(ts, 90)) * 1e6, "calls": calls,
+                     "blocks_per_s": 1e6 / us, "param_bytes": int(params.nbytes), "param_gbps": params.nbytes / us / 1e3,
+                     "frac_of_hbm": params.nbytes / us / 1e3 / PEAK_HBM_GBPS, "launches": net.last_call_stats()["launches"],
+                     "entry_point": "pnn_predict_fc" if fc else "pnn_predict_conv"}
+        net.close()
+    return out
 
 
 def cpu_leg_worker(kind, workload, batch1, threads, budget_s):
@@ -544,12 +582,14 @@ def _r(x, nd=4):
     return float("%.*g" % (nd, x))
 
 
-def compact(res):
+def compact(res, with_ms=True):
     """One measurement as the line carries it.  issued_frac only where position-major tiles skipped something (conv nets); the held
     clock and the fraction against the roof at that clock only for the split-f16 mode (the exact-f32 kernels hold the nominal clock)."""
     rf = res["roofline"]
     out = {"value": _r(res["value"], 5), "ms_per_step": _r(res["ms_per_step"], 5), "frac": _r(rf["frac"], 3),
            "pass_frac": _r(rf["whole_pass"]["frac_of_peak"], 3), "launches": res["launches_per_step"], "lsb": res.get("max_abs_lsb_vs_oracle")}
+    if not with_ms:                                  # per_width rows: value and batch say it (the line is capped at LINE_LIMIT)
+        del out["ms_per_step"]
     if (rf["whole_pass"].get("issued_over_algorithmic") or 1.0) < 0.999:
         out["issued_frac"] = _r(rf["whole_pass"].get("issued_frac_of_peak"), 3)
     if res.get("precision") == 1 and rf.get("frac_at_held_clock"):
@@ -558,8 +598,9 @@ def compact(res):
 
 
 def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=None, cpu=None, cpu_conv16=None, detail_file=None, extra_config=None,
-               rccl_ranks_seen=None, natural=None):
-    """The ONE JSON line of rank 0 (< LINE_LIMIT bytes).  `main_res` / `fast` / `per_width[name][arith]` are measure() results."""
+               rccl_ranks_seen=None, natural=None, single=None):
+    """The ONE JSON line of rank 0 (< LINE_LIMIT bytes).  `main_res` / `fast` / `per_width[name][arith]` are measure() results;
+    `single` = single_block_calls() results by workload name (exact f32)."""
     rf = main_res["roofline"]
     out = {
         "metric": "pnn_intra_pred_blocks_per_s", "value": _r(main_res["value"], 6), "unit": "blocks/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -579,7 +620,7 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
     if extra_config:
         out["config"].update(extra_config)
     if cpu:
-        out["cpu_baseline"] = {k: (_r(cpu.get(k)) if k != "sample" else cpu[k][:200]) for k in
+        out["cpu_baseline"] = {k: (_r(cpu.get(k)) if k != "sample" else cpu[k][:150]) for k in
                                ("value", "unit", "cores", "host_cores", "cpu_quota", "kind", "value_leg", "batch1_value", "batch1_cores", "sample")}
         if cpu.get("value"):
             out["cpu_baseline"]["gpu_over_cpu"] = _r(main_res["value"] / world / cpu["value"], 3)
@@ -596,10 +637,22 @@ def build_line(main_res, world, steps, warmup, cfg_name, fast=None, per_width=No
             w, fc, _, _ = WORKLOADS[name]
             row = {"arch": "fc" if fc else "conv", "batch": next(iter(per_width[name].values()))["batch_per_gpu"]}
             for arith, r in per_width[name].items():
-                row[arith] = compact(r)
+                row[arith] = compact(r, with_ms=False)
+            if single and name in single:
+                row["single_block_us"] = _r(single[name]["us"], 3)     # one block per host call, exact f32: the reference's call shape
             tab[str(w)] = row
         out["per_width"] = tab
-        out["per_width_note"] = "f32 vs 157.3, split vs 2500/3 TFLOP/s; frac = dominant GEMM, pass_frac = whole step (padding taps counted), issued_frac = on the multiply-adds issued; frac_held = frac vs the roof at held_mhz"
+        out["per_width_note"] = "f32 vs 157.3, split vs 2500/3 TFLOP/s; frac: dominant GEMM, pass_frac: whole step, issued_frac: on issued MACs, frac_held: vs roof at held_mhz; single_block_us: 1 block per host call, f32"
+    if single:
+        # the reference's call shape -- one block per Session::Run -- beside the CPU's batch-1 leg of the same net
+        sb = {}
+        for name, cb in (("fc8", cpu), ("conv16", cpu_conv16)):
+            if name not in single:
+                continue
+            r = single[name]
+            sb[name] = {"us": _r(r["us"], 3), "blocks_per_s": _r(r["blocks_per_s"], 4), "param_gbps": _r(r["param_gbps"], 3), "frac_of_hbm": _r(r["frac_of_hbm"], 2),
+                        "gpu_over_cpu_batch1": _r(r["blocks_per_s"] / cb["batch1_value"], 3) if cb and cb.get("batch1_value") else None}
+        out["single_block"] = sb
     if natural:
         out["natural_pred_psnr_db"] = {w: {"gpu_f32": _r(v.get("f32_db"), 5), "gpu_split": _r(v.get("split_db"), 5), "oracle": _r(v.get("oracle_db"), 5)} for w, v in natural.items()}
     if rccl_ranks_seen is not None:
@@ -625,6 +678,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="--gpus N > 1: weak = every rank its own batch of the workload's size (the contract's default); strong = ONE batch of that "
                          "size split over the ranks (sharding.shard_bounds), at least 200 steps per region")
+    ap.add_argument("--force-dist", default=None, choices=["nccl", "gloo"],
+                    help="--gpus 1 only: join a ONE-rank process group anyway and run the barrier, the max-over-ranks clock, the device census and a "
+                         "gather of the predictions through it -- with nccl the only execution of the RCCL branch a one-GPU box allows")
     ap.add_argument("--arithmetic", default=None, choices=sorted(ARITH), help="top-level arithmetic (default f32 = the reference's; env PNN_PRECISION=1 -> split)")
     ap.add_argument("--hm-quick", action="store_true", help=argparse.SUPPRESS)   # 4 pictures per campaign (plumbing tests)
     ap.add_argument("--hm-pictures", default="synthetic", choices=["synthetic", "natural"], help="hm_* workloads: picture set")
@@ -694,7 +750,10 @@ def main():
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = sharding.init_ranks("gloo" if share else "nccl", None if share else torch.device("cuda", local_rank))   # "nccl" = RCCL on ROCm; None at N = 1
+    if args.force_dist and world != 1:
+        raise SystemExit("--force-dist is the ONE-rank form (--gpus 1)")
+    backend = args.force_dist or ("gloo" if share else "nccl")
+    dist = sharding.init_ranks(backend, None if (share or backend == "gloo") else torch.device("cuda", local_rank), force=bool(args.force_dist))   # "nccl" = RCCL on ROCm; None at N = 1
     ranks_seen = None
     if dist is not None:
         try:
@@ -703,6 +762,12 @@ def main():
             sys.stderr.write("bench.py: count_distinct_devices failed: %r\n" % (e,))
             ndev = None
         ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": ndev}
+        if args.force_dist:
+            # ... and the optional all-gather of the predictions through the same group, on the device for RCCL
+            probe = torch.arange(3 * 64, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu").reshape(3, 8, 8)
+            back = sharding.gather_predictions(probe, 3, dist)
+            ranks_seen["gather_predictions_ok"] = bool(torch.equal(back.cpu(), probe.cpu()))
+            ranks_seen["forced_single_rank_group"] = True
 
     t_start = time.perf_counter()
     strong = args.scaling == "strong" and world > 1
@@ -743,6 +808,13 @@ def main():
                 torch.cuda.empty_cache()
         detail["per_width"] = per_width
         detail["fast_arithmetic"] = fast
+    single_res = None
+    if rank == 0 and single and not args.no_extras:
+        try:
+            single_res = single_block_calls(PER_WIDTH, local_rank)
+        except Exception as e:                        # noqa: BLE001 -- an extra of the line must never cost the measurement
+            detail["single_block_error"] = repr(e)[:500]
+        detail["single_block"] = single_res
     natural = None
     if rank == 0 and single and not args.no_extras:
         try:
@@ -772,7 +844,7 @@ def main():
             sys.stderr.write("bench.py: cannot write %s: %s\n" % (args.detail_file, e))
             dfile = None
         print(build_line(main_res, world, args.steps, args.warmup, wl.cfg_name, fast, per_width, cpu, cpu16, dfile,
-                         {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"} if share else None, ranks_seen, natural))
+                         {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"} if share else None, ranks_seen, natural, single_res))
         sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()

@@ -14,12 +14,25 @@ def rank_env(environ=None):
     return int(e.get("RANK", "0")), int(e.get("LOCAL_RANK", "0")), int(e.get("WORLD_SIZE", "1"))
 
 
-def init_ranks(backend, device=None):
+# True: the exchanges below run through the process group even when it has ONE rank (bench.py --force-dist: the only execution of the
+# RCCL branch a one-GPU box allows -- communicator set-up, barrier, all-reduce, all-gather on the real device)
+FORCE_COLLECTIVES = False
+
+
+def _single(dist):
+    return dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES)
+
+
+def init_ranks(backend, device=None, force=False):
     """Joins the job's process group when WORLD_SIZE > 1 (backend "nccl" = RCCL on the GPUs, "gloo" on the CPU) and
-    returns the torch.distributed module, or None for a single process.  Rendezvous defaults to 127.0.0.1."""
+    returns the torch.distributed module, or None for a single process.  Rendezvous defaults to 127.0.0.1.
+    force: a group even for ONE rank, and every exchange of this module goes through it (FORCE_COLLECTIVES)."""
+    global FORCE_COLLECTIVES
     rank, _, world = rank_env()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
+    if force:
+        FORCE_COLLECTIVES = True
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -66,7 +79,7 @@ def shard_bounds(n_items, rank, world_size):
 
 def max_over_ranks(seconds, dist=None, device=None):
     """The job's step time is the slowest rank's (bench contract)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return float(seconds)
     import torch
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device if device is not None else "cpu")
@@ -76,7 +89,7 @@ def max_over_ranks(seconds, dist=None, device=None):
 
 def gather_predictions(local, n_total, dist=None):
     """All ranks' [n_local, w, w] predictions concatenated in rank order on every rank (equal or ragged shards)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return local
     import torch
     world = dist.get_world_size()

@@ -441,6 +441,31 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
     net.close()
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_through_rccl(precision):
+    """`python bench.py --gpus 1 --force-dist nccl` (VERDICT r5 #8a): the RCCL branch of the N > 1 path executed on the hardware that is
+    there -- a ONE-rank group on the real device; the opening barrier and the max-over-ranks clock of every timed region, the device
+    census and a gather of predictions all go through RCCL.  The line says so (rccl_ranks_seen) and is otherwise the N = 1 line."""
+    import json
+    import subprocess
+    import sys
+    if precision != "f32":
+        pytest.skip("once is enough")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNN_AUTOTUNE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+    for k in ("PNN_PRECISION", "WORLD_SIZE", "RANK", "LOCAL_RANK", "PNN_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "nccl", "--steps", "10", "--warmup", "2",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["dtype"] == "f32" and d["value"] > 1e6
+    assert d["rccl_ranks_seen"] == {"backend": "nccl", "world_size": 1, "devices": 1, "gather_predictions_ok": True, "forced_single_rank_group": True}
+    assert d["max_abs_lsb_vs_oracle"] is not None and d["max_abs_lsb_vs_oracle"] <= 1
+
+
 @pytest.mark.parametrize("w,is_fc", [(4, True), (8, True), (16, False), (32, False), (64, False)])
 def test_small_calls_replayed_as_graphs(pnn, precision, w, is_fc):
     """Option "graphs" (opt-in): the launch chain of a small host call is captured on the second call of a shape (model, blocks,
@@ -1360,3 +1385,26 @@ def test_known_answer_behaviours_on_gpu(pnn, oracle, w, is_fc):
     assert np.all(pel[2] == 118)
     half = run(0.5 * above, 0.5 * left)
     np.testing.assert_allclose(half, 0.5 * out, rtol=0, atol=FLOAT_ATOL)
+
+
+_TF_OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_outputs.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(_TF_OUT), reason="tests/golden/tf_outputs.npz absent: made with TensorFlow 1.x by tools/tf_goldens.py")
+def test_hip_matches_tensorflow_outputs(pnn, precision):
+    """north_star's bar against the reference ITSELF: the HIP path within 1 LSB per pixel (uint8, after HM's epilogue) of what the
+    reference's TensorFlow graphs predict for the seeded weights and contexts of nets.npz -- both arithmetics, every architecture."""
+    from oracle import pnn_oracle as O                                # the epilogue only (TComPrediction.cpp:623-635); TF supplies the predictions
+    tf_out = np.load(_TF_OUT)
+    g = np.load(os.path.join(os.path.dirname(_TF_OUT), "nets.npz"))
+    for is_fc, w in [(True, 4), (True, 8), (False, 4), (False, 8), (False, 16), (False, 32), (False, 64)]:
+        tag = "%s%d" % ("fc" if is_fc else "conv", w)
+        seed, n = int(g[tag + "_seed"]), int(g[tag + "_n"])
+        params = util.make_params(w, is_fc, seed, out_gain=util.out_gain(w, is_fc))
+        above, left = util.make_contexts(w, n, seed + 1)
+        net = pnn.PredictionNeuralNetwork(n, w, is_fc, params=params)
+        got = net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left)))
+        want = O.epilogue(tf_out[tag + "_out"], util.MEAN)
+        assert np.abs(got.astype(np.int64) - want).max() <= 1, tag
+        net.close()

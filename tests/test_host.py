@@ -370,6 +370,45 @@ def test_two_rank_sharding_gloo(tmp_path, oracle):
         assert "rank %d ok" % r in o
 
 
+def test_forced_one_rank_group_gloo(tmp_path):
+    """bench.py --gpus 1 --force-dist: a process group of ONE rank, and every exchange of sharding.py -- barrier, max-over-ranks clock,
+    device census, gather of the predictions -- goes through it instead of taking the single-process shortcut.  On the GPU box with
+    "nccl" this is the only execution of the RCCL branch one device allows (tests/test_gpu_parity.py); here the same code over gloo."""
+    script = tmp_path / "one_rank.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from context_adaptive_neural_network_based_prediction_amd import sharding
+assert sharding.init_ranks("gloo") is None                      # no group without the flag ...
+calls = {"all_reduce": 0, "all_gather": 0, "barrier": 0}
+for name in calls:
+    def wrap(name=name, fn=getattr(dist, name)):
+        def f(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return f
+    setattr(dist, name, wrap())
+d = sharding.init_ranks("gloo", force=True)                      # ... and one of ONE rank with it
+assert d is dist and dist.get_world_size() == 1 and sharding.FORCE_COLLECTIVES
+assert sharding.max_over_ranks(0.25, d) == 0.25 and calls["all_reduce"] == 1
+probe = torch.arange(3 * 16, dtype=torch.int32).reshape(3, 4, 4)
+assert torch.equal(sharding.gather_predictions(probe, 3, d), probe) and calls["all_gather"] == 1
+n = []
+t = sharding.timed_steps(lambda: n.append(1), 7, lambda: None, d)
+assert len(n) == 7 and t >= 0 and calls["barrier"] == 1 and calls["all_reduce"] == 2
+assert sharding.count_distinct_devices(d, 0) == 1
+dist.destroy_process_group()
+print("ok")
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_tf_compat_headers_compile(tmp_path):
     """include/pnn_tf_compat.h + the shadow tree include/tf_compat/tensorflow/core/...: (1) the reference's own TF glue
     (integration_prediction_neural_network.cpp: create_tensors_*, load_graph(s)) compiles UNCHANGED against them when
@@ -700,13 +739,20 @@ def test_bench_line_fits_the_driver_tail_buffer():
     cpu = {"value": 12345.678901, "unit": "blocks/s", "cores": 64, "host_cores": 256, "kind": "port", "value_leg": "torch_cpu_batched",
            "batch1_value": 234.5678901, "batch1_leg": "torch_cpu_batch1", "batch1_cores": 8, "sample": "x" * 600, "legs": {"bulk": "y" * 5000}}
     natural = {w: {"contexts": 2500, "oracle_db": 24.9501234567, "f32_db": 24.9501234567, "split_db": 24.9498765432, "f32_max_abs_lsb_vs_oracle": 1} for w in ("4", "8")}
+    single = {n: {"us": 123.456789, "us_p10": 120.123456, "us_p90": 130.987654, "calls": 300, "blocks_per_s": 8100.123456, "param_bytes": 82610180,
+                  "param_gbps": 669.123456, "frac_of_hbm": 0.0836404, "launches": 11, "entry_point": "pnn_predict_conv"} for n in bench.PER_WIDTH}
     line = bench.build_line(main, 8, 20, 5, bench.WORKLOADS["fc8"][3], fast, per_width, cpu, dict(cpu), "bench_detail.json",
-                            {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"}, {"backend": "nccl", "world_size": 8, "devices": 8}, natural)
+                            {"plumbing_check": "PNN_BENCH_SHARE_GPU=1: all ranks on ONE device"}, {"backend": "nccl", "world_size": 8, "devices": 8}, natural, single)
     assert len(line) < bench.LINE_LIMIT and "\n" not in line, len(line)
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "fast_arithmetic", "per_width", "rccl_ranks_seen", "natural_pred_psnr_db"):
+              "roofline", "cpu_baseline", "fast_arithmetic", "per_width", "rccl_ranks_seen", "natural_pred_psnr_db", "single_block"):
         assert k in d, k
+    # the reference's call shape in the driver-run line: one block per host call, beside the CPU's batch-1 leg
+    assert sorted(d["single_block"]) == ["conv16", "fc8"]
+    for r in d["single_block"].values():
+        assert {"us", "blocks_per_s", "param_gbps", "frac_of_hbm", "gpu_over_cpu_batch1"} <= set(r) and r["gpu_over_cpu_batch1"] > 1
+    assert all("single_block_us" in row for row in d["per_width"].values())
     assert d["dtype"] == "f32" and d["n_gpus"] == 8 and d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "flops_per_launch", "avg_launch_us"):
         assert k in d["roofline"], k

@@ -274,3 +274,29 @@ def test_block_cost_equals_reference_rdcost(oracle, w, hadamard):
     want = oracle.block_costs(plane, xs, ys, w, pred, hadamard, use_ref=True)
     assert got[0] == 0
     assert np.array_equal(got, want)
+
+
+TF_OUT = os.path.join(GOLD, "tf_outputs.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(TF_OUT), reason="tests/golden/tf_outputs.npz absent: a holder of TensorFlow 1.x makes it with tools/tf_goldens.py (this container has no TensorFlow)")
+def test_oracle_matches_tensorflow_outputs(oracle):
+    """THE pin at the TensorFlow boundary: the reference's own graphs, run by TensorFlow on the seeded weights and
+    contexts of nets.npz (tools/tf_goldens.py), against the CPU oracle -- float predictions within 1e-3 (two float32 summation
+    orders), the HM epilogue within 1 LSB and equal on all but exact .5 ties; the two trained checkpoints restored by TF's own Saver too."""
+    tf_out = np.load(TF_OUT)
+    g = np.load(os.path.join(GOLD, "nets.npz"))
+    for is_fc, w in [(True, 4), (True, 8), (True, 16), (False, 4), (False, 8), (False, 16), (False, 32), (False, 64)]:
+        tag = "%s%d" % ("fc" if is_fc else "conv", w)
+        seed, n = int(g[tag + "_seed"]), int(g[tag + "_n"])
+        params = util.make_params(w, is_fc, seed, out_gain=util.out_gain(w, is_fc))
+        above, left = util.make_contexts(w, n, seed + 1)
+        out = oracle.fc_forward(params, w, util.flatten_fc(above, left)) if is_fc else oracle.conv_forward(params, w, above, left)
+        want = tf_out[tag + "_out"]
+        np.testing.assert_allclose(out, want, rtol=0, atol=1e-3, err_msg=tag)
+        pel, pel_tf = oracle.epilogue(out, util.MEAN), oracle.epilogue(want, util.MEAN)
+        assert np.abs(pel.astype(np.int64) - pel_tf).max() <= 1 and (pel != pel_tf).mean() < 0.01, tag
+    for w in (4, 8):
+        flat, _, _ = wts.load_pnnw(os.path.join(GOLD, "conv%d_single.pnnw" % w))
+        out = oracle.conv_forward(flat, w, g["real%d_above" % w], g["real%d_left" % w])
+        np.testing.assert_allclose(out, tf_out["real%d_out" % w], rtol=0, atol=1e-3, err_msg="trained conv %d" % w)
