@@ -19,6 +19,7 @@
 
 using namespace pnn;
 
+namespace pnn { std::recursive_mutex& unsafe_calls_lock() { static std::recursive_mutex m; return m; } }
 namespace pnn { thread_local const LaunchEvents* g_launch_events = nullptr; thread_local double g_last_issued_frac = 1.0; }
 namespace { thread_local std::string g_create_error; }
 namespace pnn {
@@ -26,17 +27,18 @@ namespace pnn {
 const DeviceInfo& device_info()
 {
     static DeviceInfo cache[16];
+    static std::once_flag filled[16];                // the service's width workers and HM's loader threads get here at the same time
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { static const DeviceInfo fallback; return fallback; }
     DeviceInfo& d = cache[dev];
-    if (d.dev != dev) {
+    std::call_once(filled[dev], [&d, dev] {
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, dev) == hipSuccess) {
             if (pr.multiProcessorCount > 0) d.cus = pr.multiProcessorCount;
             if (pr.maxSharedMemoryPerMultiProcessor > 0) d.lds = (size_t)pr.maxSharedMemoryPerMultiProcessor;
         }
         d.dev = dev;
-    }
+    });
     return d;
 }
 
@@ -51,6 +53,7 @@ int fail(pnn_ctx* c, int code, const char* fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     if (c) c->err = buf; else g_create_error = buf;
+    if (c && code == PNN_E_HIP) c->seg_cnt_dirty = true;   // a launch chain may have stopped half-way: the tiles' arrival counters are zeroed before their next use
     return code;
 }
 
@@ -62,8 +65,7 @@ namespace {
 // synchronously: in this runtime such a call invalidates the capture whatever the capture mode (thread-local: one HM run in five,
 // relaxed: two in three -- the reference's HM loads its five graphs on five threads while the main thread is already predicting).
 // Everything of that kind that this library does takes the lock; a capture holds it from begin to end.
-std::recursive_mutex& unsafe_calls_lock() { static std::recursive_mutex m; return m; }
-#define PNN_UNSAFE_CALLS_GUARD std::lock_guard<std::recursive_mutex> unsafe_guard_(unsafe_calls_lock())
+#define PNN_UNSAFE_CALLS_GUARD std::lock_guard<std::recursive_mutex> unsafe_guard_(pnn::unsafe_calls_lock())
 
 void cache_clear(pnn_ctx* c)                          // (every option change / model load: cached predictions and captured launch chains go)
 {
@@ -136,7 +138,7 @@ int wait_stream(pnn_ctx* c, hipStream_t s)
 
 // The last kernel of the pass took a completion signal (take_done_signal): spin on the flag word it raises in pinned host
 // memory behind its results.  Bounded: a launch that failed never raises it, the stream then says why.
-int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1)
+int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1, int width = 4)
 {
     const unsigned* flag = reinterpret_cast<const unsigned*>(c->h_range) + 1;
     if (c->opt_wait_sleep) {
@@ -144,7 +146,8 @@ int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1)
         constexpr double kMarginUs = 14.0, kMinSleepUs = 12.0;
         int b = 0;
         while ((2L << b) <= n && b < 11) b++;
-        double& ema = c->wait_ema_us[b];
+        const int wi = width_index(width) < 0 ? 0 : width_index(width);
+        double& ema = c->wait_ema_us[wi][b];
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         const double nap = ema - kMarginUs;
@@ -280,7 +283,8 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
 
 int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params, size_t n)
 {
-    PNN_UNSAFE_CALLS_GUARD;
+    // (the process-wide lock of the capture-unsafe calls is taken where those calls are -- upload() / free_model() in pnn_model.cpp, the
+    // tail below -- not around the file read and the weight packing: HM loads its five models on five threads, and they should overlap)
     if (!c || !params) return fail(c, PNN_E_ARG, "NULL argument");
     const int idx = width_index(width);
     if (idx < 0) return fail(c, PNN_E_ARG, "width %d is not in {4, 8, 16, 32, 64}", width);
@@ -288,6 +292,7 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
     Model* m = nullptr;
     const int rc = build_model(c, width, is_fc, params, n, &m);
     if (rc) return rc;
+    PNN_UNSAFE_CALLS_GUARD;
     free_model(c->models[idx]);
     c->models[idx] = m;
     c->tuned.clear(); c->tune_gen++;                                 // keys point into the replaced model
@@ -297,7 +302,6 @@ int pnn_load_model_params(pnn_ctx* c, int width, int is_fc, const float* params,
 
 int pnn_load_model_file(pnn_ctx* c, const char* path)
 {
-    PNN_UNSAFE_CALLS_GUARD;
     if (!c || !path) return fail(c, PNN_E_ARG, "NULL argument");
     std::vector<char> data;
     if (!read_file(path, &data)) return fail(c, PNN_E_IO, "The model file at \"%s\" cannot be loaded.", path);
@@ -794,7 +798,7 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         if (stamping && rc == PNN_OK) {
             timespec tw0, tw1;
             clock_gettime(CLOCK_MONOTONIC, &tw0);
-            const int wrc = c->done_armed ? wait_done_flag(c, s, n) : wait_stream(c, s);
+            const int wrc = c->done_armed ? wait_done_flag(c, s, n, w) : wait_stream(c, s);
             clock_gettime(CLOCK_MONOTONIC, &tw1);
             if (wrc) return wrc;
             HIPCHK(c, hipDeviceSynchronize());
@@ -824,7 +828,7 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         c->done_want = false;
         if (rc) return rc;
         if (host_trace) clock_gettime(CLOCK_MONOTONIC, &ht1);
-        if ((rc = c->done_armed ? wait_done_flag(c, s, n) : wait_stream(c, s))) return rc;
+        if ((rc = c->done_armed ? wait_done_flag(c, s, n, w) : wait_stream(c, s))) return rc;
         if (host_trace) {
             clock_gettime(CLOCK_MONOTONIC, &ht2);
             static double s_launch = 0, s_wait = 0; static long s_n = 0;

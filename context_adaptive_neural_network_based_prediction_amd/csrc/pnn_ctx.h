@@ -11,6 +11,7 @@
 
 #include <functional>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -146,6 +147,9 @@ struct pnn_ctx {
     // weights come from the MALL / HBM, not from L2, and the short ring does not cover that latency)
     long opt_f32_small_deep = 1;
     unsigned* d_seg_cnt = nullptr;                    // the tiles' arrival counters: [2 branches][kSegCntTiles], zero between launches
+    // ... which only the LAST workgroup of a tile restores: after any HIP failure on this context (a launch that died part-way, a failed
+    // capture) they may not be -- and every later folded launch would wait for an arrival count it never sees.  Zeroed again before the next one.
+    bool seg_cnt_dirty = false;
     static constexpr int kSegCntTiles = 2048;
     long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles
     long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
@@ -199,7 +203,7 @@ struct pnn_ctx {
     // SLEEPS for the part of the wait it can predict -- a running mean of this context's waits per batch-size bucket, minus a margin --
     // and spins only for the rest.  Off by default (a stand-alone codec has nothing else to do with its core); the service turns it on.
     long opt_wait_sleep = 0;
-    double wait_ema_us[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // by floor(log2(blocks))
+    double wait_ema_us[5][12] = {};                   // by width index (a context with a table holds five nets: 40 us and 235 us calls) and floor(log2(blocks))
     long opt_ring_pm = 1;                             // ring kernel: position-major tiles that skip the taps in the padding (pnn_gemm_ring.hip)
     size_t ws_cap_bytes = (size_t)8 << 30;
     // diagnostic library only (make diag, PNN_B1_STAMPS=<call number>): per-workgroup 100 MHz stamps of the kernels of one small host call
@@ -218,6 +222,8 @@ struct pnn_ctx {
 namespace pnn {
 
 int fail(pnn_ctx* c, int code, const char* fmt, ...);
+// process-wide: held by a stream capture from begin to end and by every allocation / free / synchronous copy of the library (pnn_abi.cpp)
+std::recursive_mutex& unsafe_calls_lock();
 
 #define HIPCHK(c, expr)                                                                             \
     do {                                                                                            \

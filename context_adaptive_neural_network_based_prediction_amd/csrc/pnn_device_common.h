@@ -121,6 +121,18 @@ __device__ __forceinline__ void store16_through(f32x4* dst, f32x4 v)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
 #endif
 }
+// The same store for a value that IS a matrix-instruction result (the K-segment planes of tapgemm_f32_small_kernel): the wait states
+// between the MFMA's register write and the vector-memory read are inside the asm block -- 16 of them, what an 8-pass instruction
+// (v_mfma_f32_16x16x4_f32) asks for with room to spare -- instead of resting on where the register allocator put the accumulator
+// (in AGPRs the compiler's own v_accvgpr_read sits in between; in VGPRs nothing would: ADVICE r5).
+__device__ __forceinline__ void store16_through_mfma(f32x4* dst, f32x4 v)
+{
+#ifdef PNN_PLAIN_STORES
+    *dst = v;
+#else
+    asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#endif
+}
 
 // Split activation layout of the split-precision GEMM: element (pixel, channel n) of a [pixels][C] tensor lives at
 // f16 index 2*pixel*C + (n/16)*32 + n%16 (hi) and +16 (lo); x = hi + lo with hi = (f16) x, lo = (f16)(x - hi).

@@ -263,7 +263,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         const int gxs = (p.M + 15) >> 4, tile = (cls * gy + by) * gxs + bx;
         const size_t plane_floats = (size_t)p.ncls * gy * gxs * 256;
         float* const plane0 = p.Y + (size_t)tile * 256 + lane * 4;
-        store16_through(reinterpret_cast<f32x4*>(plane0 + (size_t)seg * plane_floats), acc);
+        store16_through_mfma(reinterpret_cast<f32x4*>(plane0 + (size_t)seg * plane_floats), acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // acknowledged: the plane's bytes are in memory
         unsigned* const cnt = p.seg_cnt + tile;
         unsigned old = 0;

@@ -4,6 +4,8 @@
 // pnn/PredictionNeuralNetwork.py:126-132.
 #include "pnn_ctx.h"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +20,7 @@ namespace {
 int upload(pnn_ctx* c, Model* m, const float* host, size_t n, float** out)
 {
     void* d = nullptr;
+    std::lock_guard<std::recursive_mutex> guard(unsafe_calls_lock());   // allocation + synchronous copy: never beside another thread's stream capture (pnn_abi.cpp)
     if (hipMalloc(&d, std::max(n, (size_t)4) * sizeof(float)) != hipSuccess)
         return fail(c, PNN_E_NOMEM, "hipMalloc of %zu weight floats failed", n);
     m->allocs.push_back(d);
@@ -250,6 +253,7 @@ int build_tconv_layer(pnn_ctx* c, Model* m, const float* W, const float* b, int 
 void free_model(Model* m)
 {
     if (!m) return;
+    std::lock_guard<std::recursive_mutex> guard(unsafe_calls_lock());
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
 }

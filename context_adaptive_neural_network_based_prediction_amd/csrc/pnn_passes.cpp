@@ -115,6 +115,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         const long seg_tiles = nseg > 1 ? tapgemm_f32_small_tiles(p) / nseg : 0;
         const bool fold = nseg > 1 && c->opt_seg_fold && c->d_seg_cnt && seg_tiles <= pnn_ctx::kSegCntTiles && !c->opt_time_launches;
         if (fold) {
+            if (c->seg_cnt_dirty) {                   // see pnn_ctx::seg_cnt_dirty
+                HIPCHK(c, hipMemsetAsync(c->d_seg_cnt, 0, 2 * pnn_ctx::kSegCntTiles * 4, s));
+                if (c->side_stream && s != c->side_stream) HIPCHK(c, hipStreamSynchronize(s));   // (the other branch's launches use the second half on the side stream)
+                c->seg_cnt_dirty = false;
+            }
             ps.seg_cnt = c->d_seg_cnt + ((c->side_stream && s == c->side_stream) ? pnn_ctx::kSegCntTiles : 0);
             ps.seg_Y = Y; ps.bias = L.d_bias; ps.act = L.proto.act;
             DevBuf& sb = c->seg_part[(c->side_stream && s == c->side_stream) ? 1 : 0];   // tile-major planes: 1 KiB per (segment, tile)

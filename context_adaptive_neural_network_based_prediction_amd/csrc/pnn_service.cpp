@@ -467,7 +467,7 @@ struct Server {
         auto last_sweep = Clock::now();
         std::vector<uint64_t> gone;
         int deal = 0;                                // listener: next I/O thread to get a connection
-        while (!*stop) {
+        while (!__atomic_load_n(const_cast<const int*>(stop), __ATOMIC_ACQUIRE)) {   // (an atomic load of the caller's flag: `volatile` alone is a data race by the letter)
             const int r = epoll_wait(ep, evs, 256, 50);
             gone.clear();
             for (int i = 0; i < r; i++) {
@@ -618,6 +618,9 @@ int pnn_service_run_backend(const char* socket_path, pnn_service_backend backend
     sv.backend = backend; sv.nworkers = 1; sv.max_batch = max_batch; sv.window_us = window_us; sv.stop = stop;
     for (auto& ur : sv.users) for (void*& u : ur) u = user;
     sv.nio = 2;
+    // $PNN_SERVICE_WORKERS=5: one worker thread per width, as pnn_service_run_table has them -- the backend is then called from five
+    // threads at once and must be thread-safe (the race-detector driver tests/tsan_service.cpp: the production thread layout without a GPU)
+    if (const char* e = getenv("PNN_SERVICE_WORKERS")) if (atoi(e) == 5) { sv.nworkers = 5; sv.nio = 4; }
     { const char* e = getenv("PNN_SERVICE_TAG"); for (auto& t : sv.tag) t = e ? e : "backend:unspecified"; }
     return sv.run(socket_path, stats);
 }
@@ -724,6 +727,10 @@ int pnn_service_run_table(const char* socket_path, const char* model_table_path,
         own_queues = own_queues && !getenv("PNN_SERVICE_GROUPS") && !getenv("PNN_SERVICE_PRIORITIES");
         if (own_queues) {
             nqs = pnn_streams_on_distinct_queues(qs, 4);
+            // (said out loud: with fewer than four measured queues the service falls back to one stream and thread per width, where two
+            // busy widths may share a hardware queue -- a campaign's calls then take visibly longer, and the log should say why)
+            fprintf(stderr, "[pnn-service] hardware queues: %d of 4 measured distinct -> %s\n", nqs,
+                    nqs == 4 ? "widths 4 / 8 / 16 on a queue of their own, 32 + 64 share the fourth" : "FALLBACK: every context on the stream it created, one thread per width");
             if (nqs == 4) {
                 static const int kQueueOf[5] = {0, 1, 2, 3, 3};
                 for (int k = 0; k < 5; k++) { pnn_set_option(ctxs[k][0], "stream", (long)qs[kQueueOf[k]]); sv.group[k] = kQueueOf[k]; }

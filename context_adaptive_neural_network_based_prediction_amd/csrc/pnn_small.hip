@@ -812,6 +812,13 @@ __global__ void queue_probe_empty_kernel() {}
 hipError_t probe_queue_shared(hipStream_t a, hipStream_t b, bool* shared)
 {
     constexpr double kBusyUs = 150.0;
+    // warm-up first: the streams' first submissions (lazy queue creation, code-object load) must not fall into the timed window -- a slow
+    // first launch on `b` would read as "shared" 
+    hipLaunchKernelGGL(queue_probe_empty_kernel, dim3(1), dim3(64), 0, a);
+    hipLaunchKernelGGL(queue_probe_empty_kernel, dim3(1), dim3(64), 0, b);
+    hipError_t w = hipStreamSynchronize(a);
+    if (w == hipSuccess) w = hipStreamSynchronize(b);
+    if (w != hipSuccess) return w;
     hipLaunchKernelGGL(queue_probe_busy_kernel, dim3(1), dim3(64), 0, a, (unsigned)(kBusyUs * 100.0));
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -617,6 +617,19 @@ def test_host_code_under_sanitizers(tmp_path):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_service_under_thread_sanitizer(tmp_path):
+    """`make -C csrc tsan`: the batching service -- server in its production thread layout (five width workers, four I/O
+    threads) and client stub -- under ThreadSanitizer, driven by tests/tsan_service.cpp: 32 client threads against a stand-in backend
+    with randomised latencies, with and without a batching window, clients that reconnect / vanish mid-request / die with a request in
+    flight, tag requests, a server stopped under load.  Any report ends the run with exit code 66.  (3000 requests per client here,
+    `make tsan` alone runs 10000: profiles/r06_tsan_service.txt.)  CPU build only."""
+    csrc = os.path.join(ROOT, "context_adaptive_neural_network_based_prediction_amd", "csrc")
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(["make", "-C", csrc, "tsan", "N=3000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "tsan_service: ok" in r.stdout and "ThreadSanitizer" not in r.stdout + r.stderr
+
+
 def test_model_table_parser_against_the_reference_parser(tmp_path):
     """pnn_parse_model_table (csrc/pnn_host.cpp) vs the REFERENCE's parse_file_strings_three_keys (tools.cpp:52-111, built into
     oracle/_ref/libref_tools.so by oracle/Makefile) on fuzzed tables: runs of ',' / ';' delimiters, blank and whitespace-only
