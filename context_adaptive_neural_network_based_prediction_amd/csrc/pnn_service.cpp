@@ -10,7 +10,10 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <linux/futex.h>
 #include <poll.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
 #include <sys/epoll.h>
 #include <sys/eventfd.h>
 #include <sys/prctl.h>
@@ -25,8 +28,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -39,8 +42,53 @@ constexpr uint32_t kWantF32 = 1u;          // flags bit 0: reply with the float 
 constexpr uint32_t kWantTag = 2u;          // flags bit 1: no inputs; reply = the arithmetic tag of the context that serves `width` (pnn_arithmetic_tag)
 constexpr size_t kTagBytes = 256;          // a tag reply's payload: the string, zero-padded
 constexpr long kStallMs = 5000;            // a reply that cannot be delivered for this long drops its client
+constexpr uint32_t kWantShm = 4u;          // flags bit 2: no inputs; the client asks for the shared-memory request path (see ShmSlot)
 struct ReqHeader { uint32_t magic; int32_t width; uint32_t n_above, n_left, flags; };   // followed by the floats
 struct RspHeader { int32_t rc; uint32_t n_vals; };                                       // followed by n_vals int32 / float
+
+// ---- the shared-memory request path (round 6) --------------------------------------------------------------------------------------
+// Over the socket a request crosses four thread wake-ups and ten system calls (client send / recv, I/O thread epoll + recv, worker
+// wake-up, eventfd, I/O thread epoll + read + send: tools/service_load.cpp) and is copied four times before the first kernel sees it;
+// round 5's campaigns spent 19-27 CPU-seconds in the service and 95-120 us per 4x4 request inside it for a 40 us call.  Now the socket
+// is the CONTROL channel only (connect, hand-shake, teardown: its closing is how the server learns that a client died), and every
+// client owns ONE request slot in a memfd both sides map (one outstanding request per client -- HM's calling pattern):
+//   client:  writes header + context into its slot, state = kPosted, rings the doorbell of the width's worker (a futex word in a page
+//            all clients share; a system call only if that worker sleeps), then sleeps on its slot's state word;
+//   worker:  scans the slots for posted requests of its widths (kPosted -> kTaken by compare-and-swap), copies the contexts ONCE into
+//            the batch's staging, runs the backend, writes reply header + values into each slot, state = kReady, wakes the client.
+// Two wake-ups and two or three system calls per request; the I/O threads shrink to accept / hand-shake / teardown (and still serve
+// clients that speak the socket protocol: $PNN_SERVICE_SHM=0 in a client, the tests' raw sockets).  A client that dies with a request
+// in its slot: the control socket closes, the slot is unlisted, a worker that already holds it writes its reply into memory nobody
+// reads (the mapping lives as long as the last reference).  The server validates the header it reads from a slot exactly as one from a
+// socket: what a client scribbles into its own slot can only spoil its own reply.
+enum : uint32_t { kSlotIdle = 0, kSlotPosted = 1, kSlotTaken = 2, kSlotReady = 3 };
+constexpr size_t kShmInFloats = (size_t)5 * 64 * 64, kShmOutVals = (size_t)64 * 64;    // the largest request: a 64x64 block
+struct ShmSlot {
+    std::atomic<uint32_t> state;                      // the CLIENT's futex word
+    std::atomic<uint32_t> client_sleeps;              // the client is (about to be) asleep on `state`: the server wakes it
+    ReqHeader hdr;                                    // client, before state = kSlotPosted
+    uint64_t posted_ns;                               // CLOCK_MONOTONIC at the post (the server's queueing statistics)
+    alignas(64) RspHeader rsp;                        // server, before state = kSlotReady
+    alignas(64) float in[kShmInFloats];               // [n_above | n_left]
+    alignas(64) uint32_t out[kShmOutVals];            // int32 Pel or float, as the request asked
+};
+struct ShmDoor { alignas(64) std::atomic<uint32_t> bell; std::atomic<uint32_t> sleeping; };   // a worker's futex word + "I am (about to be) asleep"
+// ... and one BIT per (worker, slot): set by a client behind its post (fetch_or), claimed by the worker that looks (exchange of the
+// whole word) -- a worker finds the posted slots in ITS 16 words instead of touching one cache line per connected client (a
+// 100-encoder campaign holds 500 slots); the slot's state word stays the truth: a stale bit costs one look, a bit that was never set
+// belongs to a client that died.
+constexpr int kShmMaxSlots = 1024;
+struct ShmDoors { ShmDoor door[5]; alignas(64) std::atomic<uint64_t> posted[5][kShmMaxSlots / 64]; };
+constexpr size_t kSlotBytes = (sizeof(ShmSlot) + 4095) / 4096 * 4096, kDoorBytes = (sizeof(ShmDoors) + 4095) / 4096 * 4096;
+static_assert(std::atomic<uint32_t>::is_always_lock_free && std::atomic<uint64_t>::is_always_lock_free, "futex words and flags in shared memory");
+
+long futex_wait(std::atomic<uint32_t>* addr, uint32_t expect, long timeout_us)
+{
+    timespec ts{timeout_us / 1000000, (timeout_us % 1000000) * 1000};
+    return syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAIT, expect, &ts, nullptr, 0);   // (not _PRIVATE: the word is shared between processes)
+}
+long futex_wake(std::atomic<uint32_t>* addr, int n) { return syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAKE, n, nullptr, nullptr, 0); }
+uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 
 using Clock = std::chrono::steady_clock;
 
@@ -71,14 +119,22 @@ bool valid_width(int w) { return w == 4 || w == 8 || w == 16 || w == 32 || w == 
 
 bool valid_header(const ReqHeader& h)
 {
-    if (h.magic != kMagic || !valid_width(h.width) || (h.flags & ~(kWantF32 | kWantTag))) return false;
-    if (h.flags & kWantTag) return h.flags == kWantTag && h.n_above == 0 && h.n_left == 0;
+    if (h.magic != kMagic || !valid_width(h.width) || (h.flags & ~(kWantF32 | kWantTag | kWantShm))) return false;
+    if (h.flags & (kWantTag | kWantShm)) return (h.flags == kWantTag || h.flags == kWantShm) && h.n_above == 0 && h.n_left == 0;
     const uint32_t w2 = (uint32_t)(h.width * h.width);
     return (h.n_above == 5 * w2 && h.n_left == 0) || (h.n_above == 3 * w2 && h.n_left == 2 * w2);
 }
 
+struct ShmClient {                                     // server side of one client's slot; shared by the registry, the owning I/O thread and the requests in flight
+    ShmSlot* slot = nullptr;
+    int index = -1;                                   // its byte in every worker's flag array
+    std::atomic<bool> dead{false};
+    ~ShmClient() { if (slot) munmap(slot, kSlotBytes); }
+};
+
 struct Client {
     int fd = -1;
+    std::shared_ptr<ShmClient> shm;  // set by the hand-shake: this client's requests arrive through its slot
     int pid = 0;                     // peer process (SO_PEERCRED): an encoder holds one connection per session, one request at a time
     std::vector<char> rx;            // bytes of the request being received
     std::vector<char> tx;            // reply bytes not yet accepted by the socket
@@ -122,6 +178,11 @@ int ctx_backend(void* user, int width, const float* above, const float* left, in
 struct ClientCacheEntry { uint64_t hash = 0; bool valid = false; std::vector<char> in, vals; };
 struct pnn_client {
     int fd;
+    // the shared-memory request path (see ShmSlot above): this client's slot and the workers' doorbells, or NULL on the socket protocol
+    void* slot = nullptr;
+    void* doors = nullptr;
+    int worker_of[5] = {0, 0, 0, 0, 0};
+    int index = -1;                                   // this client's bit in the workers' "posted" words
     std::vector<char> buf, rbuf;                      // request / reply bytes
     size_t cache_bytes = 0;                           // 0 = off
     std::vector<ClientCacheEntry> cache[5][2];
@@ -168,14 +229,65 @@ struct Server {
     // behind a service on one arithmetic and a stand-alone decoder on another drift apart silently.  Read-only after start.
     std::string tag[5];
 
-    struct Req { uint64_t id; int width; bool want_f32; std::vector<float> above, left; Clock::time_point t_in; };
+    // One request on its way to a worker: from a socket (the floats were copied out of the receive buffer) or in a client's slot (`shm`:
+    // the floats stay where the client wrote them until the batch is staged)
+    struct Req {
+        uint64_t id; int width; bool want_f32; std::vector<float> above, left; Clock::time_point t_in;
+        std::shared_ptr<ShmClient> shm;
+        uint32_t na = 0, nl = 0;                      // floats of the two inputs
+        const float* A() const { return shm ? shm->slot->in : above.data(); }
+        const float* L() const { return shm ? shm->slot->in + na : left.data(); }
+    };
     struct Reply { uint64_t id; std::vector<char> bytes; Clock::time_point t_in; int k; };
     // Locks: one per worker queue (with its condition variable), one per I/O thread's reply / new-connection queues, one for
     // the peer accounting (only kept when a batching window is set) and the statistics.  (A single server-wide mutex was taken
     // five times per request by nine threads.)
     std::mutex qmu[5];
-    std::condition_variable cv[5];
-    std::vector<Req> queue[5];       // by worker, under qmu[k]
+    std::vector<Req> queue[5];       // socket requests by worker, under qmu[k]
+    // The workers' doorbells (ShmDoors: one futex word + a "sleeping" flag per worker) live in a page every shm client maps; the I/O
+    // threads ring them for socket requests too.  The slots of the connected shm clients: an immutable snapshot, replaced under shm_mu
+    // at hand-shake / teardown, read by the workers without a lock of their own.
+    ShmDoors* doors = nullptr;
+    int door_fd = -1;
+    // The slots of the connected shm clients by index (the index of their flag bytes): entries are replaced by the I/O threads at
+    // hand-shake / teardown (under shm_mu, std::atomic_store) and read by the workers with std::atomic_load.
+    std::mutex shm_mu;
+    std::shared_ptr<ShmClient> shm_table[kShmMaxSlots];
+    std::atomic<int> shm_hi{0};                       // indices >= this were never handed out
+    std::atomic<long> shm_clients{0}, shm_requests{0};
+    // The wake-ups of a batch's clients are NOT the worker's job: one futex_wake per client is 2-4 us of system call, in front of the
+    // worker's next batch (first form of round 6: configs[3] 4.88 -> 5.11 s, the 4x4 / 8x8 workers being what its encoders wait for;
+    // profiles/r06_service_transport.txt).  The worker writes the replies and flips the states -- a client that is not asleep yet sees
+    // its reply at once -- and hands the sleepers to its WAKER thread: one doorbell per batch instead of one system call per client.
+    struct Waker {
+        std::mutex mu;
+        std::vector<std::shared_ptr<ShmClient>> todo;
+        std::atomic<uint32_t> bell{0}, sleeping{0};
+        std::thread th;
+    } wakers[5];
+    void waker_loop(int k)
+    {
+        { char nm[16]; snprintf(nm, sizeof nm, "pnn-wk%d", nworkers == 1 ? 0 : kServiceWidthsOf(k)); prctl(PR_SET_NAME, nm, 0, 0, 0); }
+        Waker& wk = wakers[k];
+        std::vector<std::shared_ptr<ShmClient>> mine;
+        for (;;) {
+            { std::lock_guard<std::mutex> lk(wk.mu); mine.swap(wk.todo); }
+            for (auto& sc : mine) futex_wake(&sc->slot->state, 1);
+            if (!mine.empty()) { mine.clear(); continue; }
+            if (quit_flag.load()) return;
+            const uint32_t seen = wk.bell.load(std::memory_order_seq_cst);
+            wk.sleeping.store(1, std::memory_order_seq_cst);
+            bool any;
+            { std::lock_guard<std::mutex> lk(wk.mu); any = !wk.todo.empty(); }
+            if (!any && !quit_flag.load()) futex_wait(&wk.bell, seen, 50000);
+            wk.sleeping.store(0, std::memory_order_seq_cst);
+        }
+    }
+    void ring(int k)                 // a request for worker k has been posted (queue or slot): wake it if it sleeps
+    {
+        doors->door[k].bell.fetch_add(1, std::memory_order_seq_cst);
+        if (doors->door[k].sleeping.load(std::memory_order_seq_cst)) futex_wake(&doors->door[k].bell, 1);
+    }
     std::mutex dmu[8];               // done[t], fresh[t]
     std::mutex mu;                   // peers, statistics
     // Socket work is spread over `nio` I/O threads (round 3): ONE thread doing every recv / send / epoll_wait topped out at
@@ -201,6 +313,8 @@ struct Server {
     // (wait_s, under `mu`), and to its reply accepted by the socket (resident_s, per I/O thread: no lock).
     double wait_s[5] = {0, 0, 0, 0, 0}, resident_s[kMaxIo][5] = {};
     long resident_n[kMaxIo][5] = {};
+    double shm_resident_s[5] = {0, 0, 0, 0, 0};      // ... of the requests that came through slots: post -> reply written (under `mu`)
+    long shm_resident_n[5] = {0, 0, 0, 0, 0};
 
     static int widx(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4; }
     static int kServiceWidthsOf(int k) { return 4 << k; }
@@ -213,32 +327,91 @@ struct Server {
         bool any_f32 = false, any_pel = false;
         double waited = 0;                           // seconds the requests sat in the queue, summed
     };
-    // one batch = requests of ONE width and ONE input kind, in arrival order; under qmu[k]
+    // An error reply written straight into a slot (a request that never reaches the backend).
+    void slot_reply_error(ShmSlot* sl, int rc)
+    {
+        sl->rsp = RspHeader{rc, 0u};
+        sl->state.store(kSlotReady, std::memory_order_seq_cst);
+        if (sl->client_sleeps.load(std::memory_order_seq_cst)) futex_wake(&sl->state, 1);
+    }
+    // one batch = requests of ONE width and ONE input kind: the socket requests queued for worker k in arrival order (under qmu[k],
+    // taken here), then the posted slots of the shm clients (claimed by compare-and-swap: a slot belongs to the worker that took it)
     void take(int k, std::vector<Req>& batch)
     {
         batch.clear();
-        if (queue[k].empty()) return;
-        const int w = queue[k][0].width;
-        const bool has_left = !queue[k][0].left.empty();
-        for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
-            if (queue[k][i].width == w && !queue[k][i].left.empty() == has_left) {
-                batch.push_back(std::move(queue[k][i]));
-                queue[k].erase(queue[k].begin() + (long)i);
-            } else {
-                ++i;
+        int w = 0;
+        bool has_left = false;
+        {
+            std::lock_guard<std::mutex> lk(qmu[k]);
+            if (!queue[k].empty()) {
+                w = queue[k][0].width;
+                has_left = queue[k][0].nl != 0;
+                for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
+                    if (queue[k][i].width == w && (queue[k][i].nl != 0) == has_left) {
+                        batch.push_back(std::move(queue[k][i]));
+                        queue[k].erase(queue[k].begin() + (long)i);
+                    } else {
+                        ++i;
+                    }
+                }
             }
         }
+        std::atomic<uint64_t>* const flags = doors->posted[k];
+        const int hi = shm_hi.load(std::memory_order_acquire);
+        for (int wd = 0; wd * 64 < hi && (int)batch.size() < max_batch; wd++) {
+            if (!flags[wd].load(std::memory_order_acquire)) continue;
+            uint64_t bits = flags[wd].exchange(0, std::memory_order_seq_cst);   // claimed BEFORE the look: a post behind it sets its bit again
+            uint64_t leave = 0;                                                  // ... and what is not this batch's goes back
+            while (bits) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if ((int)batch.size() >= max_batch) { leave |= 1ull << b; continue; }
+                const int idx = wd * 64 + b;
+                const std::shared_ptr<ShmClient> sc = std::atomic_load(&shm_table[idx]);
+                if (!sc || sc->dead.load(std::memory_order_relaxed)) continue;
+                ShmSlot* sl = sc->slot;
+                if (sl->state.load(std::memory_order_seq_cst) != kSlotPosted) continue;
+                const ReqHeader h = sl->hdr;             // a copy: the client may scribble, the checks below are made on what is used
+                const bool well = h.magic == kMagic && valid_width(h.width);
+                if (well && worker_of(h.width) != k) {   // rang the wrong bell: passed on
+                    doors->posted[worker_of(h.width)][wd].fetch_or(1ull << b, std::memory_order_seq_cst);
+                    ring(worker_of(h.width));
+                    continue;
+                }
+                if (well && w && (h.width != w || (h.n_left != 0) != has_left)) { leave |= 1ull << b; continue; }   // this worker's, another batch's
+                uint32_t expect = kSlotPosted;
+                if (!sl->state.compare_exchange_strong(expect, kSlotTaken, std::memory_order_acq_rel)) continue;
+                ++shm_requests;
+                if (!valid_header(h) || (h.flags & (kWantTag | kWantShm))) { slot_reply_error(sl, PNN_E_ARG); continue; }
+                const int kd = kind[widx(h.width)];
+                if (kd == -2 || (kd >= 0 && (kd == 1) != (h.n_left == 0))) { ++refused; slot_reply_error(sl, kd == -2 ? PNN_E_MODEL : PNN_E_ARG); continue; }
+                if (!w) { w = h.width; has_left = h.n_left != 0; }
+                Req r;
+                r.id = 0; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0; r.shm = sc; r.na = h.n_above; r.nl = h.n_left;
+                const uint64_t now = now_ns(), posted = sl->posted_ns;
+                r.t_in = Clock::now() - std::chrono::nanoseconds(posted <= now && now - posted < 60000000000ull ? now - posted : 0);
+                batch.push_back(std::move(r));
+            }
+            if (leave) flags[wd].fetch_or(leave, std::memory_order_seq_cst);
+        }
+    }
+    bool has_pending(int k)          // anything worker k could take right now?  (a stale bit says yes once: take() clears it)
+    {
+        { std::lock_guard<std::mutex> lk(qmu[k]); if (!queue[k].empty()) return true; }
+        const int hi = shm_hi.load(std::memory_order_acquire);
+        for (int wd = 0; wd * 64 < hi; wd++) if (doors->posted[k][wd].load(std::memory_order_seq_cst)) return true;
+        return false;
     }
     void stage(Flight& f)
     {
-        const size_t n = f.batch.size(), na = f.batch[0].above.size(), nl = f.batch[0].left.size();
+        const size_t n = f.batch.size(), na = f.batch[0].na, nl = f.batch[0].nl;
         f.any_f32 = f.any_pel = false;
         f.above.resize(n * na); f.left.resize(n * nl);
         const auto now = Clock::now();
         f.waited = 0;
         for (size_t i = 0; i < n; i++) {
-            memcpy(f.above.data() + i * na, f.batch[i].above.data(), na * 4);
-            if (nl) memcpy(f.left.data() + i * nl, f.batch[i].left.data(), nl * 4);
+            memcpy(f.above.data() + i * na, f.batch[i].A(), na * 4);
+            if (nl) memcpy(f.left.data() + i * nl, f.batch[i].L(), nl * 4);
             (f.batch[i].want_f32 ? f.any_f32 : f.any_pel) = true;
             f.waited += std::chrono::duration<double>(now - f.batch[i].t_in).count();
         }
@@ -248,16 +421,37 @@ struct Server {
     {
         const size_t n = f.batch.size(), w2 = (size_t)f.batch[0].width * f.batch[0].width;
         const int wi = nworkers == 1 ? k : widx(f.batch[0].width);   // the statistics are kept per WIDTH (two widths may share a worker thread)
-        std::vector<Reply> replies(n);
+        std::vector<Reply> replies;
+        replies.reserve(n);
+        std::vector<std::shared_ptr<ShmClient>> sleepers;
+        double shm_resident = 0;
+        long shm_n = 0;
         for (size_t i = 0; i < n; i++) {
             const RspHeader rh{rc, rc == 0 ? (uint32_t)w2 : 0u};
-            replies[i].id = f.batch[i].id; replies[i].t_in = f.batch[i].t_in; replies[i].k = wi;
+            if (f.batch[i].shm) {                      // into the client's slot, by this thread: values, header, state, wake-up
+                ShmSlot* sl = f.batch[i].shm->slot;
+                if (rc == 0) memcpy(sl->out, f.batch[i].want_f32 ? reinterpret_cast<const void*>(out + i * w2) : reinterpret_cast<const void*>(dst + i * w2), w2 * 4);
+                sl->rsp = rh;
+                sl->state.store(kSlotReady, std::memory_order_seq_cst);
+                if (sl->client_sleeps.load(std::memory_order_seq_cst)) sleepers.push_back(f.batch[i].shm);   // (a client that has not gone to sleep yet re-reads the state first)
+                shm_resident += std::chrono::duration<double>(Clock::now() - f.batch[i].t_in).count(); ++shm_n;
+                continue;
+            }
+            replies.emplace_back();
+            Reply& rp = replies.back();
+            rp.id = f.batch[i].id; rp.t_in = f.batch[i].t_in; rp.k = wi;
             const char* hp = reinterpret_cast<const char*>(&rh);
-            replies[i].bytes.assign(hp, hp + sizeof rh);
+            rp.bytes.assign(hp, hp + sizeof rh);
             if (rc == 0) {
                 const char* pp = f.batch[i].want_f32 ? reinterpret_cast<const char*>(out + i * w2) : reinterpret_cast<const char*>(dst + i * w2);
-                replies[i].bytes.insert(replies[i].bytes.end(), pp, pp + w2 * 4);
+                rp.bytes.insert(rp.bytes.end(), pp, pp + w2 * 4);
             }
+        }
+        if (!sleepers.empty()) {                     // to the waker: ONE doorbell for the batch
+            Waker& wk = wakers[k];
+            { std::lock_guard<std::mutex> lk(wk.mu); for (auto& sc : sleepers) wk.todo.push_back(std::move(sc)); }
+            wk.bell.fetch_add(1, std::memory_order_seq_cst);
+            if (wk.sleeping.load(std::memory_order_seq_cst)) futex_wake(&wk.bell, 1);
         }
         bool woke[kMaxIo] = {false};
         for (int t = 0; t < nio; t++) {          // replies to their owners, one lock per I/O thread that has any
@@ -273,24 +467,55 @@ struct Server {
         std::lock_guard<std::mutex> lk(mu);
         served += (long)n; ++calls; largest = std::max<long>(largest, (long)n);
         ++calls_w[wi]; served_w[wi] += (long)n; busy_s[wi] += busy; wait_s[wi] += f.waited;
+        shm_resident_s[wi] += shm_resident; shm_resident_n[wi] += shm_n;
     }
-    // Blocks until worker k has something to do (false: the server stops).  An idle worker gives stragglers a moment to join --
-    // unless every peer process already waits for an answer (an encoder is single-threaded and blocks on its request: nobody
-    // else can arrive).
+    // Blocks until worker k has something to do (false: the server stops).  An idle worker sleeps on its doorbell (a futex word the
+    // clients and the I/O threads ring); with a batching window it gives stragglers a moment to join -- unless every peer process
+    // already waits for an answer (an encoder is single-threaded and blocks on its request: nobody else can arrive).
     bool wait_for_work(int k, std::vector<Req>& batch)
     {
-        std::unique_lock<std::mutex> lk(qmu[k]);
-        cv[k].wait(lk, [&] { return quit_flag.load() || !queue[k].empty(); });
-        if (quit_flag.load()) return false;
-        if (window_us > 0 && (int)queue[k].size() < max_batch && n_waiting_peers.load() < n_peers.load()) {
-            const auto until = Clock::now() + std::chrono::microseconds(window_us);
-            cv[k].wait_until(lk, until, [&] { return quit_flag.load() || (int)queue[k].size() >= max_batch || n_waiting_peers.load() >= n_peers.load(); });
+        ShmDoor& d = doors->door[k];
+        for (;;) {
             if (quit_flag.load()) return false;
+            take(k, batch);
+            if (!batch.empty()) {
+                if (window_us > 0 && (int)batch.size() < max_batch && n_waiting_peers.load() < n_peers.load()) {
+                    const auto until = Clock::now() + std::chrono::microseconds(window_us);
+                    while ((int)batch.size() < max_batch && n_waiting_peers.load() < n_peers.load() && !quit_flag.load()) {
+                        const auto now = Clock::now();
+                        if (now >= until) break;
+                        const uint32_t seen = d.bell.load(std::memory_order_seq_cst);
+                        d.sleeping.store(1, std::memory_order_seq_cst);
+                        if (!has_pending(k)) futex_wait(&d.bell, seen, std::max<long>(1, std::chrono::duration_cast<std::chrono::microseconds>(until - now).count()));
+                        d.sleeping.store(0, std::memory_order_seq_cst);
+                        take_more(k, batch);
+                    }
+                    if (quit_flag.load()) return false;
+                }
+                return true;
+            }
+            const uint32_t seen = d.bell.load(std::memory_order_seq_cst);
+            d.sleeping.store(1, std::memory_order_seq_cst);
+            if (!has_pending(k) && !quit_flag.load()) futex_wait(&d.bell, seen, 50000);   // (bounded: a lost wake-up costs 50 ms, not the server)
+            d.sleeping.store(0, std::memory_order_seq_cst);
         }
-        // the lock was released during the window: the I/O thread may have dropped the only queued request
-        // (an encoder killed or timed out mid-window) -- the batch is then empty
-        take(k, batch);
-        return true;
+    }
+    // the batching window: requests of the batch's width and kind that arrived meanwhile join it
+    void take_more(int k, std::vector<Req>& batch)
+    {
+        const int w = batch[0].width;
+        const bool has_left = batch[0].nl != 0;
+        {
+            std::lock_guard<std::mutex> lk(qmu[k]);
+            for (size_t i = 0; i < queue[k].size() && (int)batch.size() < max_batch;) {
+                if (queue[k][i].width == w && (queue[k][i].nl != 0) == has_left) {
+                    batch.push_back(std::move(queue[k][i]));
+                    queue[k].erase(queue[k].begin() + (long)i);
+                } else {
+                    ++i;
+                }
+            }
+        }
     }
 
     void worker(int k, int r)
@@ -332,6 +557,61 @@ struct Server {
         if (is != was) n_waiting_peers += is ? 1 : -1;
     }
 
+    // The hand-shake of the shared-memory path: a memfd of one slot for this client, listed for the workers; the reply carries the slot's
+    // and the doorbell page's descriptors (SCM_RIGHTS) and the worker index of each width.  false = the client is dropped.
+    bool shm_handshake(Client& c)
+    {
+        if (c.shm || !c.tx.empty()) return false;                // once per connection, with nothing else under way
+        const int mfd = (int)syscall(SYS_memfd_create, "pnn-slot", 1u /* MFD_CLOEXEC */);
+        if (mfd < 0) return false;
+        void* mem = ftruncate(mfd, (off_t)kSlotBytes) == 0 ? mmap(nullptr, kSlotBytes, PROT_READ | PROT_WRITE, MAP_SHARED, mfd, 0) : MAP_FAILED;
+        if (mem == MAP_FAILED) { close(mfd); return false; }
+        auto sc = std::make_shared<ShmClient>();
+        sc->slot = new (mem) ShmSlot;                            // (fresh pages are zero: state = kSlotIdle)
+        {
+            std::lock_guard<std::mutex> lk(shm_mu);
+            for (int i = 0; i < kShmMaxSlots && sc->index < 0; i++) if (!shm_table[i]) sc->index = i;
+            if (sc->index >= 0) {
+                for (int k = 0; k < 5; k++) doors->posted[k][sc->index >> 6].fetch_and(~(1ull << (sc->index & 63)), std::memory_order_seq_cst);   // a bit its previous owner left
+                std::atomic_store(&shm_table[sc->index], sc);
+                if (sc->index >= shm_hi.load()) shm_hi.store(sc->index + 1, std::memory_order_release);
+            }
+        }
+        struct { RspHeader rh; int32_t worker[5]; int32_t index; } body;
+        body.rh = RspHeader{sc->index >= 0 ? 0 : PNN_E_NOMEM, 6u};     // more clients than flag bits: this one stays on the socket protocol
+        for (int i = 0; i < 5; i++) body.worker[i] = worker_of(4 << i);
+        body.index = sc->index;
+        if (sc->index < 0) {
+            close(mfd);
+            ssize_t ns;
+            do ns = send(c.fd, &body, sizeof body, MSG_NOSIGNAL); while (ns < 0 && errno == EINTR);
+            return ns == (ssize_t)sizeof body;
+        }
+        iovec iov{&body, sizeof body};
+        alignas(cmsghdr) char ctl[CMSG_SPACE(2 * sizeof(int))];
+        memset(ctl, 0, sizeof ctl);
+        msghdr mh;
+        memset(&mh, 0, sizeof mh);
+        mh.msg_iov = &iov; mh.msg_iovlen = 1; mh.msg_control = ctl; mh.msg_controllen = sizeof ctl;
+        cmsghdr* cm = CMSG_FIRSTHDR(&mh);
+        cm->cmsg_level = SOL_SOCKET; cm->cmsg_type = SCM_RIGHTS; cm->cmsg_len = CMSG_LEN(2 * sizeof(int));
+        const int fds[2] = {mfd, door_fd};
+        memcpy(CMSG_DATA(cm), fds, sizeof fds);
+        ssize_t sent;
+        do sent = sendmsg(c.fd, &mh, MSG_NOSIGNAL); while (sent < 0 && errno == EINTR);
+        close(mfd);                                              // the mapping and the client's descriptor keep the memory
+        if (sent != (ssize_t)sizeof body) { shm_unlist(sc); return false; }
+        c.shm = sc;
+        ++shm_clients;
+        return true;
+    }
+    void shm_unlist(const std::shared_ptr<ShmClient>& sc)
+    {
+        sc->dead.store(true);
+        std::lock_guard<std::mutex> lk(shm_mu);
+        if (sc->index >= 0 && std::atomic_load(&shm_table[sc->index]) == sc) std::atomic_store(&shm_table[sc->index], std::shared_ptr<ShmClient>());
+    }
+
     // One I/O thread: its share of the connections (receive, queue for the workers, reply); thread 0 also owns the listener.
     // epoll, not poll: with hundreds of connections (an encoder holds five) a poll set rebuilt and scanned per wake-up was what
     // bounded the server; event data = client ID (0: listener, 1: this thread's wake eventfd).
@@ -365,6 +645,7 @@ struct Server {
             close(it->second.fd);
             const int pid = it->second.pid;
             const bool was_in_flight = it->second.in_flight;
+            if (it->second.shm) shm_unlist(it->second.shm);          // a request still posted in its slot is never taken; one already taken is answered into the void
             clients.erase(it);
             if (was_in_flight)
                 for (int k = 0; k < nworkers; k++) {
@@ -403,6 +684,10 @@ struct Server {
                     if (c.rx.size() > want) return false;     // bytes of a second request behind an unanswered one
                     if (c.rx.size() == want) {
                         if (c.in_flight) return false;        // one outstanding request per client
+                        if (h.flags & kWantShm) {             // the hand-shake of the shared-memory request path: a slot for this client
+                            c.rx.clear();
+                            return shm_handshake(c);
+                        }
                         if (h.flags & kWantTag) {             // answered here, by the I/O thread: never queued
                             const RspHeader rh{0, (uint32_t)(kTagBytes / 4)};
                             char body[kTagBytes];
@@ -431,7 +716,7 @@ struct Server {
                         }
                         Req r;
                         r.id = id; r.width = h.width; r.want_f32 = (h.flags & kWantF32) != 0; r.t_in = Clock::now();
-                        r.above.resize(h.n_above); r.left.resize(h.n_left);
+                        r.above.resize(h.n_above); r.left.resize(h.n_left); r.na = h.n_above; r.nl = h.n_left;
                         memcpy(r.above.data(), c.rx.data() + sizeof h, (size_t)h.n_above * 4);
                         if (h.n_left) memcpy(r.left.data(), c.rx.data() + sizeof h + (size_t)h.n_above * 4, (size_t)h.n_left * 4);
                         c.in_flight = true;
@@ -442,10 +727,10 @@ struct Server {
                             std::lock_guard<std::mutex> lk(qmu[k]);
                             queue[k].push_back(std::move(r));
                         }
-                        cv[k].notify_one();
+                        ring(k);
                         // the other workers only care when "every peer waits" has just become true (they may be sitting in their window)
                         if (nworkers > 1 && window_us > 0 && n_waiting_peers.load() >= n_peers.load())
-                            for (int o = 0; o < nworkers; o++) if (o != k) { std::lock_guard<std::mutex> lk(qmu[o]); cv[o].notify_one(); }
+                            for (int o = 0; o < nworkers; o++) if (o != k) ring(o);
                         return true;
                     }
                 }
@@ -544,6 +829,12 @@ struct Server {
         if (make_addr(socket_path, &addr)) return PNN_E_ARG;
         if (const char* e = getenv("PNN_SERVICE_IO_THREADS")) nio = atoi(e);
         nio = std::max(1, std::min(nio, (int)kMaxIo));
+        // the doorbell page: the workers' futex words, mapped by every shm client
+        door_fd = (int)syscall(SYS_memfd_create, "pnn-doors", 1u /* MFD_CLOEXEC */);
+        void* dm = (door_fd >= 0 && ftruncate(door_fd, (off_t)kDoorBytes) == 0) ? mmap(nullptr, kDoorBytes, PROT_READ | PROT_WRITE, MAP_SHARED, door_fd, 0) : MAP_FAILED;
+        if (dm == MAP_FAILED) { if (door_fd >= 0) close(door_fd); return PNN_E_IO; }
+        doors = new (dm) ShmDoors;
+        struct DoorGuard { Server* sv; ~DoorGuard() { munmap(sv->doors, kDoorBytes); close(sv->door_fd); sv->doors = nullptr; } } door_guard{this};
         const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
         if (lfd < 0) return PNN_E_IO;
         unlink(socket_path);
@@ -579,24 +870,40 @@ struct Server {
             epoll_ctl(eps[0], EPOLL_CTL_ADD, lfd, &ev);
         }
         std::vector<std::thread> threads;
-        for (int k = 0; k < nworkers; k++)
+        for (int k = 0; k < nworkers; k++) {
             for (int r = 0; r < nrep[k]; r++) threads.emplace_back([this, k, r] { worker(k, r); });
+            wakers[k].th = std::thread([this, k] { waker_loop(k); });
+        }
         std::vector<std::thread> io;
         for (int t = 1; t < nio; t++) io.emplace_back([this, t, lfd, &eps] { io_loop(t, lfd, eps[t]); });
         io_loop(0, lfd, eps[0]);                     // the calling thread: listener + its share of the connections
         for (auto& th : io) th.join();
         quit_flag = true;
         for (int t = 0; t < nio; t++) for (int cfd : fresh[t]) close(cfd);   // dealt but never adopted
-        for (int k = 0; k < nworkers; k++) { std::lock_guard<std::mutex> lk(qmu[k]); cv[k].notify_all(); }
+        for (int k = 0; k < nworkers; k++) { doors->door[k].bell.fetch_add(1, std::memory_order_seq_cst); futex_wake(&doors->door[k].bell, 64); }
+        // whoever still waits in a slot (a server stopped under its clients) is told: the closing control socket says the rest
+        for (auto& th : threads) th.join();
+        threads.clear();
+        for (int k = 0; k < nworkers; k++) { wakers[k].bell.fetch_add(1, std::memory_order_seq_cst); futex_wake(&wakers[k].bell, 1); wakers[k].th.join(); }
+        {
+            std::lock_guard<std::mutex> lk(shm_mu);
+            for (int i = 0; i < kShmMaxSlots; i++) {
+                const std::shared_ptr<ShmClient> sc = std::atomic_load(&shm_table[i]);
+                if (sc && sc->slot->state.load() == kSlotPosted) slot_reply_error(sc->slot, PNN_E_IO);
+                std::atomic_store(&shm_table[i], std::shared_ptr<ShmClient>());
+            }
+        }
         for (auto& th : threads) th.join();
         for (int t = 0; t < nio; t++) { close(eps[t]); close(wake_fd[t]); }
         close(lfd);
         unlink(socket_path);
         if (stats) { stats[0] = served; stats[1] = calls; stats[2] = largest; stats[3] = accepted.load(); }
         if (getenv("PNN_SERVICE_DEBUG"))
+            fprintf(stderr, "[pnn-service] transport: %ld of %ld clients on the shared-memory request path, %ld requests through slots\n", shm_clients.load(), accepted.load(), shm_requests.load());
+        if (getenv("PNN_SERVICE_DEBUG"))
             for (int k = 0; k < nworkers; k++)
             {
-                double rs = 0; long rn = 0;
+                double rs = shm_resident_s[k]; long rn = shm_resident_n[k];
                 for (int t = 0; t < nio; t++) { rs += resident_s[t][k]; rn += resident_n[t][k]; }
                 fprintf(stderr, "[pnn-service] worker %d: %.2f s inside the backend, %ld calls (%.1f us each), %ld requests (%.2f per call); per request %.1f us queued before "
                         "its batch is taken, %.1f us from last byte in to reply out\n", k, busy_s[k], calls_w[k], calls_w[k] ? busy_s[k] * 1e6 / calls_w[k] : 0.0, served_w[k],
@@ -765,6 +1072,37 @@ int pnn_client_connect(pnn_client** out, const char* socket_path)
     c->fd = fd;
     const char* e = getenv("PNN_CACHE_MB");
     c->cache_bytes = (size_t)(e ? atol(e) : 64) << 20;
+    // The shared-memory request path ($PNN_SERVICE_SHM=0: stay on the socket protocol): ask for a slot; the reply carries two
+    // descriptors (the slot, the workers' doorbell page).  Anything unexpected leaves this client on the socket protocol.
+    const char* shm = getenv("PNN_SERVICE_SHM");
+    if (!shm || atoi(shm) != 0) {
+        const ReqHeader h{kMagic, 4, 0u, 0u, kWantShm};
+        struct { RspHeader rh; int32_t worker[5]; int32_t index; } body;
+        memset(&body, 0, sizeof body);
+        if (write_all(fd, &h, sizeof h)) {
+            iovec iov{&body, sizeof body};
+            alignas(cmsghdr) char ctl[CMSG_SPACE(2 * sizeof(int))];
+            msghdr mh;
+            memset(&mh, 0, sizeof mh);
+            mh.msg_iov = &iov; mh.msg_iovlen = 1; mh.msg_control = ctl; mh.msg_controllen = sizeof ctl;
+            ssize_t got;
+            do got = recvmsg(fd, &mh, MSG_CMSG_CLOEXEC); while (got < 0 && errno == EINTR);
+            int fds[2] = {-1, -1};
+            for (cmsghdr* cm = CMSG_FIRSTHDR(&mh); cm; cm = CMSG_NXTHDR(&mh, cm))
+                if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS && cm->cmsg_len == CMSG_LEN(2 * sizeof(int))) memcpy(fds, CMSG_DATA(cm), sizeof fds);
+            if (got > 0 && got < (ssize_t)sizeof body && !read_all(fd, reinterpret_cast<char*>(&body) + got, sizeof body - (size_t)got)) got = -1;
+            if (got > 0 && body.rh.rc == 0 && body.rh.n_vals == 6 && fds[0] >= 0 && fds[1] >= 0 && body.index >= 0 && body.index < kShmMaxSlots) {
+                void* sm = mmap(nullptr, kSlotBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fds[0], 0);
+                void* dm = mmap(nullptr, kDoorBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fds[1], 0);
+                bool ok = sm != MAP_FAILED && dm != MAP_FAILED;
+                for (int i = 0; i < 5; i++) { c->worker_of[i] = body.worker[i]; ok = ok && body.worker[i] >= 0 && body.worker[i] < 5; }
+                if (ok) { c->slot = sm; c->doors = dm; c->index = body.index; }
+                else { if (sm != MAP_FAILED) munmap(sm, kSlotBytes); if (dm != MAP_FAILED) munmap(dm, kDoorBytes); }
+            }
+            for (int f : fds) if (f >= 0) close(f);
+            if (got <= 0) { close(fd); delete c; return PNN_E_IO; }    // the server hung up on the hand-shake
+        }
+    }
     *out = c;
     return PNN_OK;
 }
@@ -794,6 +1132,48 @@ static int client_call(pnn_client* c, int width, const float* above, const float
             return PNN_OK;
         }
         ++c->misses;
+    }
+    if (c->slot) {
+        // through the slot: context in place, one doorbell, sleep on the slot's state word until the worker has written the reply
+        ShmSlot* sl = static_cast<ShmSlot*>(c->slot);
+        const int wk = c->worker_of[width == 4 ? 0 : width == 8 ? 1 : width == 16 ? 2 : width == 32 ? 3 : 4];
+        ShmDoor& door = static_cast<ShmDoors*>(c->doors)->door[wk];
+        sl->hdr = h;
+        memcpy(sl->in, in, in_bytes);
+        sl->posted_ns = now_ns();
+        sl->client_sleeps.store(0, std::memory_order_relaxed);
+        sl->state.store(kSlotPosted, std::memory_order_seq_cst);
+        static_cast<ShmDoors*>(c->doors)->posted[wk][c->index >> 6].fetch_or(1ull << (c->index & 63), std::memory_order_seq_cst);
+        door.bell.fetch_add(1, std::memory_order_seq_cst);
+        if (door.sleeping.load(std::memory_order_seq_cst)) futex_wake(&door.bell, 1);
+        int idle_rounds = 0;
+        for (;;) {
+            uint32_t st = sl->state.load(std::memory_order_acquire);
+            if (st == kSlotReady) break;
+            sl->client_sleeps.store(1, std::memory_order_seq_cst);
+            st = sl->state.load(std::memory_order_seq_cst);
+            if (st == kSlotReady) break;
+            if (futex_wait(&sl->state, st, 200000) != 0 && errno == ETIMEDOUT && ++idle_rounds >= 1) {
+                // nothing for 200 ms: is the server still there?  (its end of the control socket closes when it dies or drops this client)
+                pollfd pf{c->fd, POLLIN, 0};
+                char probe;
+                if (poll(&pf, 1, 0) > 0 && (pf.revents & (POLLHUP | POLLERR) || (pf.revents & POLLIN && recv(c->fd, &probe, 1, MSG_PEEK | MSG_DONTWAIT) == 0))) {
+                    if (sl->state.load(std::memory_order_acquire) == kSlotReady) break;
+                    return PNN_E_IO;
+                }
+            }
+        }
+        const RspHeader r = sl->rsp;
+        if (r.rc == 0 && r.n_vals == w2) memcpy(vals, sl->out, (size_t)w2 * 4);
+        sl->state.store(kSlotIdle, std::memory_order_release);
+        if (r.rc != 0) return r.rc;
+        if (r.n_vals != w2) return PNN_E_IO;
+        if (slot) {
+            slot->in.assign(in, in + in_bytes);
+            slot->vals.assign(static_cast<const char*>(vals), static_cast<const char*>(vals) + (size_t)w2 * 4);
+            slot->hash = hash; slot->valid = true;
+        }
+        return PNN_OK;
     }
     if (!write_all(c->fd, c->buf.data(), c->buf.size())) return PNN_E_IO;
     // the reply in ONE recv where the kernel has it whole (the server sends header and values with one send; an error reply is the
@@ -865,6 +1245,8 @@ int pnn_client_cache_stats(const pnn_client* c, long* hits, long* misses)
 void pnn_client_close(pnn_client* c)
 {
     if (!c) return;
+    if (c->slot) munmap(c->slot, kSlotBytes);
+    if (c->doors) munmap(c->doors, kDoorBytes);
     close(c->fd);
     delete c;
 }

@@ -91,9 +91,17 @@ static void campaign(const char* dir, int window_us, int per_client, bool stop_u
     std::thread server([&] { rc_server = pnn_service_run_backend(sock.c_str(), sum_backend, nullptr, 16, window_us, &stop, stats); });
     std::atomic<int> bad{0};
     std::atomic<long> ok_requests{0};
+    // three clients in four on the shared-memory request path (a slot per client, the workers' doorbells), every fourth on the socket
+    // protocol: connected here, one after the other, because the choice is an environment variable read at connect
+    pnn_client* conn[32];
+    for (int k = 0; k < 32; k++) {
+        setenv("PNN_SERVICE_SHM", (k & 3) == 3 ? "0" : "1", 1);
+        conn[k] = nullptr;
+        for (int t = 0; t < 1000 && pnn_client_connect(&conn[k], sock.c_str()) != 0; t++) usleep(2000);
+    }
+    setenv("PNN_SERVICE_SHM", "1", 1);
     auto client = [&](int k) {
-        pnn_client* c = nullptr;
-        for (int t = 0; t < 1000 && pnn_client_connect(&c, sock.c_str()) != 0; t++) usleep(2000);
+        pnn_client* c = conn[k];
         if (!c) { bad++; return; }
         unsigned seed = 100 + k;
         std::vector<float> a, l, f32;

@@ -22,6 +22,7 @@
 extern "C" {
 int pnn_predict_f32_pel(pnn_ctx*, int, const float*, const float*, int, float*, int32_t*) { return PNN_E_HIP; }
 int pnn_model_info(const pnn_ctx*, int, int*, int*, long*) { return PNN_E_MODEL; }
+int pnn_arithmetic_tag(const pnn_ctx*, char* o, size_t n) { snprintf(o, n, "none"); return PNN_OK; }
 int pnn_create_empty(pnn_ctx**, float, int) { return PNN_E_HIP; }
 int pnn_load_model_file(pnn_ctx*, const char*) { return PNN_E_HIP; }
 int pnn_set_option(pnn_ctx*, const char*, long) { return PNN_E_HIP; }
