@@ -140,7 +140,15 @@ int wait_stream(pnn_ctx* c, hipStream_t s)
 // memory behind its results.  Bounded: a launch that failed never raises it, the stream then says why.
 int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1, int width = 4)
 {
-    const unsigned* flag = reinterpret_cast<const unsigned*>(c->h_range) + 1;
+    const unsigned* const flag0 = reinterpret_cast<const unsigned*>(c->h_range) + (c->done_nflags > 0 ? pnn_ctx::kDoneFlag0 : 1);
+    const int nflags = c->done_nflags > 0 ? c->done_nflags : 1;
+    // every flag word of the call stands at its number (one word, or one per workgroup of the last kernel); `first_open` remembers where
+    // the scan stopped: words in front of it have been seen raised
+    int first_open = 0;
+    auto raised = [&]() {
+        while (first_open < nflags && __atomic_load_n(flag0 + first_open, __ATOMIC_ACQUIRE) == c->done_seq) ++first_open;
+        return first_open == nflags;
+    };
     if (c->opt_wait_sleep) {
         // sleep through the predictable part of the wait (see pnn_ctx::opt_wait_sleep), spin for the rest
         constexpr double kMarginUs = 14.0, kMinSleepUs = 12.0;
@@ -155,12 +163,12 @@ int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1, int width = 4)
         if (nap >= kMinSleepUs) {
             timespec ts{0, (long)(nap * 1e3)};
             nanosleep(&ts, nullptr);
-            overslept = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->done_seq;
+            overslept = raised();
         }
-        for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; spins++) {
+        for (long spins = 0; !raised(); spins++) {
             if (spins < 400000) { __builtin_ia32_pause(); continue; }
             HIPCHK(c, hipStreamSynchronize(s));
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
+            if (!raised()) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
             break;
         }
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -169,10 +177,10 @@ int wait_done_flag(pnn_ctx* c, hipStream_t s, long n = 1, int width = 4)
         ema = overslept ? ema * 0.85 : (ema == 0.0 ? us : 0.9 * ema + 0.1 * us);
         return PNN_OK;
     }
-    for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; spins++) {
+    for (long spins = 0; !raised(); spins++) {
         if (spins < 200000) { __builtin_ia32_pause(); continue; }   // ~ a few milliseconds
         HIPCHK(c, hipStreamSynchronize(s));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
+        if (!raised()) return fail(c, PNN_E_HIP, "the pass finished without raising its completion flag");
         break;
     }
     return PNN_OK;
@@ -259,12 +267,12 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_WAIT_SLEEP")) c->opt_wait_sleep = atol(e);
     if (const char* e = getenv("PNN_GRAPHS")) c->opt_graphs = atol(e);
     if (const char* e = getenv("PNN_F32_SMALL_DEEP")) c->opt_f32_small_deep = atol(e);
-    if (hipHostMalloc((void**)&c->h_range, 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&c->h_range, (pnn_ctx::kDoneFlag0 + pnn_ctx::kDoneFlagsMax) * 4, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
     }
     *c->h_range = 0;
-    c->h_range[1] = 0;                                // the completion flag of the small host calls (signal_done)
+    for (int i = 1; i < pnn_ctx::kDoneFlag0 + pnn_ctx::kDoneFlagsMax; i++) c->h_range[i] = 0;   // the completion flag(s) of the small host calls (signal_done)
     if (hipMalloc((void**)&c->d_done, 256) != hipSuccess || hipMemset(c->d_done, 0, 256) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the completion counter failed");
@@ -760,16 +768,19 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
                 inline_input = true;
                 c->done_armed = false;
             } else {
-                ge->armed = c->done_armed; ge->seq = c->done_seq;
+                ge->armed = c->done_armed; ge->seq = c->done_seq; ge->nflags = c->done_nflags;
                 ge->stat_gemm_launches = c->stat_gemm_launches; ge->stat_launches = c->stat_launches;
                 ge->stat_gemm_flops = c->stat_gemm_flops; ge->stat_gemm_flops_skipped = c->stat_gemm_flops_skipped;
             }
             rc = PNN_OK;
         }
         if (ge && ge->exec) {
-            if (ge->armed) __atomic_store_n(reinterpret_cast<unsigned*>(c->h_range) + 1, 0u, __ATOMIC_RELEASE);   // the number this chain raises may still stand there
+            if (ge->armed) {                          // the number this chain raises may still stand there
+                __atomic_store_n(reinterpret_cast<unsigned*>(c->h_range) + 1, 0u, __ATOMIC_RELEASE);
+                for (int i = 0; i < ge->nflags; i++) __atomic_store_n(reinterpret_cast<unsigned*>(c->h_range) + pnn_ctx::kDoneFlag0 + i, 0u, __ATOMIC_RELEASE);
+            }
             HIPCHK(c, hipGraphLaunch(ge->exec, s));
-            c->done_armed = ge->armed; c->done_seq = ge->seq;
+            c->done_armed = ge->armed; c->done_seq = ge->seq; c->done_nflags = ge->nflags;
             c->stat_gemm_launches = ge->stat_gemm_launches; c->stat_launches = ge->stat_launches;
             c->stat_gemm_flops = ge->stat_gemm_flops; c->stat_gemm_flops_skipped = ge->stat_gemm_flops_skipped;
             replay = true;
@@ -809,18 +820,20 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
             fprintf(stderr, "[pnn-stamps] width %d, %d block(s): %d stamped launches (us from the first workgroup's entry; per launch: first / median / last over its workgroups); host wait after the last launch call %.1f us\n",
                     w, n, c->diag_launch, (tw1.tv_sec - tw0.tv_sec) * 1e6 + (tw1.tv_nsec - tw0.tv_nsec) * 1e-3);
             for (int l = 0; l < c->diag_launch; l++) {
-                std::vector<double> ent, ls, le, ex;
+                std::vector<double> ent, ls, le, ex, stv;
                 for (int i = 0; i < c->diag_wgs[l]; i++) {
                     const unsigned long long* d = &h[((size_t)l * pnn_ctx::kDiagWgs + i) * 8];
                     if (!d[4]) continue;
                     ent.push_back((double)(d[4] - t00) / 100.0);
                     if (d[3]) { ls.push_back((double)(d[3] - t00) / 100.0); le.push_back((double)(d[3] + d[1] - t00) / 100.0); }
                     if (d[5]) ex.push_back((double)(d[5] - t00) / 100.0);
+                    if (d[6]) stv.push_back((double)(d[6] - t00) / 100.0);
                 }
                 auto fml = [](std::vector<double>& v, char* buf) { if (v.empty()) { snprintf(buf, 64, "      -      "); return; } std::sort(v.begin(), v.end()); snprintf(buf, 64, "%5.1f /%5.1f /%5.1f", v.front(), v[v.size() / 2], v.back()); };
-                char b0[64], b1[64], b2[64], b3[64];
-                fml(ent, b0); fml(ls, b1); fml(le, b2); fml(ex, b3);
-                fprintf(stderr, "[pnn-stamps]  %-28s K %5.0f %4d WGs (%zu stamped) | entry %s | chain start %s | chain end %s | exit %s\n", c->diag_names[l].c_str(), c->diag_k[l], c->diag_wgs[l], ent.size(), b0, b1, b2, b3);
+                char b0[64], b1[64], b2[64], b3[64], b4[64];
+                fml(ent, b0); fml(ls, b1); fml(le, b2); fml(ex, b3); fml(stv, b4);
+                fprintf(stderr, "[pnn-stamps]  %-28s K %5.0f %4d WGs (%zu stamped) | entry %s | chain start %s | chain end %s | exit %s%s%s\n", c->diag_names[l].c_str(), c->diag_k[l], c->diag_wgs[l], ent.size(), b0, b1, b2, b3,
+                        stv.empty() ? "" : " | results stored (before the completion signal) ", stv.empty() ? "" : b4);
             }
         }
 #endif

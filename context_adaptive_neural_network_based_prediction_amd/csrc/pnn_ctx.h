@@ -115,6 +115,7 @@ struct pnn_ctx {
         int uses = 0;                                 // calls of this shape so far (0: run and size the buffers, 1: capture, then replay)
         bool failed = false, armed = false;
         unsigned seq = 0;                             // the completion number its last kernel raises
+        int nflags = 0;                               // ... in that many per-workgroup flag words (0: the one word)
         int stat_gemm_launches = 0, stat_launches = 0;
         double stat_gemm_flops = 0, stat_gemm_flops_skipped = 0;
     };
@@ -197,6 +198,8 @@ struct pnn_ctx {
     unsigned done_seq = 0;                            // the sequence number the running / last pass raises
     unsigned done_seq_alloc = 0;                      // numbers handed out so far (a replayed graph raises the number it was captured with)
     bool done_want = false, done_last_chunk = true, done_armed = false;
+    int done_nflags = 0;                              // 0: the one flag word h_range[1]; N > 0: the N per-workgroup words from h_range[kDoneFlag0] on (DoneSignal::per_wg)
+    static constexpr int kDoneFlag0 = 16, kDoneFlagsMax = 512;
     long opt_flag_wait = 1;
     // The host thread of a small call spins on the completion flag for as long as the device works: 45-400 us of a CPU per call, and the
     // batching service runs five such threads (19 of its 31 CPU-seconds per Kodak-size campaign, round 4).  wait_sleep = 1: the thread
@@ -252,8 +255,19 @@ inline DoneSignal take_done_signal(pnn_ctx* c)
 {
     if (!c->done_want || !c->done_last_chunk || !c->d_done) return DoneSignal{nullptr, nullptr, 0, 0};
     c->done_armed = true;
+    c->done_nflags = 0;
     c->done_seq = ++c->done_seq_alloc;
     return DoneSignal{c->d_done, reinterpret_cast<unsigned*>(c->h_range) + 1, c->done_seq, 0};
+}
+// ... with a flag word per workgroup of the last kernel (nwg of them): see DoneSignal::per_wg
+inline DoneSignal take_done_signal_per_wg(pnn_ctx* c, int nwg)
+{
+    if (nwg < 1 || nwg > pnn_ctx::kDoneFlagsMax) return take_done_signal(c);
+    if (!c->done_want || !c->done_last_chunk || !c->d_done) return DoneSignal{nullptr, nullptr, 0, 0};
+    c->done_armed = true;
+    c->done_nflags = nwg;
+    c->done_seq = ++c->done_seq_alloc;
+    return DoneSignal{nullptr, reinterpret_cast<unsigned*>(c->h_range) + pnn_ctx::kDoneFlag0, c->done_seq, 1};
 }
 int tuned_cfg(pnn_ctx* c, const void* key, long M, int ncodes, int rule, const std::function<bool(int)>& legal,
               const std::function<hipError_t(int)>& launch, hipStream_t s, int* cfg, float* best_us);

@@ -46,6 +46,17 @@ __device__ __forceinline__ void signal_done(const DoneSignal& d)
     }
 }
 
+// The same signal where ONE wave of the workgroup wrote all of the workgroup's results and every workgroup has a flag word of its own
+// (DoneSignal::per_wg): called by that wave alone, behind its stores -- one fence, one flag store, nothing to wait for in between.
+// (The counter form above costs fc_out's last kernel a fence in every wave, a barrier, an atomic round trip and a second fence:
+// 3.8 us from its last MFMA to its exit, profiles/r06_b1_stamps_fc_out.txt.)
+__device__ __forceinline__ void signal_done_by_wave(const DoneSignal& d, unsigned wg)
+{
+    if (!d.host_flag) return;                        // launch-uniform
+    __threadfence_system();                          // this wave's results are on their way to the host, in front of the flag
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(d.host_flag + wg, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // pnn/tfutils.py:192, max(0.1 v, v).  fmaxf() would put a canonicalising v_max_f32 v, v in front (the IEEE quieting of a
 // signalling NaN the compiler cannot rule out): three VALU instructions per value in epilogues that are VALU-bound; the
 // values here come out of v_fma_f32, which never produces a signalling NaN.

@@ -734,6 +734,9 @@ __global__ __launch_bounds__(512) void fc_out_f32_chain_kernel(const FcOutF32Arg
 #ifdef PNN_F32_DIAG
     unsigned long long dr0 = 0, dr1 = 0;
 #endif
+    // wave 0 finishes the tile: its bias piece is requested now, not behind the barrier (one exposed memory latency less)
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (z == 0 && nblk + 4 * q < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nblk + 4 * q);
     if (z < segs) {
         const int m = mblk + l15, n0 = z * 32 * NT;
         const bool mv = m < p.M;
@@ -782,14 +785,16 @@ __global__ __launch_bounds__(512) void fc_out_f32_chain_kernel(const FcOutF32Arg
     if (z == 0 && mg < p.M && n < p.Cout) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < segs; t++) sum += *reinterpret_cast<const f32x4*>(&part[t][l15][4 * q]);
-        const f32x4 v = sum + *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 v = sum + bias4;
         if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (size_t)mg * p.Cout + n) = v;
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + (size_t)mg * p.Cout + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
 #ifdef PNN_F32_DIAG
     const unsigned long long dr2 = __builtin_amdgcn_s_memrealtime();
 #endif
-    signal_done(a.done);
+    // wave 0 wrote all of the workgroup's results: it alone signals (per-workgroup flag words), or the counter form for a caller that asked for it
+    if (a.done.per_wg) { if (z == 0) signal_done_by_wave(a.done, blockIdx.y * gridDim.x + blockIdx.x); }
+    else signal_done(a.done);
 #ifdef PNN_F32_DIAG
     if (p.Xlo && tid == 0) {
         unsigned long long* d = (unsigned long long*)p.Xlo + 8 * (blockIdx.y * gridDim.x + blockIdx.x);

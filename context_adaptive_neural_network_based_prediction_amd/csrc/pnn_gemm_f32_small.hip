@@ -24,7 +24,9 @@
 // layer at batch 1 is 75 workgroups, each streaming its 75 KiB of weights.  K segments of the deep convolution layers
 // (GemmLayer::nseg) as in tapgemm_f32_kernel: z = class * nseg + segment, raw sums to plane `segment`, seg_reduce_kernel finishes.
 #include "pnn_kernels.h"
+#include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include "pnn_device_common.h"
 
@@ -487,6 +489,167 @@ __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs
 #endif
 }
 
+// The same layer with ALL of its operands resident (round 6, second form).  The ring above keeps 10 of a segment's 20 chunks in flight per
+// chain and measured 2.7 us for the 20-chunk chains (profiles/r06_fcseg_ab.txt: 324 cycles per chunk against the chain's 152) -- the
+// loaders request the second half only as slots come free.  A 1200-deep layer is 75 chunks of 2 KiB per output tile: 76 chunk slots
+// (every segment rounded up to whole stages of 4: 20 + 20 + 20 + 16) are 152 KiB, one workgroup per CU.  So: 4 chain waves + EIGHT
+// loader waves (two per chain, chunks alternating), every loader issues its 10 chunks -- 50 LDS-DMA instructions, under the 6-bit
+// vmcnt -- at once, and the whole layer slice is in flight one memory latency after entry; a stage (4 chunks per chain) is published
+// by a barrier once both of its loaders count it landed (vmcnt <= 40, 30, 20, 10, 0).  A chunk past the end of a segment inside a live
+// stage (the last segment's 16th) holds zeros (range misses); whole stages past the end are skipped by their chain wave (barriers only).
+constexpr int kFcAllCPS = 4, kFcAllStages = kFcSegChunks / kFcAllCPS;            // chunks per stage and chain; stages per full segment
+constexpr int kFcAllPerLoader = kFcSegChunks / 2;                                // chunks per loader wave
+static_assert(kFcSegChunks % kFcAllCPS == 0 && 5 * kFcAllPerLoader < 64, "whole stages; all of a loader's instructions under one vmcnt");
+constexpr int kFcAllMaxSlots = 76;
+constexpr size_t kFcAllLds = ((size_t)kFcAllMaxSlots * 128 + kFcSegNS * 64) * 16;
+
+__global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32SmallArgs args)
+{
+    touch_kernargs<sizeof(F32SmallArgs)>();
+    (void)args;
+    const auto* ka = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    CF32SmallParams& p = ka->p;
+    constexpr int NS = kFcSegNS, CPS = kFcAllCPS, NST = kFcAllStages, PL = kFcAllPerLoader;
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [76 chunk slots][weights 64 pieces | activations 64 pieces] | [NS][64] segment sums
+#ifdef PNN_F32_DIAG
+    const unsigned long long de0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, q = lane >> 4;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int n0 = by * 16;
+    const int cpt = p.Cin >> 4, segc = kFcSegChunks;
+    // waves 0-3: the chains; waves 4-11: loader (wave - 4) >> 1 ... no: chain sg = (wave - 4) & 3, half = (wave - 4) >> 2
+    const int sg = wave < NS ? wave : (wave - NS) & (NS - 1);
+    int c0 = sg * segc, c1 = c0 + segc;
+    if (c0 > cpt) c0 = cpt;
+    if (c1 > cpt) c1 = cpt;
+    if (sg >= p.nseg) c1 = c0;
+    // this chain's chunk slots: the segments' stage-rounded lengths, one after the other
+    int slot0 = 0;
+    for (int k = 0; k < sg; k++) {
+        int a = k * segc, b = a + segc;
+        if (a > cpt) a = cpt;
+        if (b > cpt) b = cpt;
+        if (k >= p.nseg) b = a;
+        slot0 += (b - a + CPS - 1) / CPS * CPS;
+    }
+    const int nlive = c1 - c0, nst = (nlive + CPS - 1) / CPS;      // this chain's live stages
+    f32x4* const mine = ring + slot0 * 128;
+    f32x4* const part = ring + kFcAllMaxSlots * 128;
+
+    if (wave >= NS) {
+        const int half = (wave - NS) >> 2;                          // this loader's chunks of the segment: half, half + 2, ...
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7fffffffu, 0x00020000);
+        const unsigned bstride = (unsigned)(4 * p.Npad) << 4;
+        const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
+        constexpr unsigned kOob = 0x80000000u;
+        const int mx = bx * 16 + (lane >> 2);
+        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (unsigned)((lane & 3) << 3) : kOob;
+        const int nslots = nst * CPS;                               // slots this chain owns (live stages)
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int j = 2 * i + half;                            // chunk of the segment
+            const int ci = c0 + j;
+            const bool live = ci < c1;
+            // a chunk past the segment inside a live stage: zeros into its slot (range miss).  Past the live stages there is nothing to
+            // fill, but the instructions still go out -- every loader issues exactly PL chunks, the vmcnt thresholds below count on it --
+            // as range misses into the segment-sum area, which nobody reads or writes before all of them have landed (vmcnt 0, last barrier)
+            f32x4* dst = j < nslots ? mine + j * 128 : part;
+            const unsigned wo = live ? wlane + (unsigned)ci * bstride : kOob;
+            const unsigned ao = live ? apix : kOob;
+            const unsigned so = (unsigned)(ci << 6);
+            f32s_dma16(wrsrc, wo, dst);
+            float* xd = reinterpret_cast<float*>(dst + 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+        }
+        // stage t is whole when both loaders have seen their chunks 2t and 2t + 1 land (loads complete in issue order)
+        f32s_wait_vm<5 * (PL - 2)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<5 * (PL - 4)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<5 * (PL - 6)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<5 * (PL - 8)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<0>(); __builtin_amdgcn_s_barrier();
+        static_assert(NST == 5 && PL == 10, "the five waits above");
+        __builtin_amdgcn_s_barrier();                // the segment sums' barrier
+        return;
+    }
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(3);
+#ifdef PNN_F32_DIAG
+    unsigned long long dq0 = 0, dr0 = 0;
+#endif
+    // per chunk two 16-byte LDS reads and four MFMAs; the next chunk's reads sit between this chunk's MFMAs (inside a stage); the first
+    // chunk of a stage is read behind the stage's barrier
+    auto chunk = [&](const f32x4 fw, const f32x4 fx, const f32x4* nsrc, f32x4& nw, f32x4& nx, bool rd) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[0], fx[0], acc, 0, 0, 0);
+        if (rd) nw = nsrc[0];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[1], fx[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[2], fx[2], acc, 0, 0, 0);
+        if (rd) nx = nsrc[64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[3], fx[3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int t = 0; t < NST; t++) {
+        __builtin_amdgcn_s_barrier();                // stage t of every chain has landed
+        if (t >= nst) continue;                      // past this chain's segment (wave-uniform): the barriers only
+#ifdef PNN_F32_DIAG
+        if (t == 0) { dq0 = __builtin_amdgcn_s_memtime(); dr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        const f32x4* src = mine + (t * CPS) * 128 + lane;
+        f32x4 w0 = src[0], x0 = src[64], w1, x1;
+        chunk(w0, x0, src + 128, w1, x1, true);
+        chunk(w1, x1, src + 256, w0, x0, true);
+        chunk(w0, x0, src + 384, w1, x1, true);
+        chunk(w1, x1, src, w0, x0, false);
+        static_assert(CPS == 4, "four chunks per stage, unrolled");
+    }
+#ifdef PNN_F32_DIAG
+    unsigned long long* const dstamp = (p.Xlo && wave == 0) ? (unsigned long long*)p.Xlo + 8 * (by * gridDim.x + bx) : nullptr;
+    if (dstamp && lane == 0) {
+        dstamp[0] = __builtin_amdgcn_s_memtime() - dq0; dstamp[1] = __builtin_amdgcn_s_memrealtime() - dr0; dstamp[2] = (unsigned long long)(c1 - c0); dstamp[3] = dr0;
+        dstamp[4] = de0;
+    }
+#endif
+    part[sg * 64 + lane] = acc;
+    __builtin_amdgcn_s_barrier();
+    if (wave != 0) return;
+    f32x4 tsum = part[lane];
+    for (int k = 1; k < p.nseg; k++) tsum += part[k * 64 + lane];
+    const int mg = bx * 16 + l15, n = n0 + 4 * q;
+    if (mg < p.M && n < p.Cout) {
+        f32x4 v = tsum + *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
+        const size_t o = (size_t)mg * p.Cout + n;
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o) = v;
+        if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
+    }
+#ifdef PNN_F32_DIAG
+    if (dstamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dstamp[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+// does the resident form hold this layer?  (76 chunk slots: K <= 1216 in segments of kFcSegChunks)
+static bool fcseg_all_fits(const TapGemmParams& p)
+{
+    if ((int)p.seg_chunks != kFcSegChunks || p.nseg > kFcSegNS) return false;
+    const int cpt = p.Cin >> 4;
+    int slots = 0;
+    for (int k = 0; k < p.nseg; k++) {
+        const int a = std::min(k * kFcSegChunks, cpt), b = std::min(a + kFcSegChunks, cpt);
+        slots += (b - a + kFcAllCPS - 1) / kFcAllCPS * kFcAllCPS;
+    }
+    return slots <= kFcAllMaxSlots;
+}
+
 long fcseg_f32_small_tiles(const TapGemmParams& p) { return (long)((p.M + 15) / 16) * ((p.Cout + 15) / 16); }
 bool fcseg_f32_small_fits(const TapGemmParams& p)
 {
@@ -506,6 +669,16 @@ hipError_t launch_fcseg_f32_small(const TapGemmParams& p, hipStream_t s)
         __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
     }
     const F32SmallArgs a{p};
+    static const bool no_all = getenv("PNN_FCSEG_RING") != nullptr;   // A/B: the ring form for every layer
+    if (fcseg_all_fits(p) && !no_all) {
+        static int done_all[16] = {};
+        if (!__atomic_load_n(&done_all[di], __ATOMIC_ACQUIRE)) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcAllLds)) != hipSuccess) return e;
+            __atomic_store_n(&done_all[di], 1, __ATOMIC_RELEASE);
+        }
+        pnn_launch(fcseg_f32_small_all_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(768), kFcAllLds, s, a);
+        return hipGetLastError();
+    }
     pnn_launch(fcseg_f32_small_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), kFcSegLds, s, a);
     return hipGetLastError();
 }

@@ -7,7 +7,9 @@
 
 namespace pnn {
 
-struct DoneSignal { unsigned* counter; unsigned* host_flag; unsigned seq, pad; };   // see signal_done, pnn_device_common.h
+// see signal_done, pnn_device_common.h.  per_wg = 1 (round 6, fc_out_f32_chain_kernel): workgroup g raises host_flag[g] by itself -- no
+// counter, no second fence; the host waits for all of the launch's flags
+struct DoneSignal { unsigned* counter; unsigned* host_flag; unsigned seq, per_wg; };
 
 // Per-launch timing (pnn_abi.cpp, option time_launches): when set, the GEMM launchers attach these events to the kernel
 // itself (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end -- what rocprofv3

@@ -701,7 +701,8 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
                 r.part = nullptr; r.bias = m->fc[3].d_bias; r.mean = c->mean; r.Y = d_out; r.Yi = d_dst;
                 if (fc_out_f32_small_fits(r)) {
                     if (void* slot = diag_stamp_slot(c, c->opt_fc_out_f32 == 2 ? "fc_out_f32_small (32x32x2)" : "fc_out_f32_chain", (long)((nb + 15) / 16) * ((n_out + 15) / 16), 1200.0)) r.Xlo = slot;
-                    HIPCHK(c, launch_fc_out_f32_small(r, s, take_done_signal(c), c->opt_fc_out_f32 == 2));
+                    const int nwg = (int)((nb + 15) / 16) * ((n_out + 15) / 16);      // fc_out_f32_chain_kernel's workgroups: a completion flag each
+                    HIPCHK(c, launch_fc_out_f32_small(r, s, c->opt_fc_out_f32 == 2 ? take_done_signal(c) : take_done_signal_per_wg(c, nwg), c->opt_fc_out_f32 == 2));
                     c->stat_gemm_launches++; c->stat_launches++;
                     c->stat_gemm_flops += 2.0 * (double)nb * m->fc[3].k_total * n_out;
                     return PNN_OK;
