@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 using namespace pnn;
 
@@ -379,6 +381,11 @@ void pnn_destroy(pnn_ctx* c)
     if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_done) (void)hipFree(c->d_done);
     if (c->d_seg_cnt) (void)hipFree(c->d_seg_cnt);
+    if (c->copy_in) {
+        (void)hipStreamDestroy(c->copy_in); (void)hipStreamDestroy(c->copy_out);
+        for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_in[i]); (void)hipEventDestroy(c->ev_pass[i]); (void)hipEventDestroy(c->ev_out[i]); }
+    }
+    for (pnn::DevBuf* b : {&c->stage2_in[0], &c->stage2_in[1], &c->stage2_out[0], &c->stage2_out[1]}) if (b->p) (void)hipFree(b->p);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -470,6 +477,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "f32_overlap")) c->opt_f32_overlap = value;
     else if (!strcmp(name, "f32_small")) c->opt_f32_small = value;
     else if (!strcmp(name, "fc_out_f32")) c->opt_fc_out_f32 = value;
+    else if (!strcmp(name, "host_slice")) c->opt_host_slice = value;
     else if (!strcmp(name, "seg_fold")) c->opt_seg_fold = value;
     else if (!strcmp(name, "f32_small_deep")) c->opt_f32_small_deep = value;
     else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;
@@ -662,6 +670,147 @@ static bool all_finite(const float* x, size_t n)
     return bad == 0;
 }
 
+static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst, int dst_stride);
+
+// host_predict for a call of several passes' worth of blocks: slices of `slice` blocks through TWO staging sets on three streams --
+// H2D of slice i + 1 and D2H of slice i - 1 beside the pass of slice i.  The copies come from / go to the caller's (pageable) arrays
+// through the runtime's own staging, which holds the calling thread for their length: the order of issue below is what overlaps them with
+// the device's work (H2D i + 1, then pass i + 1 enqueued behind it, then D2H i).  Same kernels per block, one summation order at every
+// batch size: bit-identical to the sequential call (tests/test_gpu_parity.py).
+static int host_predict_sliced(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst, int dst_stride, long slice)
+{
+    const int w = m->width;
+    const long w2 = (long)w * w;
+    const size_t pa = (size_t)(m->is_fc ? 5 : 3) * w2, pl = m->is_fc ? 0 : (size_t)2 * w2;
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stats(c);
+    int rc;
+    hipStream_t s = c->stream;
+    if (!c->copy_in) {
+        PNN_UNSAFE_CALLS_GUARD;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_pass[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        DevBuf* in = k ? c->stage2_in : c->stage_in;
+        DevBuf* ob = k ? c->stage2_out : c->stage_out;
+        if ((rc = dev_reserve(c, in[0], (size_t)slice * pa * 4))) return rc;
+        if (pl && (rc = dev_reserve(c, in[1], (size_t)slice * pl * 4))) return rc;
+        if ((rc = dev_reserve(c, ob[0], (size_t)slice * w2 * 4))) return rc;
+        if (dst && (rc = dev_reserve(c, ob[1], (size_t)slice * w2 * 4))) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));                // the staging sets may still be read by an earlier asynchronous call of this context
+    const long nsl = (n + slice - 1) / slice;
+    auto count = [&](long i) { return std::min<long>(slice, (long)n - i * slice); };
+    // TWO host threads: a copy from / to the caller's pageable arrays holds its calling thread for its length (the runtime stages it), and
+    // scan + copy-in of an FC 8x8 slice (5.2 MB) are as long as its pass -- one thread doing both directions was the bound (11.4 M blocks/s
+    // for 17.8 M on the device, profiles/r06_host_rate.txt).  The FEEDER scans and copies slices in, as far ahead as the two staging sets
+    // allow; this thread enqueues the passes and copies the results out.  What couples them: `fed` (slices whose copy-in has been issued,
+    // their event recorded) and `enqueued` (slices whose pass has been enqueued, its event recorded) under one mutex.
+    std::mutex mu;
+    std::condition_variable cv;
+    long fed = 0, enqueued = 0;
+    int feeder_rc = PNN_OK;
+    std::string feeder_err;
+    bool abort_all = false;
+    const int device = c->device;
+    std::thread feeder([&] {
+        if (hipSetDevice(device) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); feeder_rc = PNN_E_HIP; feeder_err = "hipSetDevice failed in the copy-in thread"; cv.notify_all(); return; }
+        for (long i = 0; i < nsl; i++) {
+            const int k = (int)(i & 1);
+            DevBuf* in = k ? c->stage2_in : c->stage_in;
+            hipError_t e = hipSuccess;
+            int rcl = PNN_OK;
+            // (the non-finite scan of THIS slice, here and not over the whole call up front: 84 MB of a 16-slice FC 8x8 call are 2 ms of one
+            // host thread, and the device computes the slices before meanwhile)
+            if (!all_finite(above + (size_t)i * slice * pa, (size_t)count(i) * pa) || (pl && !all_finite(left + (size_t)i * slice * pl, (size_t)count(i) * pl))) rcl = PNN_E_ARG;
+            if (rcl == PNN_OK && i >= 2) {           // the pass of slice i - 2 reads this set: its event must exist before this stream can wait for it
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return enqueued >= i - 1 || abort_all; });
+                if (abort_all) return;
+                lk.unlock();
+                e = hipStreamWaitEvent(c->copy_in, c->ev_pass[k], 0);
+            }
+            if (rcl == PNN_OK && e == hipSuccess) e = hipMemcpyAsync(in[0].p, above + (size_t)i * slice * pa, (size_t)count(i) * pa * 4, hipMemcpyHostToDevice, c->copy_in);
+            if (rcl == PNN_OK && e == hipSuccess && pl) e = hipMemcpyAsync(in[1].p, left + (size_t)i * slice * pl, (size_t)count(i) * pl * 4, hipMemcpyHostToDevice, c->copy_in);
+            if (rcl == PNN_OK && e == hipSuccess) e = hipEventRecord(c->ev_in[k], c->copy_in);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rcl != PNN_OK || e != hipSuccess) {
+                feeder_rc = rcl != PNN_OK ? rcl : PNN_E_HIP;
+                feeder_err = rcl != PNN_OK ? "non-finite value in the input contexts" : std::string("copy-in of a slice failed: ") + hipGetErrorString(e);
+                cv.notify_all();
+                return;
+            }
+            fed = i + 1;
+            cv.notify_all();
+        }
+    });
+    auto pass = [&](long i) -> int {
+        const int k = (int)(i & 1);
+        DevBuf* in = k ? c->stage2_in : c->stage_in;
+        DevBuf* ob = k ? c->stage2_out : c->stage_out;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return fed > i || feeder_rc != PNN_OK; });
+            if (fed <= i) return feeder_rc;
+        }
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->ev_out[k], 0));                  // the results of slice i - 2 have left this set
+        const int r = run_net(c, m, (const float*)in[0].p, (long)pa, (const float*)in[1].p, (long)pl, count(i), (float*)ob[0].p, dst ? (int32_t*)ob[1].p : nullptr, s);
+        if (r) return r;
+        HIPCHK(c, hipEventRecord(c->ev_pass[k], s));
+        { std::lock_guard<std::mutex> lk(mu); enqueued = i + 1; }
+        cv.notify_all();
+        return PNN_OK;
+    };
+    auto copy_out = [&](long i) -> int {
+        const int k = (int)(i & 1);
+        DevBuf* ob = k ? c->stage2_out : c->stage_out;
+        HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_pass[k], 0));
+        if (out) HIPCHK(c, hipMemcpyAsync(out + (size_t)i * slice * w2, ob[0].p, (size_t)count(i) * w2 * 4, hipMemcpyDeviceToHost, c->copy_out));
+        if (dst) {
+            if (dst_stride == w) HIPCHK(c, hipMemcpyAsync(dst + (size_t)i * slice * w2, ob[1].p, (size_t)count(i) * w2 * 4, hipMemcpyDeviceToHost, c->copy_out));
+            else HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)i * slice * w * dst_stride, (size_t)dst_stride * 4, ob[1].p, (size_t)w * 4, (size_t)w * 4, (size_t)count(i) * w,
+                                            hipMemcpyDeviceToHost, c->copy_out));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_out[k], c->copy_out));
+        return PNN_OK;
+    };
+    // nothing of a failed call stays in flight, and the feeder is never left waiting
+    auto finish = [&](int code) {
+        { std::lock_guard<std::mutex> lk(mu); abort_all = code != PNN_OK; }
+        cv.notify_all();
+        feeder.join();
+        (void)hipStreamSynchronize(c->copy_in); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(c->copy_out);
+        if (code == PNN_OK && feeder_rc != PNN_OK) code = feeder_rc;
+        if (code != PNN_OK && feeder_rc != PNN_OK && !feeder_err.empty()) return fail(c, feeder_rc, "%s", feeder_err.c_str());
+        return code;
+    };
+    if ((rc = pass(0))) return finish(rc);
+    for (long i = 0; i < nsl; i++) {
+        if (i + 1 < nsl && (rc = pass(i + 1))) return finish(rc);
+        if ((rc = copy_out(i))) return finish(rc);
+    }
+    if ((rc = finish(PNN_OK))) return rc;
+    if (c->opt_precision == 1 && *c->h_range) {
+        // a slice left the f16 range of the split-precision kernels: the whole call again on the exact-f32 kernels (what the one-pass form
+        // does for batches above 256 blocks), sequentially
+        *c->h_range = 0;
+        c->range_fallbacks++;
+        const long keep = c->opt_precision, keep_slice = c->opt_host_slice;
+        c->opt_precision = 0; c->opt_host_slice = -1;
+        rc = host_predict(c, m, above, left, n, out, dst, dst_stride);
+        c->opt_precision = keep; c->opt_host_slice = keep_slice;
+        return rc;
+    }
+    return PNN_OK;
+}
+
 static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* left, int n, float* out, int32_t* dst,
                         int dst_stride)
 {
@@ -670,6 +819,12 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
     if (n < 0 || (n > 0 && (!above || (!out && !dst)))) return fail(c, PNN_E_ARG, "bad buffers / batch size");
     if (n == 0) return PNN_OK;
     if (!m->is_fc && !left) return fail(c, PNN_E_ARG, "`left` is NULL for a convolutional model");
+    {
+        // A call of several passes' worth of blocks (the reference's batched driver slices N into many batches, pnn/batching.py:7-88) runs
+        // slice by slice with the neighbouring slices' copies -- and their non-finite scans -- beside each pass (round 6, host_predict_sliced)
+        const long slice = c->opt_host_slice > 0 ? c->opt_host_slice : std::max(64L, std::min(4096L, 262144L / w2));   // the bench batches: 4096 / 4096 / 1024 / 256 / 64
+        if (c->opt_host_slice >= 0 && !(n == 1 && c->opt_cache_mb > 0) && (long)n >= 2 * slice) return host_predict_sliced(c, m, above, left, n, out, dst, dst_stride, slice);
+    }
     {   // the range guard's v_max_f32 drops NaN operands: non-finite inputs are refused here (a few hundred floats per block)
         const size_t ca = (size_t)n * (m->is_fc ? 5 : 3) * w2, cl = m->is_fc ? 0 : (size_t)n * 2 * w2;
         if (!all_finite(above, ca) || !all_finite(left, cl)) return fail(c, PNN_E_ARG, "non-finite value in the input contexts");
@@ -865,11 +1020,11 @@ static int host_predict(pnn_ctx* c, Model* m, const float* above, const float* l
         }
         return PNN_OK;
     }
-    // One copy in, one pass, one copy out.  Streaming the batch through in chunks (staging copy, H2D, compute and D2H of successive chunks
-    // overlapped on three streams) was built in round 5 and measured SLOWER at every bench batch (FC 8x8 x 4096: 0.58 against 0.48 ms,
-    // conv 16x16 x 1024: 1.23 against 1.08): the runtime's own copy from pageable memory already runs at 25 GB/s, and a quarter or half
-    // of a bench batch does not fill the chip -- FC 8x8 at 4096 is exactly one workgroup per CU, so half of it takes as long as all of
-    // it (profiles/r05_host_rate.txt).  Pinned caller arrays (pnn_host_alloc) save another 10 %.
+    // One copy in, one pass, one copy out -- for ONE pass's worth of blocks.  Streaming a bench batch through in chunks (staging copy,
+    // H2D, compute and D2H of successive chunks overlapped on three streams) was built in round 5 and measured SLOWER at every bench batch
+    // (FC 8x8 x 4096: 0.58 against 0.48 ms, conv 16x16 x 1024: 1.23 against 1.08): a quarter or half of a bench batch does not fill the
+    // chip -- FC 8x8 at 4096 is exactly one workgroup per CU, so half of it takes as long as all of it (profiles/r05_host_rate.txt).
+    // (Calls of two slices' worth or more never get here: host_predict_sliced, above.)
     HIPCHK(c, hipMemcpyAsync(c->stage_in[0].p, above, in_a, hipMemcpyHostToDevice, s));
     if (in_l) HIPCHK(c, hipMemcpyAsync(c->stage_in[1].p, left, in_l, hipMemcpyHostToDevice, s));
     if (slot && !dst && (rc = dev_reserve(c, c->stage_out[1], (size_t)n * w2 * 4))) return rc;   // a cached entry serves both result kinds

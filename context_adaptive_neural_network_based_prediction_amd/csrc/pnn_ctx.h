@@ -97,6 +97,14 @@ struct pnn_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     pnn::DevBuf stage_in[2], stage_out[2], stage_tbs;
+    // Host calls of several passes' worth of blocks (pnn_predict_fc / _conv / _pel with N >= 2 slices; the reference's batched driver,
+    // pnn/batching.py:7-88): a second staging set, two copy streams and their events -- slice i + 1 copied in and slice i - 1 copied out
+    // while slice i computes (host_predict_sliced, pnn_abi.cpp).  host_slice: blocks per slice, 0 = the bench batch of the width
+    // (4096 / 4096 / 1024 / 256 / 64), -1 = never slice (one copy in, passes, one copy out)
+    pnn::DevBuf stage2_in[2], stage2_out[2];
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_pass[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    long opt_host_slice = 0;
     pnn::DevBuf seg_part[2];                               // K-segment partial sums of the exact-f32 conv layers: main stream / side stream
     // Prediction cache for the in-loop (n == 1) host calls: HM evaluates the same TB with the same context several
     // times during rate-distortion search.  Direct-mapped per width, exact match on the input bytes.

@@ -196,6 +196,15 @@ def predict_by_batch_via_pnn(tuple_batches_float32, sess, predictor, batch_size)
         width_target = tuple_batches_float32[0].shape[1]
     if width_target != predictor.width_target:
         raise ValueError("inputs are for width %d, the predictor is for width %d" % (width_target, predictor.width_target))
+    # The reference runs its nb_batches batches strictly one after the other (batching.py:64-86).  Here they are ONE call of the C ABI
+    # whose slices are those batches ("host_slice" = batch_size): batch i + 1 is copied in and batch i - 1 copied out while batch i
+    # computes (host_predict_sliced, csrc/pnn_abi.cpp) -- the same predictions bit for bit, a block's result does not depend on its batch.
+    if nb_batches >= 2 and not predictor._is_torch(tuple_batches_float32[0]):
+        predictor.set_option("host_slice", batch_size)
+        try:
+            return predictor.predict(*tuple_batches_float32[:1 if predictor.is_fully_connected else 2])
+        finally:
+            predictor.set_option("host_slice", 0)
     predictions_float32 = np.zeros((nb_predictions, width_target, width_target, 1), dtype=np.float32)
     for i in range(nb_batches):
         sl = slice(i * batch_size, (i + 1) * batch_size)

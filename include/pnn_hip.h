@@ -97,6 +97,9 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "autotune"             2   on first sight of a (layer, batch) pair time the legal configurations on the device and keep the fastest:
  *                              2 only launches >= 4 GFLOP, 1 always, 0 rule-based choice only.  Never while the stream is being captured
  * BOTH:
+ *   "host_slice"           0   host-array calls (pnn_predict_fc / _conv / _pel) of at least two slices' worth of blocks run slice by slice on two
+ *                              staging sets: slice i + 1 is copied in and slice i - 1 copied out while slice i computes.  0: slices of the bench
+ *                              batch of the width (4096 / 4096 / 1024 / 256 / 64 blocks); N > 0: N blocks; -1: never (one copy in, passes, one copy out)
  *   "pair"                 1   small conv passes run layer i of BOTH branches as one launch
  *   "branch_streams"       1   small passes of the 32x32 / 64x64 nets, and passes at batch, run the two branches on two streams; 2: every
  *                              small conv pass too; 0: one stream

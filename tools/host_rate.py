@@ -3,7 +3,9 @@
 pnn_predict_fc / pnn_predict_conv / pnn_predict_pel take HOST arrays (what the reference's Session::Run takes) and return host
 arrays: every call stages its contexts to the device and its predictions back.  bench.py's `value` is measured with the inputs
 already in HBM (pnn_predict_tbs_device, the gather reads the picture plane on the device); this prints what the host-array form
-of the same batch sustains -- never the bench value, noted in DESIGN.md section 5.   usage: python tools/host_rate.py [fc8 conv16 ...]
+of the same batch sustains -- never the bench value, noted in DESIGN.md section 5.   usage: python tools/host_rate.py [--slices S] [fc8 conv16 ...]
+--slices S (round 6): ONE call of S bench batches (what the reference's batched driver hands over, pnn/batching.py:7-88): the library runs it slice by
+slice with the copies of the neighbouring slices beside each pass ("host_slice"); printed beside the same call with the option off (-1).
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,10 +26,16 @@ def pinned_like(a):
 
 
 def main():
-    names = sys.argv[1:] or ["fc8", "conv16"]
+    argv = sys.argv[1:]
+    slices = 1
+    if "--slices" in argv:
+        i = argv.index("--slices")
+        slices = int(argv[i + 1])
+        del argv[i:i + 2]
+    names = argv or ["fc8", "conv16"]
     for name in names:
         wl = bench.Workload(name, 0, 0, 0)
-        w, n = wl.width, wl.batch
+        w, n = wl.width, wl.batch * slices
         rng = np.random.RandomState(5)
         if wl.is_fc:
             ins = [rng.uniform(-120, 120, (n, 5 * w * w)).astype(np.float32)]
@@ -48,15 +56,22 @@ def main():
                 a1 = None if wl.is_fc else arrs[1].ctypes.data_as(_lib.f32p)
                 dp = ctypes.cast(d.ctypes.data, _lib.i32p)
                 call = lambda: L.pnn_predict_pel(net.ctx, w, a0, a1, n, dp, w)
-                for _ in range(5):
-                    assert call() == 0
-                reps, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < 1.5:
-                    call()
-                    reps += 1
-                dt = (time.perf_counter() - t0) / reps
-                print("%-7s %-5s batch %5d %-32s %.4f ms per call = %10.0f blocks/s  (%d B in + %d B out per block = %.1f GB/s over the link)"
-                      % (name, label, n, how + ":", dt * 1e3, n / dt, in_b, 4 * w * w, (in_b + 4 * w * w) * n / dt / 1e9), flush=True)
+                want = None
+                for mode in ((0,) if slices == 1 else (0, -1)):
+                    net.set_option("host_slice", mode)
+                    for _ in range(5):
+                        assert call() == 0
+                    if want is None:
+                        want = np.array(d, copy=True)
+                    assert np.array_equal(np.asarray(d), want), "host_slice changes the result"
+                    reps, t0 = 0, time.perf_counter()
+                    while time.perf_counter() - t0 < 1.5:
+                        call()
+                        reps += 1
+                    dt = (time.perf_counter() - t0) / reps
+                    tag = "" if slices == 1 else (" x %d slices overlapped" % slices if mode == 0 else " x %d, one copy in / out" % slices)
+                    print("%-7s %-5s batch %5d%s %-32s %.4f ms per call = %10.0f blocks/s  (%d B in + %d B out per block = %.1f GB/s over the link)"
+                          % (name, label, wl.batch, tag, how + ":", dt * 1e3, n / dt, in_b, 4 * w * w, (in_b + 4 * w * w) * n / dt / 1e9), flush=True)
             net.close()
             for _, p in pins + [(None, pdst_h)]:
                 L.pnn_host_free(p)
