@@ -173,7 +173,7 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
     const int nstages = (nchunks + KC - 1) / KC;     // the packed weights are zero-padded to whole stages (kChunkPad)
     // SEQ: stages of segment k = its live taps x (cpt / KC) (a segmented layer has whole stages per tap); fold_at = the stage count at
     // which the running segment ends (segments without a live tap end where they begin and fold nothing)
-    const int sq_n = SEQ == 1 ? p.nseg : 1, sq_base = (t1 - t0) / sq_n, sq_rem = (t1 - t0) - sq_base * sq_n;
+    const int sq_n = SEQ != 0 ? p.nseg : 1, sq_base = (t1 - t0) / sq_n, sq_rem = (t1 - t0) - sq_base * sq_n;
     auto seg_stages = [&](int k) {
         const unsigned mk = ((1u << (sq_base + (k < sq_rem ? 1 : 0))) - 1u) << (k * sq_base + (k < sq_rem ? k : sq_rem));
         return __builtin_popcount(tmask & mk) * (cpt / KC);
@@ -388,9 +388,15 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
     int s = 0, buf = 0;
     if (SEQ == 1) while (fold_at == 0 && sq_k < sq_n - 1) { ++sq_k; fold_at += seg_stages(sq_k); }   // leading segments without a live tap
     if constexpr (SEQ == 2) {
-        // every segment but the last: seg_chunks / KC stages (even), the plain two-stage loop, then the fold
-        const int spp = (int)p.seg_chunks / KC;
-        for (int k = 0; k + 1 < p.nseg; k++) {
+        // every segment in front of the last LIVE one: an even number of stages (a one-tap layer: seg_chunks / KC; segments of whole taps:
+        // live taps x cpt / KC, launch_f32 takes this form only where cpt / KC is even), the plain two-stage loop, then the fold.  The last
+        // live segment ends with the tile's last stage (tail) below; segments behind it have no live tap: nothing to add.
+        const bool one_tap_seq = t1 - t0 == 1;
+        int last_live = 0;
+        if (one_tap_seq) last_live = p.nseg - 1;
+        else for (int k = 0; k < p.nseg; k++) if (seg_stages(k) > 0) last_live = k;
+        for (int k = 0; k < last_live; k++) {
+            const int spp = one_tap_seq ? (int)p.seg_chunks / KC : seg_stages(k);
             for (int i = 0; i < spp; i += 2) {
                 stage(buf, a0, a1);
                 buf = buf == 2 ? 0 : buf + 1;
@@ -951,6 +957,13 @@ static hipError_t launch_f32(const TapGemmParams& p0, bool fuse, hipStream_t s)
     }
     if (fuse) return hipErrorInvalidValue;
     if (seq && one_tap) {
+        static int done[16] = {};
+        const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, 2>, done);
+        if (e != hipSuccess) return e;
+        pnn_launch(tapgemm_f32_kernel<RT, NT, KC, false, 2>, g1, dim3(256), lds, s, p);
+        return hipGetLastError();
+    }
+    if (seq && ((p0.Cin / 16) / KC) % 2 == 0) {       // segments of whole taps, an even number of stages per tap: the two-stage inner loops (SEQ = 2)
         static int done[16] = {};
         const hipError_t e = set_attr((const void*)tapgemm_f32_kernel<RT, NT, KC, false, 2>, done);
         if (e != hipSuccess) return e;

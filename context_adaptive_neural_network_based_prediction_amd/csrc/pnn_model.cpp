@@ -167,6 +167,9 @@ int finish_gemm_layer(pnn_ctx* c, Model* m, const std::vector<float>& kn, const 
         L->nseg = 1;
         if (seg_depth > 0 && tmax > 1 && (long)tmax * p.Cin >= seg_min)
             L->nseg = (int)std::min<long>(std::min(tmin, 8), ((long)tmax * p.Cin + seg_depth - 1) / seg_depth);
+        // (Round 6, built, measured, not kept: mid-depth layers -- 1152 <= K < 2304, the 16x16 net's 1152- / 1600-deep ones -- in min(taps, 4)
+        // segments: a single 16x16 block 86 -> 71 us, but six blocks 96 -> 102 us, the 64x64 net 234 -> 258, and every conv net 2.5-4 % slower
+        // at batch: profiles/r06_conv_kseg.txt.)
         if (L->nseg < 1) L->nseg = 1;
         // One-tap layers (FC, round 6): a 1200-deep hidden layer is ONE chain of 75 chunks per output -- 4.7 us of a single-block call's
         // 7.8 us kernel whatever the batch (profiles/r06_b1_stamps.txt).  Deeper than kFcSegChunks chunks it is summed in segments of

@@ -180,9 +180,10 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     }
     if (f32k) {
         if (next) { p.W2p = next->d_w; p.Npad2 = next->proto.Npad; p.K2chunks = next->proto.chunk_begin[1]; p.part = part; }
+        const long seg_mode = c->opt_f32_seg_mode;
         auto legal = [&](int code) {
-            if (code >= ntile && (nseg == 1 || c->opt_f32_seg_mode == 0)) return false;
-            if (code < ntile && nseg > 1 && c->opt_f32_seg_mode == 1) return false;
+            if (code >= ntile && (nseg == 1 || seg_mode == 0)) return false;
+            if (code < ntile && nseg > 1 && seg_mode == 1) return false;
             const TileCfg t = tapgemm_f32_cfg(code % ntile);
             if (fcseg && L.fc_seg_chunks % (2 * t.kc)) return false;  // an even number of whole stages per segment (tapgemm_f32_kernel, SEQ = 2)
             if (fcseg && t.rt * t.nt >= 8) return false;              // ... and room for the running total beside the accumulators (the 256 x 128 tile spills)
@@ -211,7 +212,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             // the planes cost a write and a read of nseg x the output and a launch (in cycles at 2.4 GHz, ~4 TB/s through L2 / MALL)
             cost_par += (double)(nseg + 1) * (double)out_floats * 4.0 / 4.0e12 * 2.4e9 + 9000.0;
             const int cs = choose_cfg_f32(c, M, p.Cout, p.ncls, p.Cin, L.k_total, false, &cost_seq);
-            if (c->opt_f32_seg_mode == 1 || (c->opt_f32_seg_mode < 0 && cs >= 0 && cost_seq < cost_par)) cfg = ntile + cs;
+            if (seg_mode == 1 || (seg_mode < 0 && cs >= 0 && cost_seq < cost_par)) cfg = ntile + cs;
         }
         bool tune = c->opt_f32_cfg < 0 && (c->opt_autotune == 1 || (c->opt_autotune == 2 && flops >= 4.0e9));
         if (tune) {                                   // never while the caller's stream is being captured into a hipGraph
@@ -852,6 +853,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
                     }
                 }
                 c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
+                if (void* slot = diag_stamp_slot(c, br ? "f32_small pair, left branch" : "f32_small pair, above branch", tapgemm_f32_small_tiles(q[br]), L.k_total)) q[br].Xlo = slot;
             }
             static const bool dbg = getenv("PNN_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[pnn] f32 gemm pair: branch layer %zu, M = %d / %d -> one f32 small-kernel launch\n", i + 1, q[0].M, q[1].M);
