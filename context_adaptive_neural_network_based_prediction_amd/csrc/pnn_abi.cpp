@@ -269,6 +269,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_WAIT_SLEEP")) c->opt_wait_sleep = atol(e);
     if (const char* e = getenv("PNN_GRAPHS")) c->opt_graphs = atol(e);
     if (const char* e = getenv("PNN_F32_SMALL_DEEP")) c->opt_f32_small_deep = atol(e);
+    if (const char* e = getenv("PNN_CHAIN_IO")) c->opt_chain_io = atol(e);
     if (hipHostMalloc((void**)&c->h_range, (pnn_ctx::kDoneFlag0 + pnn_ctx::kDoneFlagsMax) * 4, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
@@ -478,6 +479,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "f32_small")) c->opt_f32_small = value;
     else if (!strcmp(name, "fc_out_f32")) c->opt_fc_out_f32 = value;
     else if (!strcmp(name, "host_slice")) c->opt_host_slice = value;
+    else if (!strcmp(name, "chain_io")) c->opt_chain_io = value;
     else if (!strcmp(name, "seg_fold")) c->opt_seg_fold = value;
     else if (!strcmp(name, "f32_small_deep")) c->opt_f32_small_deep = value;
     else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;

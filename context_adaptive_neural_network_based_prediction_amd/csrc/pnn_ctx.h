@@ -160,6 +160,9 @@ struct pnn_ctx {
     // capture) they may not be -- and every later folded launch would wait for an arrival count it never sees.  Zeroed again before the next one.
     bool seg_cnt_dirty = false;
     static constexpr int kSegCntTiles = 2048;
+    // 1: tensors between two launches of the small exact-f32 kernels travel in chain order (pnn_gemm_f32_small.hip, XCH: one 16-byte
+    // LDS-DMA instruction per chunk of activations instead of four 4-byte ones); 0: channel order everywhere.  Same bits.
+    long opt_chain_io = 1;
     long opt_f32_small_tiles = 1024;                  // ... "few" = at most this many 16 x 16 tiles
     long opt_f32_overlap = 1;                         // exact-f32 conv passes at batch: the two branches on two streams (see branches_overlap_at_batch)
     long opt_f32_cfg = -1;                            // tuning aid: force this tapgemm_f32 configuration on every layer it is legal for

@@ -65,9 +65,29 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 }  // namespace
 
 // INL: the f32 input rows of an FC net's first layer travel INSIDE the kernel-argument block (see tapgemm_small_inline_kernel).
-template <bool INL, int LA>
+// A lane's four consecutive output channels n0 + 4 q + r of one pixel (base = the pixel's 16-channel group n0), in channel order or in
+// chain order (see XCH below): channels 4q + {0, 2} are neighbours there, and so are 4q + {1, 3}, eight floats further on.
+__device__ __forceinline__ void f32s_store4(float* group, int q, f32x4 v, bool chain)
+{
+    if (!chain) { *reinterpret_cast<f32x4*>(group + 4 * q) = v; return; }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float* d = group + 4 * (q >> 1) + 2 * (q & 1);
+    *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[2]};
+    *reinterpret_cast<f32x2*>(d + 8) = (f32x2){v[1], v[3]};
+}
+
+// XCH (round 6): the activations are in CHAIN ORDER -- NHWC as ever, but within every 16-channel group channel kk sits at position
+// 4 g + i with g = (kk >> 3) + 2 (kk & 1), i = (kk & 7) >> 1, i.e. the four values lane group g multiplies in a chunk are 16 contiguous
+// bytes.  A loader then fetches a chunk's activations with ONE 16-byte LDS-DMA instruction (lane = (g, row): piece g of the row's
+// group) instead of four 4-byte ones whose lanes pick single floats.  Those four were what a conv layer's chunk cost above the chain:
+// 200-250 cycles per chunk against the FC layers' 152 (their rows past M = 1 are range misses), and with one instruction in their place
+// (ablation build) a single 16x16 block took 73.7 us instead of 86.9 (profiles/r06_b1_chain_order.txt).  The PRODUCER of such a tensor
+// is the epilogue below (p.chain_io bit 1: two 8-byte stores per lane instead of one 16-byte); the pass decides which tensors travel
+// that way (both ends on these kernels: pnn_passes.cpp).  Same values in another place: not a bit of any sum changes.
+template <bool INL, int LA, bool XCH = false>
 __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz, const int gy)
 {
+    static_assert(!(INL && XCH), "the argument-block input is the caller's raw context");
     constexpr int NL = kF32SmallNL, CPL = kF32SmallCPL, CS = kF32SmallCS, D = LA + 2;
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [D stages][CS chunks][weights 64 pieces | activations 64 pieces]
 #ifdef PNN_F32_DIAG                                 // diagnostic library only (make diag): 100 MHz stamps of the MFMA wave -> p.Xlo[workgroup][8]
@@ -127,8 +147,8 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
         const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
         constexpr unsigned kOob = 0x80000000u;
-        // the activation row this lane FETCHES for: m = 16 bx + (lane >> 2)
-        const int mx = bx * 16 + (lane >> 2);
+        // the activation row this lane FETCHES for: m = 16 bx + (lane >> 2) (element lane & 3 of it), XCH: 16 bx + (lane & 15) (piece lane >> 4)
+        const int mx = bx * 16 + (XCH ? (lane & 15) : (lane >> 2));
         const bool xok = mx < p.M;
         const int mxc = xok ? mx : 0;
         int xb, xi, xj;
@@ -138,7 +158,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
             const int rq = mxc - xb * SP;
             xi = rq / p.SW; xj = rq - xi * p.SW;
         }
-        const unsigned xlane = (unsigned)((lane & 3) << 3);                 // element i = lane & 3: k advances by 2 per i
+        const unsigned xlane = XCH ? (unsigned)((lane >> 4) << 4) : (unsigned)((lane & 3) << 3);   // element i = lane & 3: k advances by 2 per i; XCH: 16-byte piece lane >> 4
         int ci = c0 + j;                             // this loader's chunks: c0 + j, + NL, + 2 NL, ...
         int it = t0 + ci / cpt, icc = ci - (ci / cpt) * cpt;
         unsigned apix = kOob;
@@ -163,12 +183,16 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
 #endif
             f32s_dma16(wrsrc, wo, dst);
             float* xd = reinterpret_cast<float*>(dst + 64);
-            // lane group g: first k = 8 (g & 1) + (g >> 1) -> byte offsets 0, 32, 4, 36 -- in the SCALAR offset: the instruction's
-            // immediate offset moves the LDS destination as well as the source
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+            if (XCH) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 16, ao, so, 0, 0);
+            } else {
+                // lane group g: first k = 8 (g & 1) + (g >> 1) -> byte offsets 0, 32, 4, 36 -- in the SCALAR offset: the instruction's
+                // immediate offset moves the LDS destination as well as the source
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+            }
             if (icc >= cpt) {
                 do { icc -= cpt; ++it; } while (icc >= cpt);
                 tap_setup(it);
@@ -178,7 +202,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
 #pragma unroll
             for (int u = 0; u < CPL; u++) issue1(slot, u);
         };
-        constexpr int PER = 5 * CPL;                 // vector-memory instructions per issue()
+        constexpr int PER = (XCH ? 2 : 5) * CPL;     // vector-memory instructions per issue()
         static_assert(PER * LA < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
         for (int s = 0; s < LA; s++) issue(s);
@@ -291,7 +315,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         for (int sgm = 1; sgm < 8; sgm++) if (sgm < nseg) t += pl[sgm];
         f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-        *reinterpret_cast<f32x4*>(p.seg_Y + obase + n) = v;
+        f32s_store4(p.seg_Y + obase + n0, q, v, (p.chain_io & 2) != 0);
         F32S_DIAG_EXIT();
         return;
     }
@@ -299,7 +323,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-    if (Yo) *reinterpret_cast<f32x4*>(Yo + obase + n) = v;
+    if (Yo) f32s_store4(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     F32S_DIAG_EXIT();
 }
@@ -311,13 +335,13 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
 // from the MALL / HBM with a latency that 18 chunks of lookahead (1.1 us at the chain's pace) do not cover and 36 chunks do: a 4x4 / 8x8
 // call 55 -> 47 us inside configs[3], a 16x16 call 117 -> 107, the campaign 5.8-6.1 -> 5.5 s.  (Deep rings everywhere: conv 64x64 single
 // block 236 -> 259 us -- its 1024-tile layers then run in rounds.)
-template <int LA>
+template <int LA, bool XCH>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_kernel(const F32SmallArgs args)
 {
     touch_kernargs<sizeof(F32SmallArgs)>();
     (void)args;
     const auto* k = (const __attribute__((address_space(4))) F32SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    tapgemm_f32_small_body<false, LA>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+    tapgemm_f32_small_body<false, LA, XCH>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 template <int LA>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_inline_kernel(const F32SmallArgsInline args)
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_inline_kernel(const F32
 
 // Two independent layers in ONE launch (the same layer of the two branches of a convolutional net), see tapgemm_small_pair_kernel.
 struct F32SmallArgs2 { TapGemmParams a, b; int na; };
-template <int LA>
+template <int LA, bool XCH>
 __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32SmallArgs2 args)
 {
     touch_kernargs<sizeof(F32SmallArgs2)>();
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32Sm
     const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
     const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
     const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
-    tapgemm_f32_small_body<false, LA>(*p, r % gx, r / gx, bz, gy);
+    tapgemm_f32_small_body<false, LA, XCH>(*p, r % gx, r / gx, bz, gy);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -360,6 +384,7 @@ constexpr int kFcSegNS = 4, kFcSegLA = 5, kFcSegCPL = 2;
 static_assert(5 * kFcSegCPL * kFcSegLA < 64, "vmcnt is a 6-bit counter");
 constexpr size_t kFcSegLds = ((size_t)kFcSegNS * (kFcSegLA + 2) * kFcSegCPL * 128 + kFcSegNS * 64) * 16;
 
+template <bool XCH>
 __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs args)
 {
     touch_kernargs<sizeof(F32SmallArgs)>();
@@ -394,8 +419,8 @@ __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs
         const unsigned bstride = (unsigned)(4 * p.Npad) << 4;               // bytes per packed chunk
         const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
         constexpr unsigned kOob = 0x80000000u;
-        const int mx = bx * 16 + (lane >> 2);
-        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (unsigned)((lane & 3) << 3) : kOob;
+        const int mx = bx * 16 + (XCH ? (lane & 15) : (lane >> 2));
+        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (XCH ? (unsigned)((lane >> 4) << 4) : (unsigned)((lane & 3) << 3)) : kOob;
         int ci = c0;
         auto issue = [&](int slot) {
 #pragma unroll
@@ -408,13 +433,17 @@ __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs
                 ci++;
                 f32s_dma16(wrsrc, wo, dst);
                 float* xd = reinterpret_cast<float*>(dst + 64);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+                if (XCH) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 16, ao, so, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+                }
             }
         };
-        constexpr int PER = 5 * CPL;
+        constexpr int PER = (XCH ? 2 : 5) * CPL;
 #pragma unroll
         for (int st = 0; st < LA; st++) issue(st);
         f32s_wait_vm<PER * (LA - 1)>();              // stage 0 has landed
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs
         f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
         const size_t o = (size_t)mg * p.Cout + n;
-        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o) = v;
+        if (p.Y) f32s_store4(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
 #ifdef PNN_F32_DIAG
@@ -503,6 +532,7 @@ static_assert(kFcSegChunks % kFcAllCPS == 0 && 5 * kFcAllPerLoader < 64, "whole 
 constexpr int kFcAllMaxSlots = 76;
 constexpr size_t kFcAllLds = ((size_t)kFcAllMaxSlots * 128 + kFcSegNS * 64) * 16;
 
+template <bool XCH>
 __global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32SmallArgs args)
 {
     touch_kernargs<sizeof(F32SmallArgs)>();
@@ -546,8 +576,8 @@ __global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32Small
         const unsigned bstride = (unsigned)(4 * p.Npad) << 4;
         const unsigned wlane = (unsigned)((q * p.Npad + n0 + l15) << 4);
         constexpr unsigned kOob = 0x80000000u;
-        const int mx = bx * 16 + (lane >> 2);
-        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (unsigned)((lane & 3) << 3) : kOob;
+        const int mx = bx * 16 + (XCH ? (lane & 15) : (lane >> 2));
+        const unsigned apix = mx < p.M ? (((unsigned)mx * (unsigned)p.Cin) << 2) + (XCH ? (unsigned)((lane >> 4) << 4) : (unsigned)((lane & 3) << 3)) : kOob;
         const int nslots = nst * CPS;                               // slots this chain owns (live stages)
 #pragma unroll
         for (int i = 0; i < PL; i++) {
@@ -563,16 +593,21 @@ __global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32Small
             const unsigned so = (unsigned)(ci << 6);
             f32s_dma16(wrsrc, wo, dst);
             float* xd = reinterpret_cast<float*>(dst + 64);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+            if (XCH) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 16, ao, so, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd), 4, ao, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 64), 4, ao, so + 32u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 128), 4, ao, so + 4u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xd + 192), 4, ao, so + 36u, 0, 0);
+            }
         }
         // stage t is whole when both loaders have seen their chunks 2t and 2t + 1 land (loads complete in issue order)
-        f32s_wait_vm<5 * (PL - 2)>(); __builtin_amdgcn_s_barrier();
-        f32s_wait_vm<5 * (PL - 4)>(); __builtin_amdgcn_s_barrier();
-        f32s_wait_vm<5 * (PL - 6)>(); __builtin_amdgcn_s_barrier();
-        f32s_wait_vm<5 * (PL - 8)>(); __builtin_amdgcn_s_barrier();
+        constexpr int IPC = XCH ? 2 : 5;             // vector-memory instructions per chunk
+        f32s_wait_vm<IPC * (PL - 2)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<IPC * (PL - 4)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<IPC * (PL - 6)>(); __builtin_amdgcn_s_barrier();
+        f32s_wait_vm<IPC * (PL - 8)>(); __builtin_amdgcn_s_barrier();
         f32s_wait_vm<0>(); __builtin_amdgcn_s_barrier();
         static_assert(NST == 5 && PL == 10, "the five waits above");
         __builtin_amdgcn_s_barrier();                // the segment sums' barrier
@@ -629,7 +664,7 @@ __global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32Small
         f32x4 v = tsum + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
         const size_t o = (size_t)mg * p.Cout + n;
-        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o) = v;
+        if (p.Y) f32s_store4(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
 #ifdef PNN_F32_DIAG
@@ -665,21 +700,26 @@ hipError_t launch_fcseg_f32_small(const TapGemmParams& p, hipStream_t s)
     if (e != hipSuccess) return e;
     const int di = dev >= 0 && dev < 16 ? dev : 0;
     if (!__atomic_load_n(&done[di], __ATOMIC_ACQUIRE)) {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcSegLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcSegLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcSegLds)) != hipSuccess) return e;
         __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
     }
     const F32SmallArgs a{p};
+    const bool xch = (p.chain_io & 1) != 0;          // the activations are in chain order (see tapgemm_f32_small_body)
     static const bool no_all = getenv("PNN_FCSEG_RING") != nullptr;   // A/B: the ring form for every layer
     if (fcseg_all_fits(p) && !no_all) {
         static int done_all[16] = {};
         if (!__atomic_load_n(&done_all[di], __ATOMIC_ACQUIRE)) {
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcAllLds)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_all_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcAllLds)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fcseg_f32_small_all_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFcAllLds)) != hipSuccess) return e;
             __atomic_store_n(&done_all[di], 1, __ATOMIC_RELEASE);
         }
-        pnn_launch(fcseg_f32_small_all_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(768), kFcAllLds, s, a);
+        if (xch) pnn_launch(fcseg_f32_small_all_kernel<true>, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(768), kFcAllLds, s, a);
+        else pnn_launch(fcseg_f32_small_all_kernel<false>, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(768), kFcAllLds, s, a);
         return hipGetLastError();
     }
-    pnn_launch(fcseg_f32_small_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), kFcSegLds, s, a);
+    if (xch) pnn_launch(fcseg_f32_small_kernel<true>, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), kFcSegLds, s, a);
+    else pnn_launch(fcseg_f32_small_kernel<false>, dim3((unsigned)((p.M + 15) / 16), (unsigned)((p.Cout + 15) / 16)), dim3(512), kFcSegLds, s, a);
     return hipGetLastError();
 }
 
@@ -700,11 +740,14 @@ static hipError_t f32_small_attrs()
     if (e != hipSuccess) return e;
     const int di = dev >= 0 && dev < 16 ? dev : 0;
     if (__atomic_load_n(&done[di], __ATOMIC_ACQUIRE)) return hipSuccess;
-    const void* fns[6] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLA>),
-                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLA>), reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLADeep>),
-                          reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLADeep>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLADeep>)};
-    for (int i = 0; i < 6; i++)
-        if ((e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes(i >= 3))) != hipSuccess) return e;
+    const void* fns[10] = {reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLA, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLA, true>),
+                           reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLA>),
+                           reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLA, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLA, true>),
+                           reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLADeep, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_kernel<kF32SmallLADeep, true>),
+                           reinterpret_cast<const void*>(&tapgemm_f32_small_inline_kernel<kF32SmallLADeep>),
+                           reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLADeep, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_kernel<kF32SmallLADeep, true>)};
+    for (int i = 0; i < 10; i++)
+        if ((e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes(i >= 5))) != hipSuccess) return e;
     __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
     return hipSuccess;
 }
@@ -730,8 +773,11 @@ hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const
         return hipGetLastError();
     }
     const F32SmallArgs a{p};
-    if (deep) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLADeep>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
-    else pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
+    const bool xch = (p.chain_io & 1) != 0;          // the activations are in chain order (see tapgemm_f32_small_body)
+    if (deep && xch) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLADeep, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+    else if (deep) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLADeep, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+    else if (xch) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
+    else pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
     return hipGetLastError();
 }
 
@@ -744,8 +790,12 @@ hipError_t launch_tapgemm_f32_small_pair(const TapGemmParams& a, const TapGemmPa
     args.a = a; args.b = b;
     args.na = (int)tapgemm_f32_small_tiles(a);
     const long total = args.na + tapgemm_f32_small_tiles(b);
-    if (f32_small_deep(total, deep_mode, false)) pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLADeep>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
-    else pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLA>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
+    if ((a.chain_io & 1) != (b.chain_io & 1)) return hipErrorInvalidValue;   // one instantiation per launch: both layers' inputs in the same order
+    const bool xch = (a.chain_io & 1) != 0, deep = f32_small_deep(total, deep_mode, false);
+    if (deep && xch) pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLADeep, true>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
+    else if (deep) pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLADeep, false>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
+    else if (xch) pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLA, true>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
+    else pnn_launch(tapgemm_f32_small_pair_kernel<kF32SmallLA, false>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
     return hipGetLastError();
 }
 

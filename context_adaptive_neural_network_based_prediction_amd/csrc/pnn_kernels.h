@@ -101,7 +101,10 @@ struct TapGemmParams {
     // ring kernel, position-major tiles (set by launch_tapgemm_ring, see pnn_gemm_ring.hip): pm_groups > 0 = a workgroup's BM
     // rows are BM BLOCKS at ONE position of the SH x SW grid, so a tap that falls outside the image does so for the whole
     // tile and is skipped; pm_groups = number of block groups, nblk = number of blocks; the position order: pos_order above
-    int pm_groups, nblk;
+    // (tapgemm_f32_small kernels, in nblk's bytes: chain_io bit 0 = the activations X are in CHAIN ORDER -- NHWC with every 16-channel
+    // group permuted so that the four values a lane group of the 16x16x4 chain multiplies are contiguous, pnn_gemm_f32_small.hip --,
+    // bit 1 = write the output that way; set by the pass for tensors whose producer AND consumer are those kernels)
+    int pm_groups; union { int nblk; int chain_io; };
     // image kernel, fused last layer (Cout == 64 -> 1 transposed convolution, kernel k1, stride s1, pad1 before, bias1): k1 != 0
     float bias1; int k1, s1, pad1;
     // tapgemm_f32_kernel, K segments (nseg > 1, see GemmLayer::nseg): grid z = class * nseg + segment; a workgroup walks only its

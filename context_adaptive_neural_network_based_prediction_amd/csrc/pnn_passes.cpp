@@ -26,11 +26,41 @@ void* diag_stamp_slot(pnn_ctx* c, const char* name, long wgs, double k)
 
 namespace {
 
+// Would run_gemm send this layer (nb blocks, no fused next layer) to the small exact-f32 kernels?  The ONE statement of that rule:
+// run_gemm decides by it, and the passes by it which tensors travel in chain order (both ends on those kernels, pnn_gemm_f32_small.hip).
+bool f32_small_applies(const pnn_ctx* c, const GemmLayer& L, long nb, bool has_next, bool has_yi)
+{
+    static const bool big_diag = getenv("PNN_F32_DIAG") != nullptr;
+    if (has_next || !c->opt_f32_small || c->opt_f32_cfg >= 0 || big_diag) return false;
+    TapGemmParams p = L.proto;
+    const long M = nb * p.SH * p.SW;
+    if (M > 0x7fffffffL) return false;
+    p.M = (int)M;
+    if (L.fc_seg_chunks > 0 && L.nseg > 1) {
+        p.nseg = L.nseg; p.seg_chunks = (unsigned)L.fc_seg_chunks;
+        return fcseg_f32_small_fits(p) && fcseg_f32_small_tiles(p) <= c->opt_f32_small_tiles;
+    }
+    p.nseg = (!has_yi && L.nseg > 1) ? L.nseg : 1;
+    return tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles;
+}
+// ... and may its OUTPUT be written in chain order?  (a K-segmented layer only when its planes are added up inside the launch: the
+// seg_reduce kernel writes channel order)
+bool f32_small_chain_out_ok(const pnn_ctx* c, const GemmLayer& L, long nb)
+{
+    if (!c->opt_chain_io || L.proto.Cout % 16) return false;
+    if (L.nseg <= 1 || L.fc_seg_chunks > 0) return true;
+    TapGemmParams p = L.proto;
+    p.M = (int)(nb * p.SH * p.SW); p.nseg = L.nseg;
+    return c->opt_seg_fold && c->d_seg_cnt && tapgemm_f32_small_tiles(p) / L.nseg <= pnn_ctx::kSegCntTiles && !c->opt_time_launches;
+}
+
 // Exact-f32 launch.  `next` (optional): the net's output layer (<= 64 outputs) applied to this layer's activated tile inside the
 // launch (tapgemm_f32_kernel, 128 x 160 tile); `part` then receives the per-column-tile partial sums [tiles][M][64], *tiles_out
 // their count, and the caller finishes with launch_fuse_reduce.  Y / Yi must be null in that case.
+// chain_io: bit 0 = X is in chain order, bit 1 = write Y in chain order (TapGemmParams::chain_io) -- only for a layer that
+// f32_small_applies() sends to the small kernels; anything else is the caller's mistake and refused.
 int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s,
-             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr, const float* host_rows = nullptr)
+             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr, const float* host_rows = nullptr, int chain_io = 0)
 {
     TapGemmParams p = L.proto;
     p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
@@ -75,10 +105,12 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
     }
     // Few output tiles (the in-loop single-block calls, the batching service's handfuls): the same fmaf chain per output on the 16x16x4
     // instruction, one wave per 16 x 16 tile over all CUs (pnn_gemm_f32_small.hip) -- bit-identical, 3.2 x shorter dependent chain
-    static const bool big_diag = getenv("PNN_F32_DIAG") != nullptr;
-    if (fcseg && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && fcseg_f32_small_fits(p) && fcseg_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
+    const bool small_f32 = f32k && f32_small_applies(c, L, nblocks, next != nullptr, Yi != nullptr);
+    if (chain_io && !small_f32) return fail(c, PNN_E_ARG, "internal: chain-order activations for a layer that does not run on the small kernels");
+    if (fcseg && small_f32) {
         TapGemmParams ps = p;
         ps.Wp = L.d_w_ch;                             // the weights in the chain waves' lane order
+        ps.chain_io = chain_io;
         if (debug) fprintf(stderr, "[pnn] gemm M=%ld K=%.0f N=%d nseg=%d -> f32 small kernel, %d K segments side by side (%ld tiles of 16 x 16)\n", M, L.k_total, p.Cout, L.nseg, L.nseg, fcseg_f32_small_tiles(p));
         if (void* slot = diag_stamp_slot(c, "fcseg_f32_small", fcseg_f32_small_tiles(p), L.k_total)) ps.Xlo = slot;   // (diagnostic library, PNN_B1_STAMPS)
         if (profile || c->opt_time_launches) {
@@ -108,9 +140,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         c->stat_gemm_flops += flops;
         return PNN_OK;
     }
-    if (f32k && !fcseg && !next && c->opt_f32_small && c->opt_f32_cfg < 0 && tapgemm_f32_small_tiles(p) <= c->opt_f32_small_tiles && !big_diag) {
+    if (!fcseg && small_f32) {
         TapGemmParams ps = p;
         ps.Wp = L.d_w_ch;                             // the same weights in the small kernel's lane order
+        ps.chain_io = chain_io;
+        if ((chain_io & 1) && host_rows) host_rows = nullptr;   // (the argument-block input is the caller's raw context: never in chain order)
         // K segments: added up by the launch itself (the tile's last workgroup to arrive) when the tiles have counters
         const long seg_tiles = nseg > 1 ? tapgemm_f32_small_tiles(p) / nseg : 0;
         const bool fold = nseg > 1 && c->opt_seg_fold && c->d_seg_cnt && seg_tiles <= pnn_ctx::kSegCntTiles && !c->opt_time_launches;
@@ -153,6 +187,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows, (int)c->opt_f32_small_deep));
         }
         if (nseg > 1 && !fold) {
+            if (chain_io & 2) return fail(c, PNN_E_ARG, "internal: chain-order output of a layer whose K segments are reduced by a second launch");
             HIPCHK(c, launch_seg_reduce(p.Y, nseg, out_floats, p.Cout, L.d_bias, L.proto.act, Y, s));
             c->stat_launches++;
         }
@@ -677,8 +712,15 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
         if ((rc = run_gemm_sp(c, m->fc[2], P1, nullptr, P0, nullptr, nullptr, nullptr, nb, s))) return rc;
         return run_gemm(c, m->fc[3], P0, d_out, d_dst, nb, s);
     }
-    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s, nullptr, nullptr, nullptr, c->host_input))) return rc;
-    if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s))) return rc;
+    // Small passes: the hidden activations travel in CHAIN ORDER between the three small-kernel launches (pnn_gemm_f32_small.hip: a
+    // consumer's loaders then fetch a chunk's activations with one 16-byte instruction instead of four 4-byte ones); the output layer's
+    // kernel reads channel order, so the third layer writes that.  All three or none: they have the same number of tiles.
+    const bool out64 = m->fc[3].proto.Cout <= 64 && m->fc[3].proto.Cout % 4 == 0;
+    const bool chain = c->opt_chain_io && out64 && !(c->opt_fuse_last && nb >= 1024) && f32_small_applies(c, m->fc[0], nb, false, false) &&
+                       f32_small_applies(c, m->fc[1], nb, false, false) && f32_small_applies(c, m->fc[2], nb, false, false) &&
+                       f32_small_chain_out_ok(c, m->fc[0], nb) && f32_small_chain_out_ok(c, m->fc[1], nb);
+    if ((rc = run_gemm(c, m->fc[0], d_ctx, P0, nullptr, nb, s, nullptr, nullptr, nullptr, c->host_input, chain ? 2 : 0))) return rc;
+    if ((rc = run_gemm(c, m->fc[1], P0, P1, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, chain ? 3 : 0))) return rc;
     // Output layer of the 4x4 / 8x8 nets (<= 64 outputs) on the exact-f32 path: summed in K segments of 160 hidden units +
     // fuse_reduce at EVERY batch size -- inside the last hidden layer's launch (big batches: its 1200-wide activations never
     // leave the registers of the waves that produce them; the 29 us / 14 %-of-peak launch of rounds 1-3 is gone) or from the
@@ -692,7 +734,7 @@ int fc_pass(pnn_ctx* c, Model* m, const float* d_ctx, bool ctx_is_split, long nb
         if (c->opt_fuse_last && nb >= 1024) {
             if ((rc = run_gemm(c, m->fc[2], P1, nullptr, nullptr, nb, s, &m->fc[3], part, &tiles))) return rc;
         } else {
-            if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s))) return rc;
+            if ((rc = run_gemm(c, m->fc[2], P1, P0, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, chain ? 1 : 0))) return rc;
             TapGemmParams q = m->fc[3].proto;
             q.X = P0; q.Wp = m->fc[3].d_w; q.part = part; q.M = (int)nb; q.x_bytes = (unsigned)(4.0 * (double)nb * q.Cin);
             // small passes: the K segments and their reduction in ONE launch (fc_out_f32_small_kernel: the same bits, one launch less
@@ -824,12 +866,15 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         c->stat_launches++;
         const size_t nl = m->branch[0].size();
         int cur = 0;
+        bool in_chain = false;                        // the tensors layer i reads are in chain order (written so by layer i - 1 of both branches)
         for (size_t i = 0; i < nl; i++) {
             const bool last = i + 1 == nl;
             TapGemmParams q[2];
             float* dst[2];
             size_t out_floats[2];
             bool folded[2] = {false, false};
+            // ... and layer i writes that way when layer i + 1 is another launch of this kernel (the last branch layer feeds the merger: channel order)
+            const bool out_chain = !last && f32_small_chain_out_ok(c, m->branch[0][i], nb) && f32_small_chain_out_ok(c, m->branch[1][i], nb);
             for (int br = 0; br < 2; br++) {
                 const GemmLayer& L = m->branch[br][i];
                 q[br] = L.proto;
@@ -852,6 +897,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
                         q[br].seg_Y = dst[br]; q[br].bias = L.d_bias; q[br].act = L.proto.act;
                     }
                 }
+                q[br].chain_io = (in_chain ? 1 : 0) | (out_chain ? 2 : 0);
                 c->stat_gemm_flops += 2.0 * (double)q[br].M * L.k_total * q[br].Cout;
                 if (void* slot = diag_stamp_slot(c, br ? "f32_small pair, left branch" : "f32_small pair, above branch", tapgemm_f32_small_tiles(q[br]), L.k_total)) q[br].Xlo = slot;
             }
@@ -865,6 +911,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
                 HIPCHK(c, launch_seg_reduce(q[br].Y, L.nseg, out_floats[br], q[br].Cout, L.d_bias, L.proto.act, dst[br], s));
                 c->stat_launches++;
             }
+            in_chain = out_chain;
             cur ^= 1;
         }
         pair = true;                                  // the branches are done
@@ -927,15 +974,19 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
     tp.done = take_done_signal(c);
     bool last_done = false;                          // the last layer went out with (or inside) the GEMM in front of it
+    bool t_in_chain = false;                         // exact f32, small passes: the transposed convolutions hand their maps on in chain order (see fc_pass)
     for (size_t i = 0; i < nt; i++) {
         const bool last = i + 1 == nt;
+        const bool t_out_chain = !sp && !last && f32_small_applies(c, m->tconv[i], nb, false, false) && f32_small_applies(c, m->tconv[i + 1], nb, false, false) &&
+                                 f32_small_chain_out_ok(c, m->tconv[i], nb);
         if (sp && last) {                            // run_gemm_sp launches the net's last layer too, or has the image kernel apply it
             tp.X = P[cur ^ 1];
             rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, P[cur ^ 1], nullptr, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, false, 0, nullptr, &tp);
             last_done = true;
         } else if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, nullptr, P[cur ^ 1], nullptr, nullptr, nb, s);
-        else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s);
+        else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, (t_in_chain ? 1 : 0) | (t_out_chain ? 2 : 0));
         if (rc) return rc;
+        t_in_chain = t_out_chain;
         cur ^= 1;
     }
     if (!last_done) {

@@ -430,6 +430,12 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
         assert np.array_equal(run(above[:1], left[:1])[0], want[0]), "f32_small_deep = %d, one block" % deep
     for _ in range(3):                                               # the tiles' counters go back to zero: launch after launch
         assert np.array_equal(run(above[:1], left[:1])[0], want[0])
+    for chain in (0, 1):                                             # hidden tensors in channel order / in the chain's order (round 6): the same sums
+        net.set_option("chain_io", chain)
+        assert np.array_equal(run(above, left), want), "chain_io = %d" % chain
+        for m in (1, 2, 17):
+            if m <= n:
+                assert np.array_equal(run(above[:m], left[:m]), want[:m]), "chain_io = %d, %d blocks" % (chain, m)
     net.set_option("fc_out_f32", 0)                                  # FC: the output layer's K segments and their reduction as two launches
     assert np.array_equal(run(above, left), want)
     assert np.array_equal(net.predict_pel(*((util.flatten_fc(above, left),) if is_fc else (above, left))), pel)
