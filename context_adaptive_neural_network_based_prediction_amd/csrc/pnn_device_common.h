@@ -145,6 +145,18 @@ __device__ __forceinline__ void store16_through_mfma(f32x4* dst, f32x4 v)
 #endif
 }
 
+// A lane's four consecutive output channels 16 G + 4 q + r of one pixel (group = the pixel's 16-channel group G), in channel order or in
+// CHAIN ORDER (tapgemm_f32_small_body, XCH: within a group channel kk sits at 4 g + i, g = (kk >> 3) + 2 (kk & 1), i = (kk & 7) >> 1 --
+// the order the 16x16x4 chain's lane groups consume): channels 4q + {0, 2} are neighbours there, and so are 4q + {1, 3}, eight floats on.
+__device__ __forceinline__ void store4_chain(float* group, int q, f32x4 v, bool chain)
+{
+    if (!chain) { *reinterpret_cast<f32x4*>(group + 4 * q) = v; return; }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float* d = group + 4 * (q >> 1) + 2 * (q & 1);
+    *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[2]};
+    *reinterpret_cast<f32x2*>(d + 8) = (f32x2){v[1], v[3]};
+}
+
 // Split activation layout of the split-precision GEMM: element (pixel, channel n) of a [pixels][C] tensor lives at
 // f16 index 2*pixel*C + (n/16)*32 + n%16 (hi) and +16 (lo); x = hi + lo with hi = (f16) x, lo = (f16)(x - hi).
 __device__ __forceinline__ void store_split4(void* base, size_t pixel_times_c, int n, f32x4 v, float& amax)

@@ -65,17 +65,6 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 }  // namespace
 
 // INL: the f32 input rows of an FC net's first layer travel INSIDE the kernel-argument block (see tapgemm_small_inline_kernel).
-// A lane's four consecutive output channels n0 + 4 q + r of one pixel (base = the pixel's 16-channel group n0), in channel order or in
-// chain order (see XCH below): channels 4q + {0, 2} are neighbours there, and so are 4q + {1, 3}, eight floats further on.
-__device__ __forceinline__ void f32s_store4(float* group, int q, f32x4 v, bool chain)
-{
-    if (!chain) { *reinterpret_cast<f32x4*>(group + 4 * q) = v; return; }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    float* d = group + 4 * (q >> 1) + 2 * (q & 1);
-    *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[2]};
-    *reinterpret_cast<f32x2*>(d + 8) = (f32x2){v[1], v[3]};
-}
-
 // XCH (round 6): the activations are in CHAIN ORDER -- NHWC as ever, but within every 16-channel group channel kk sits at position
 // 4 g + i with g = (kk >> 3) + 2 (kk & 1), i = (kk & 7) >> 1, i.e. the four values lane group g multiplies in a chunk are 16 contiguous
 // bytes.  A loader then fetches a chunk's activations with ONE 16-byte LDS-DMA instruction (lane = (g, row): piece g of the row's
@@ -315,7 +304,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
         for (int sgm = 1; sgm < 8; sgm++) if (sgm < nseg) t += pl[sgm];
         f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-        f32s_store4(p.seg_Y + obase + n0, q, v, (p.chain_io & 2) != 0);
+        store4_chain(p.seg_Y + obase + n0, q, v, (p.chain_io & 2) != 0);
         F32S_DIAG_EXIT();
         return;
     }
@@ -323,7 +312,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-    if (Yo) f32s_store4(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
+    if (Yo) store4_chain(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     F32S_DIAG_EXIT();
 }
@@ -510,7 +499,7 @@ __global__ __launch_bounds__(512) void fcseg_f32_small_kernel(const F32SmallArgs
         f32x4 v = t + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
         const size_t o = (size_t)mg * p.Cout + n;
-        if (p.Y) f32s_store4(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
+        if (p.Y) store4_chain(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
 #ifdef PNN_F32_DIAG
@@ -664,7 +653,7 @@ __global__ __launch_bounds__(768) void fcseg_f32_small_all_kernel(const F32Small
         f32x4 v = tsum + *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
         const size_t o = (size_t)mg * p.Cout + n;
-        if (p.Y) f32s_store4(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
+        if (p.Y) store4_chain(p.Y + (size_t)mg * p.Cout + n0, q, v, (p.chain_io & 2) != 0);
         if (p.Yi) *reinterpret_cast<int4*>(p.Yi + o) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     }
 #ifdef PNN_F32_DIAG

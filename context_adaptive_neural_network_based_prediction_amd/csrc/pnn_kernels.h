@@ -203,6 +203,7 @@ struct Conv1Params {
     // plane through TB descriptor tbs[b] (branch 0: the above portion w x 3w, 1: the left portion 2w x w; unit-pixel availability
     // units), Pel (pel_bytes) -> float, minus mean: the values gather_f32x4_kernel would have written
     const void* plane; const TbDev* tbs; int pel_bytes, unit, w, branch; float mean;
+    int chain;       // f32 output only: 1 = write it in chain order (its consumer is a small exact-f32 kernel, pnn_gemm_f32_small.hip)
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s);   // both branches in one launch (same batch, same kernel size)
@@ -222,6 +223,7 @@ struct MergerParams {
     int B, C, na, nl, nout;
     int split;   // 1: write Y in the split f16 activation layout
     int* range_flag; // split output only: raised when a value leaves the f16 range
+    int chain;       // f32 output only: 1 = write it in chain order (its consumer is a small exact-f32 kernel, pnn_gemm_f32_small.hip)
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);
 

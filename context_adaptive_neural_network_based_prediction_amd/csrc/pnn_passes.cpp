@@ -852,11 +852,14 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         if ((rc = dev_reserve(c, c->ws[5], (size_t)nb * m->pmax * 4))) return rc;
         float* Q[2][2] = {{P[0], P[1]}, {(float*)c->ws[4].p, (float*)c->ws[5].p}};
         Conv1Params f[2];
+        // the first convolutions' maps in chain order too: their consumer is the pair launch of layer 1 (both branches or neither)
+        const bool first_chain = c->opt_chain_io && m->first[0].proto.Cout % 16 == 0 && m->first[1].proto.Cout % 16 == 0;
         for (int br = 0; br < 2; br++) {
             f[br] = m->first[br].proto;
             f[br].X = br == 0 ? d_above : d_left; f[br].W = m->first[br].d_w; f[br].bias = m->first[br].d_bias;
             f[br].Wsp = m->first[br].d_w_sp; f[br].out_scale = m->first[br].sp_inv_scale; f[br].npad = m->first[br].npad;
             f[br].B = (int)nb; f[br].range_flag = c->h_range; f[br].Y = Q[br][0]; f[br].split = 0;
+            f[br].chain = first_chain ? 1 : 0;
             if (!f[br].X && c->lazy.plane) {
                 f[br].plane = c->lazy.plane; f[br].tbs = reinterpret_cast<const TbDev*>(c->lazy.tbs); f[br].pel_bytes = c->lazy.pel_bytes; f[br].unit = c->lazy.unit;
                 f[br].w = m->width; f[br].branch = br; f[br].mean = c->mean;
@@ -866,7 +869,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
         c->stat_launches++;
         const size_t nl = m->branch[0].size();
         int cur = 0;
-        bool in_chain = false;                        // the tensors layer i reads are in chain order (written so by layer i - 1 of both branches)
+        bool in_chain = first_chain;                  // the tensors layer i reads are in chain order (written so by layer i - 1 of both branches)
         for (size_t i = 0; i < nl; i++) {
             const bool last = i + 1 == nl;
             TapGemmParams q[2];
@@ -967,6 +970,9 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     mp.A = F[0]; mp.L = F[1]; mp.Wp = m->merger.d_w; mp.bias = m->merger.d_bias; mp.Y = P[0]; mp.B = (int)nb;
     mp.split = (sp && nt > 0) ? 1 : 0;
     mp.range_flag = c->h_range;
+    // exact f32, small passes: the merged map in chain order when the first transposed convolution runs on the small kernels
+    const bool merger_chain = !sp && nt > 0 && c->opt_chain_io && mp.C % 16 == 0 && f32_small_applies(c, m->tconv[0], nb, false, false);
+    mp.chain = merger_chain ? 1 : 0;
     HIPCHK(c, launch_merger(mp, s));
     c->stat_launches++;
     int cur = 0;
@@ -974,7 +980,7 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
     tp.done = take_done_signal(c);
     bool last_done = false;                          // the last layer went out with (or inside) the GEMM in front of it
-    bool t_in_chain = false;                         // exact f32, small passes: the transposed convolutions hand their maps on in chain order (see fc_pass)
+    bool t_in_chain = merger_chain;                  // exact f32, small passes: the transposed convolutions hand their maps on in chain order (see fc_pass)
     for (size_t i = 0; i < nt; i++) {
         const bool last = i + 1 == nt;
         const bool t_out_chain = !sp && !last && f32_small_applies(c, m->tconv[i], nb, false, false) && f32_small_applies(c, m->tconv[i + 1], nb, false, false) &&

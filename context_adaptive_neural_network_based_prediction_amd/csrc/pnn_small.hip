@@ -140,7 +140,7 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
 #pragma unroll
             for (int kx = 0; kx < K; kx++) acc += xr[ky * PW + kx] * w[ky * K + kx];
         acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]);
-        *reinterpret_cast<f32x4*>(yb + (size_t)pix * p.Cout + 4 * cg) = acc;
+        store4_chain(yb + (size_t)pix * p.Cout + ((4 * cg) & ~15), cg & 3, acc, p.chain != 0);
     }
 }
 
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
 #pragma unroll
                 for (int i = 0; i < 4; i++) v[i] = leaky(acc[4 * q + i][r] + bv[q][i]);
                 if (SPLIT) store_split4(p.Y, pix * p.C, c0 + 4 * q, v, amax);
-                else *reinterpret_cast<f32x4*>(p.Y + pix * p.C + c0 + 4 * q) = v;
+                else store4_chain(p.Y + pix * p.C + c0, q, v, p.chain != 0);
             }
         }
     }
