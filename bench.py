@@ -725,7 +725,7 @@ def main():
             "config": {"workload": r.get("config", args.workload), "step": "all encodes + decodes of the campaign", "pictures": r.get("pictures"),
                        "picture_set": args.hm_pictures, "parallelism": "independent encodes dealt over one batching service per device, no collective"},
             "hm": {k: r.get(k) for k in ("variant", "pictures", "picture_set", "arithmetic", "wall_s_all_encodes_and_decodes", "pictures_per_s", "wall_vs_regular",
-                                         "every_decode_equals_its_encoder", "service_start_s", "bits_total", "host_cpu", "error")} if isinstance(r, dict) else None,
+                                         "every_decode_equals_its_encoder", "arithmetic_tags", "service_start_s", "bits_total", "host_cpu", "error")} if isinstance(r, dict) else None,
             "roofline": None,
             "cpu_baseline": {"value": cpu_pnn.get("pictures_per_s"), "unit": "pictures/s", "cores": cpu_pnn.get("cores"), "kind": "port",
                              "sample": cpu_pnn.get("sample"), "gpu_same_sample": cpu_pnn.get("gpu_same_sample_pictures_per_s"),
