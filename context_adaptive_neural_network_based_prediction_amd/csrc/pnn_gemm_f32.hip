@@ -260,14 +260,17 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
     // (Round 6, tried and removed: the fold INSIDE the next stage's first k-step -- per accumulator tile, its first MFMA taking a zero
     // addend -- needs a second form of the stage body; with it the register allocator spilled 199 VGPRs and FC 8x8 at batch 4096 lost
     // 10 %, profiles/r06_fcseg_ab.txt.)
-    auto fold_now = [&]() {
+    // first: nothing has been folded yet -- the total is 0, and 0 + p = p exactly for a chain sum p (one that starts from +0 is never
+    // -0): a copy in place of read, read, add, write
+    auto fold_now = [&](bool first = false) {
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    total[SEQ ? rt : 0][SEQ ? nt : 0][i] += acc[rt][nt][i];
+                    if (first) total[SEQ ? rt : 0][SEQ ? nt : 0][i] = acc[rt][nt][i];
+                    else total[SEQ ? rt : 0][SEQ ? nt : 0][i] += acc[rt][nt][i];
                     acc[rt][nt][i] = 0.f;
                 }
     };
@@ -404,7 +407,7 @@ __device__ __forceinline__ void f32_tile(const TapGemmParams& p, f32x4* const ld
                 buf = buf == 2 ? 0 : buf + 1;
             }
             s += spp;
-            fold_now();
+            if (k == 0) fold_now(true); else fold_now();
         }
     }
     for (; s + 2 < nstages; s += 2) {

@@ -14,11 +14,12 @@ ap.add_argument("--widths", default="4,8")
 ap.add_argument("--n", type=int, default=1)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--calls", type=int, default=300)
+ap.add_argument("--conv-small", action="store_true", help="widths 4 / 8 as CONVOLUTIONAL nets (the reference's trained checkpoints are of that kind)")
 ap.add_argument("sets", nargs="*", default=["-"])
 args = ap.parse_args()
 L = _lib.lib()
 for w in [int(x) for x in args.widths.split(",")]:
-    fc = w <= 8
+    fc = w <= 8 and not args.conv_small
     n = args.n
     nets = []
     a, l = util.make_contexts(w, n, 2)
