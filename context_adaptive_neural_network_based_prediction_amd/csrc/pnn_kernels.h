@@ -204,6 +204,7 @@ struct Conv1Params {
     // units), Pel (pel_bytes) -> float, minus mean: the values gather_f32x4_kernel would have written
     const void* plane; const TbDev* tbs; int pel_bytes, unit, w, branch; float mean;
     int chain;       // f32 output only: 1 = write it in chain order (its consumer is a small exact-f32 kernel, pnn_gemm_f32_small.hip)
+    int mfma;        // f32 output only: 1 = the taps' chain on the f32 matrix instruction instead of the VALU (same bits; set by the launcher)
 };
 hipError_t launch_conv_cin1(const Conv1Params& p, hipStream_t s);
 hipError_t launch_conv_cin1_pair(const Conv1Params& a, const Conv1Params& b, hipStream_t s);   // both branches in one launch (same batch, same kernel size)

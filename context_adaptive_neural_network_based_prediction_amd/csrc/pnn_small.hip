@@ -21,17 +21,11 @@ namespace pnn {
 // arithmetic): the contraction over the taps runs on the matrix cores, see FirstConv.  HBM-bound on the output write.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) Conv1Params CConv1;   // read in place in the kernel-argument segment: scalar loads
-template <int K>
-__device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const int by)
+// Stages rows [oy0 * s - pad, ... + PH) of block b's zero-padded input plane (PH x PW floats) in LDS; returns whether a value would leave
+// the f16 range (split path: leaves_f16, pnn_device_common.h).
+__device__ __forceinline__ bool conv_cin1_stage(CConv1& p, const long b, const int oy0, const int PH, const int PW, float* xs)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    // blockIdx.y = band of p.band_rows output rows (small batches: one image is spread over several workgroups; a
-    // single workgroup per image took 72 us for a 64x192 portion at batch 1)
-    const int oy0 = by * p.band_rows;
-    const int oy1 = oy0 + p.band_rows < p.OH ? oy0 + p.band_rows : p.OH;
-    const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
-    const long b = bx;
-    bool in_bad = false;                              // split path: an input element outside the f16 range (leaves_f16, pnn_device_common.h)
+    bool in_bad = false;
     if (!p.X) {
         // the gather fused in: straight from the picture plane through this block's TB descriptor
         const TbDev d = p.tbs[b];
@@ -56,15 +50,29 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
             xs[idx] = v;
         }
     } else {
-    const float* xb = p.X + b * p.IH * p.IW;
-    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
-        const int r = idx / PW, c = idx - r * PW;
-        const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
-        const float v = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
-        in_bad |= leaves_f16(v);
-        xs[idx] = v;
+        const float* xb = p.X + b * p.IH * p.IW;
+        for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+            const int r = idx / PW, c = idx - r * PW;
+            const int iy = oy0 * p.s + r - p.pad, ix = c - p.pad;
+            const float v = ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) ? xb[iy * p.IW + ix] : 0.f;
+            in_bad |= leaves_f16(v);
+            xs[idx] = v;
+        }
     }
-    }
+    return in_bad;
+}
+
+template <int K>
+__device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const int by)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    // blockIdx.y = band of p.band_rows output rows (small batches: one image is spread over several workgroups; a
+    // single workgroup per image took 72 us for a 64x192 portion at batch 1)
+    const int oy0 = by * p.band_rows;
+    const int oy1 = oy0 + p.band_rows < p.OH ? oy0 + p.band_rows : p.OH;
+    const int PH = (oy1 - oy0 - 1) * p.s + K, PW = (p.OW - 1) * p.s + K;
+    const long b = bx;
+    const bool in_bad = conv_cin1_stage(p, b, oy0, PH, PW, xs);
     if (p.split && in_bad && p.range_flag) *p.range_flag = 1;
     const int npix = p.OH * p.OW;
     if (p.split) {
@@ -123,13 +131,81 @@ __device__ __forceinline__ void conv_cin1_body(CConv1& p, const int bx, const in
         report_range(p.range_flag, amax);
         return;
     }
+    // Exact f32 (round 6): the contraction over the taps on the f32 matrix instruction.  Per output it is the SAME chain as the VALU
+    // form this replaces -- acc = bias; acc = fma(x[tap], w[tap], acc) for tap = 0 .. K^2 - 1 in (ky, kx) order: the matrix instruction's
+    // addend is the bias, its k-steps are the taps in ascending order (step i: tap 2i from lane half 0, then 2i + 1 from half 1; the odd
+    // one out multiplies a zero weight: fma(x, 0, acc) = acc) -- at 256 instead of 64 multiply-adds per cycle and CU (packed-fp32 VALU
+    // code is not built here: Makefile).  Same bits (tools/lib_ab_bits.py), so the launcher picks: this form for small passes, where
+    // one workgroup's arithmetic is on the call's critical path (single-block calls of the 16x16 / 32x32 / 64x64 nets: -2 us each); at
+    // the bench batches the layer is bound by its output write and this form is 0-1 % SLOWER (profiles/r06_cin1_mfma.txt).  A wave
+    // takes 32 consecutive pixels of the band at a time and leaves them through a wave-private LDS tile as ONE contiguous run (the
+    // accumulator layout owns 16-byte fragments of 32 different pixels).
+    __syncthreads();
+    if (p.mfma) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+        constexpr int NK = (K * K + 1) / 2;
+        const int cq = p.Cout >> 2, PITCH = cq + 1, nct = p.Cout >> 5;
+        f32x4* stage = reinterpret_cast<f32x4*>(xs + ((PH * PW + 3) & ~3)) + wave * 32 * PITCH;
+        float wv[2][NK];
+        int off[NK];
+#pragma unroll
+        for (int i = 0; i < NK; i++) {
+            const int t = 2 * i + h;
+            off[i] = t < K * K ? (t / K) * PW + t % K : 0;
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) wv[ct][i] = (t < K * K && ct < nct) ? p.W[(size_t)t * p.Cout + ct * 32 + l31] : 0.f;
+        }
+        f32x16 bacc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (ct < nct ? ct * 32 + 8 * g + 4 * h : 0));
+                bacc[ct][4 * g] = bv[0]; bacc[ct][4 * g + 1] = bv[1]; bacc[ct][4 * g + 2] = bv[2]; bacc[ct][4 * g + 3] = bv[3];
+            }
+        const int band_pix = (oy1 - oy0) * p.OW;
+        f32x4* yo = reinterpret_cast<f32x4*>(p.Y) + ((size_t)b * npix + (size_t)oy0 * p.OW) * cq;
+        const bool chain = p.chain != 0;
+        for (int rt = wave; rt * 32 < band_pix; rt += 4) {
+            const int lp = rt * 32 + l31;
+            const bool valid = lp < band_pix;
+            const int ly = valid ? lp / p.OW : 0, lx = valid ? lp - ly * p.OW : 0;
+            const float* xr = xs + (ly * p.s) * PW + lx * p.s;       // (an idle row reads pixel 0: its outputs are not stored)
+            float xv[NK];
+#pragma unroll
+            for (int i = 0; i < NK; i++) xv[i] = xr[off[i]];
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                if (ct >= nct) break;
+                f32x16 acc = bacc[ct];
+#pragma unroll
+                for (int i = 0; i < NK; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ct][i], xv[i], acc, 0, 0, 0);
+                // lane (pixel l31, half h): register 4g + r = channel 32 ct + 8g + 4h + r
+                float* row = reinterpret_cast<float*>(stage + l31 * PITCH);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]);
+                    const int c0 = ct * 32 + 8 * g + 4 * h;
+                    store4_chain(row + (c0 & ~15), (c0 & 15) >> 2, v, chain);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();             // the tile is this wave's own: LDS keeps a wave's accesses in order
+            const int rows = band_pix - rt * 32 < 32 ? band_pix - rt * 32 : 32;
+            for (int i = lane; i < rows * cq; i += 64) {
+                const int row = i / cq, q = i - row * cq;
+                yo[(size_t)(rt * 32) * cq + i] = stage[row * PITCH + q];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     const int CG = p.Cout >> 2;                       // lanes per pixel (8 or 16)
     const int cg = threadIdx.x % CG, psub = threadIdx.x / CG, ppi = 256 / CG;
     f32x4 w[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; t++) w[t] = *reinterpret_cast<const f32x4*>(p.W + (size_t)t * p.Cout + 4 * cg);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cg);
-    __syncthreads();
     float* yb = p.Y + b * npix * p.Cout;
     for (int pix = oy0 * p.OW + psub; pix < oy1 * p.OW; pix += ppi) {
         const int oy = pix / p.OW, ox = pix - oy * p.OW;
@@ -175,11 +251,12 @@ static bool conv_cin1_bands(const Conv1Params& p, Conv1Params* q, int* bands_out
     *bands_out = (p.OH + q->band_rows - 1) / q->band_rows;
     // staged plane (+ the split path's four wave-private output tiles of 32 pixels x (Cout / 4 + 1) 16-byte slots)
     auto lds_of = [&](int rows) {
-        return ((size_t)((rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) + 3) / 4 * 16 + (p.split ? (size_t)4 * 32 * (p.Cout / 4 + 1) * 16 : 0);
+        return ((size_t)((rows - 1) * p.s + p.k) * ((p.OW - 1) * p.s + p.k) + 3) / 4 * 16 + (size_t)4 * 32 * (p.Cout / 4 + 1) * 16;
     };
     while (lds_of(q->band_rows) > 64 * 1024 && q->band_rows > 1) q->band_rows = (q->band_rows + 1) / 2;
     *bands_out = (p.OH + q->band_rows - 1) / q->band_rows;
     *lds_out = lds_of(q->band_rows);
+    q->mfma = !p.split && p.B < 256;                  // f32 output: the matrix-instruction form of the same chain for small passes (conv_cin1_body)
     return *lds_out <= 64 * 1024 && (p.Cout == 32 || p.Cout == 64) && (p.k == 3 || p.k == 5) && (!p.split || p.Wsp);
 }
 
