@@ -199,7 +199,8 @@ def predict_by_batch_via_pnn(tuple_batches_float32, sess, predictor, batch_size)
     # The reference runs its nb_batches batches strictly one after the other (batching.py:64-86).  Here they are ONE call of the C ABI
     # whose slices are those batches ("host_slice" = batch_size): batch i + 1 is copied in and batch i - 1 copied out while batch i
     # computes (host_predict_sliced, csrc/pnn_abi.cpp) -- the same predictions bit for bit, a block's result does not depend on its batch.
-    if nb_batches >= 2 and not predictor._is_torch(tuple_batches_float32[0]):
+    sliced = nb_batches >= 2 and hasattr(predictor, "set_option") and hasattr(predictor, "_is_torch")   # (any object with predict() may stand in for the predictor)
+    if sliced and not predictor._is_torch(tuple_batches_float32[0]):
         predictor.set_option("host_slice", batch_size)
         try:
             return predictor.predict(*tuple_batches_float32[:1 if predictor.is_fully_connected else 2])
