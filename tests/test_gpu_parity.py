@@ -475,6 +475,48 @@ def test_host_calls_of_several_slices_overlap_and_keep_the_bits(pnn, precision, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,is_fc,slice_blocks,n", [(8, True, 256, 1100), (16, False, 64, 300)])
+def test_sliced_host_call_edge_cases(pnn, precision, w, is_fc, slice_blocks, n):
+    """The sliced host call's own corners: a non-finite value in a LATE slice (found by the feeder thread while earlier slices already
+    run) fails the call like the one-pass form does and leaves the context usable; in the split mode a block that leaves the f16 range
+    in a middle slice sends the call through the exact-f32 kernels -- the result of the unsliced call, bit for bit."""
+    from context_adaptive_neural_network_based_prediction_amd import _lib
+    params = util.make_params(w, is_fc, 611, out_gain=util.out_gain(w, is_fc)).copy()
+    above, left = util.make_contexts(w, n, 612, masked_fraction=0.0)
+    pack = lambda a, l: (util.flatten_fc(a, l),) if is_fc else (a, l)
+    net = pnn.PredictionNeuralNetwork(slice_blocks, w, is_fc, params=params)
+    net.set_option("host_slice", slice_blocks)
+    want = net.predict(*pack(above, left))
+    bad = above.copy()
+    bad[n - 5].reshape(-1)[3] = np.nan                                  # last slice
+    with pytest.raises(_lib.PnnError, match="non-finite"):
+        net.predict(*pack(bad, left))
+    assert np.array_equal(net.predict(*pack(above, left)), want)        # nothing of the failed call is left behind
+    net.close()
+    if precision != "split_f16":
+        return
+    specs = wts.tensor_specs(w, is_fc)
+    offs = np.concatenate([[0], np.cumsum([int(np.prod(sh)) for _, sh, _ in specs])])
+    gain = 300.0 if is_fc else 1000.0                                   # as in test_range_fallback_touches_only_the_overflowing_block
+    params[offs[0]:offs[2]] *= gain
+    params[offs[-3]:offs[-2]] /= gain
+    hot = 2 * slice_blocks + 7                                          # a block of the third slice
+    above[hot] *= 40.0
+    left[hot] *= 40.0
+    net = pnn.PredictionNeuralNetwork(slice_blocks, w, is_fc, params=params)
+    net.set_option("host_slice", -1)
+    one_pass = net.predict(*pack(above, left))
+    net.set_option("host_slice", slice_blocks)
+    got = net.predict(*pack(above, left))
+    assert np.isfinite(got).all()
+    # both forms repeat a call of more than 256 blocks WHOLE on the exact-f32 kernels when one block overflowed (pnn_abi.cpp): same bits
+    assert np.array_equal(got, one_pass)
+    fb = ctypes.c_long()
+    assert _lib.lib().pnn_check_range(net.ctx, None, ctypes.byref(fb)) == 0 and fb.value >= 1
+    net.close()
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_through_rccl(precision):
     """`python bench.py --gpus 1 --force-dist nccl` (VERDICT r5 #8a): the RCCL branch of the N > 1 path executed on the hardware that is
     there -- a ONE-rank group on the real device; the opening barrier and the max-over-ranks clock of every timed region, the device
