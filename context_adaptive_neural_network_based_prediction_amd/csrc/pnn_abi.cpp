@@ -270,6 +270,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
     if (const char* e = getenv("PNN_GRAPHS")) c->opt_graphs = atol(e);
     if (const char* e = getenv("PNN_F32_SMALL_DEEP")) c->opt_f32_small_deep = atol(e);
     if (const char* e = getenv("PNN_CHAIN_IO")) c->opt_chain_io = atol(e);
+    if (const char* e = getenv("PNN_TAILS")) c->opt_tails = atol(e);
     if (hipHostMalloc((void**)&c->h_range, (pnn_ctx::kDoneFlag0 + pnn_ctx::kDoneFlagsMax) * 4, hipHostMallocDefault) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipHostMalloc of the range flag failed");
@@ -280,7 +281,7 @@ int pnn_create_empty(pnn_ctx** out, float mean, int device)
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the completion counter failed");
     }
-    if (hipMalloc((void**)&c->d_seg_cnt, 2 * pnn_ctx::kSegCntTiles * 4) != hipSuccess || hipMemset(c->d_seg_cnt, 0, 2 * pnn_ctx::kSegCntTiles * 4) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_seg_cnt, pnn_ctx::kCntWords * 4) != hipSuccess || hipMemset(c->d_seg_cnt, 0, pnn_ctx::kCntWords * 4) != hipSuccess) {
         pnn_destroy(c);
         return fail(nullptr, PNN_E_NOMEM, "hipMalloc of the K-segment counters failed");
     }
@@ -480,6 +481,7 @@ int pnn_set_option(pnn_ctx* c, const char* name, long value)
     else if (!strcmp(name, "fc_out_f32")) c->opt_fc_out_f32 = value;
     else if (!strcmp(name, "host_slice")) c->opt_host_slice = value;
     else if (!strcmp(name, "chain_io")) c->opt_chain_io = value;
+    else if (!strcmp(name, "tails")) c->opt_tails = value;
     else if (!strcmp(name, "seg_fold")) c->opt_seg_fold = value;
     else if (!strcmp(name, "f32_small_deep")) c->opt_f32_small_deep = value;
     else if (!strcmp(name, "f32_small_max_tiles")) c->opt_f32_small_tiles = value;

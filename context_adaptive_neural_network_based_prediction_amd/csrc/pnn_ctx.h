@@ -160,6 +160,11 @@ struct pnn_ctx {
     // capture) they may not be -- and every later folded launch would wait for an arrival count it never sees.  Zeroed again before the next one.
     bool seg_cnt_dirty = false;
     static constexpr int kSegCntTiles = 2048;
+    // ... followed by the arrival counters of the small launches' TAILS (SmallTail, pnn_kernels.h): one per tail instance of a launch
+    static constexpr int kTailCnt = 2048, kCntWords = 2 * kSegCntTiles + kTailCnt;
+    // 1: in small exact-f32 conv passes the merger runs as the tail of the branches' last pair launch and the last transposed convolution
+    // as the tail of the GEMM in front of it (two launches less per call); 0: every layer its own launch
+    long opt_tails = 1;
     // 1: tensors between two launches of the small exact-f32 kernels travel in chain order (pnn_gemm_f32_small.hip, XCH: one 16-byte
     // LDS-DMA instruction per chunk of activations instead of four 4-byte ones); 0: channel order everywhere.  Same bits.
     long opt_chain_io = 1;

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "pnn_device_common.h"
+#include "pnn_small_bodies.h"
 
 namespace pnn {
 
@@ -73,7 +74,9 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 // (ablation build) a single 16x16 block took 73.7 us instead of 86.9 (profiles/r06_b1_chain_order.txt).  The PRODUCER of such a tensor
 // is the epilogue below (p.chain_io bit 1: two 8-byte stores per lane instead of one 16-byte); the pass decides which tensors travel
 // that way (both ends on these kernels: pnn_passes.cpp).  Same values in another place: not a bit of any sum changes.
-template <bool INL, int LA, bool XCH = false>
+// WT (round 6): the tile is written THROUGH to memory (store16_through) -- its reader is a tail of this same launch, on another XCD
+// whose L2 does not see this one's (small_tail_* below); channel order, no K segments.
+template <bool INL, int LA, bool XCH = false, bool WT = false>
 __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz, const int gy)
 {
     static_assert(!(INL && XCH), "the argument-block input is the caller's raw context");
@@ -312,7 +315,8 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-    if (Yo) store4_chain(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
+    if (WT) store16_through(reinterpret_cast<f32x4*>(Yo + obase + n), v);
+    else if (Yo) store4_chain(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     F32S_DIAG_EXIT();
 }
@@ -356,6 +360,79 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_pair_kernel(const F32Sm
     const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
     const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
     tapgemm_f32_small_body<false, LA, XCH>(*p, r % gx, r / gx, bz, gy);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// TAILS (round 6): the small layer BEHIND a GEMM layer of a small conv pass inside that layer's launch.  A single-block call of the
+// 16x16 net is nine launches, and the device-side stamps price a kernel boundary at 1.4-2.0 us from the last exit to the next entry plus
+// 1.1-1.4 us until the first MFMA (profiles/r06_b1_stamps.txt) -- more than the merger (8 active workgroups) or the last transposed
+// convolution (one workgroup per block) take themselves.  So the workgroups of the layer in front write their tiles through to memory,
+// count themselves on a counter per tail instance (memory-side atomics), and the LAST one to arrive for an instance runs it: no
+// workgroup ever waits for another (nothing to dead-lock behind other contexts' kernels), the instance starts the moment its inputs are
+// complete instead of one launch later.  Kind 1 (pair launch of the branches' last layers): the merger's tile (block b, channels 16 by ..)
+// needs the 3 + 2 tiles (b, by) of the two branch maps -- 5 arrivals; kind 2 (the last GEMM of the transposed stack): the last layer of
+// block b needs all (pixels per block / 16) x (Cout / 16) tiles of it.  The bodies are those of merger_mfma_kernel and
+// tconv_cout1_mfma_kernel (pnn_small_bodies.h): the same bits as the separate launches (tests/test_gpu_parity.py).
+struct F32SmallTailArgs { TapGemmParams p; SmallTail t; };
+struct F32SmallTail2Args { TapGemmParams a, b; int na; SmallTail t; };
+typedef const __attribute__((address_space(4))) SmallTail CSmallTail;
+
+// every wave of the workgroup calls this behind tapgemm_f32_small_body; true in ALL its waves of the one workgroup that completes `group`
+__device__ __forceinline__ bool small_tail_arrive(unsigned* cnt, const unsigned expected, unsigned* lds_word)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the chain wave's write-through stores are acknowledged (the loaders have none in flight)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == expected - 1u) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        *lds_word = old == expected - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *lds_word != 0u;
+    __syncthreads();                                 // (the word is part of the LDS the tail is about to use)
+    return last;
+}
+
+template <int LA, bool XCH>
+__global__ __launch_bounds__(256) void tapgemm_f32_small_tail_kernel(const F32SmallTailArgs args)
+{
+    touch_kernargs<sizeof(F32SmallTailArgs)>();
+    const auto* k = (const __attribute__((address_space(4))) F32SmallTailArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
+    tapgemm_f32_small_body<false, LA, XCH, true>(k->p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+    // kind 2: the last transposed convolution of the block this tile belongs to
+    const int SP = k->p.SH * k->p.SW;
+    const long b = ((long)blockIdx.x * 16) / SP;
+    if (!small_tail_arrive(k->t.cnt + b, (unsigned)(SP >> 4) * gridDim.y, reinterpret_cast<unsigned*>(ring))) return;
+    const TConv1Params& tp = args.t.t;
+    tconv_cout1_mfma_band<2, 5, true>(tp, reinterpret_cast<float*>(ring), b, 0);
+    if (tp.done.host_flag) {                         // one flag word per block (DoneSignal::per_wg)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(tp.done.host_flag + b, tp.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int LA, bool XCH>
+__global__ __launch_bounds__(256) void tapgemm_f32_small_pair_tail_kernel(const F32SmallTail2Args args)
+{
+    touch_kernargs<sizeof(F32SmallTail2Args)>();
+    const auto* k = (const __attribute__((address_space(4))) F32SmallTail2Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
+    const int na = k->na;
+    const bool second = (int)blockIdx.x >= na;
+    CF32SmallParams* p = second ? &k->b : &k->a;
+    const int wg = second ? (int)blockIdx.x - na : (int)blockIdx.x;
+    const int gx = (p->M + 15) >> 4, gy = (p->Cout + 15) >> 4;
+    const int bz = wg / (gx * gy), r = wg - bz * gx * gy;
+    const int bx = r % gx, by = r / gx;
+    tapgemm_f32_small_body<false, LA, XCH, true>(*p, bx, by, bz, gy);
+    // kind 1: the merger's tile (block b, channel group by)
+    const int SP = p->SH * p->SW;
+    const long b = ((long)bx * 16) / SP;
+    const MergerParams& mp = args.t.m;
+    if (!small_tail_arrive(k->t.cnt + b * gy + by, (unsigned)((mp.na + mp.nl) >> 4), reinterpret_cast<unsigned*>(ring))) return;
+    merger_mfma_tile<false, true>(mp, reinterpret_cast<f32x4 (*)[16][64]>(ring), by * 16, b);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -767,6 +844,79 @@ hipError_t launch_tapgemm_f32_small(const TapGemmParams& p, hipStream_t s, const
     else if (deep) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLADeep, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
     else if (xch) pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
     else pnn_launch(tapgemm_f32_small_kernel<kF32SmallLA, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
+    return hipGetLastError();
+}
+
+// May the layer run with a tail?  Whole 16-row tiles per block, one class, no K segments, channel-order output, Cout in whole tiles.
+static bool f32_small_tail_layer_ok(const TapGemmParams& p)
+{
+    const int SP = p.SH * p.SW;
+    return SP >= 16 && SP % 16 == 0 && p.ncls == 1 && p.nseg <= 1 && !(p.chain_io & 2) && p.Cout % 16 == 0 && p.Y && !p.Yi && p.M % SP == 0;
+}
+static hipError_t f32_small_tail_attrs()
+{
+    static int done[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const int di = dev >= 0 && dev < 16 ? dev : 0;
+    if (__atomic_load_n(&done[di], __ATOMIC_ACQUIRE)) return hipSuccess;
+    const void* fns[8] = {reinterpret_cast<const void*>(&tapgemm_f32_small_tail_kernel<kF32SmallLA, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_tail_kernel<kF32SmallLA, true>),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_tail_kernel<kF32SmallLA, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_tail_kernel<kF32SmallLA, true>),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_tail_kernel<kF32SmallLADeep, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_tail_kernel<kF32SmallLADeep, true>),
+                          reinterpret_cast<const void*>(&tapgemm_f32_small_pair_tail_kernel<kF32SmallLADeep, false>), reinterpret_cast<const void*>(&tapgemm_f32_small_pair_tail_kernel<kF32SmallLADeep, true>)};
+    for (int i = 0; i < 8; i++)
+        if ((e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapgemm_f32_small_lds_bytes(i >= 4))) != hipSuccess) return e;
+    __atomic_store_n(&done[di], 1, __ATOMIC_RELEASE);
+    return hipSuccess;
+}
+
+// The last GEMM of the transposed stack + the net's last layer per block (SmallTail kind 2).  hipErrorInvalidValue: not this shape.
+bool f32_small_cout1_tail_ok(const TapGemmParams& p, const TConv1Params& t)
+{
+    if (!f32_small_tail_layer_ok(p) || p.Cout != 64 || t.Cin != 64 || t.s != 2 || t.k != 5 || t.pad > t.k - 1) return false;
+    if (t.IH != p.OH || t.IW != p.OW || p.os != 1 || t.B * p.SH * p.SW != p.M) return false;   // the GEMM's output map is the last layer's input
+    const int npx = t.IH * t.IW;                      // one band: the whole input map in T
+    return (size_t)((npx + 31) / 32) * 32 * kTcTP * sizeof(float) <= tapgemm_f32_small_lds_bytes(false);
+}
+hipError_t launch_tapgemm_f32_small_tail(const TapGemmParams& p, const SmallTail& t, hipStream_t s, int deep_mode)
+{
+    hipError_t e = f32_small_tail_attrs();
+    if (e != hipSuccess) return e;
+    if (t.kind != 2 || !t.cnt || !f32_small_cout1_tail_ok(p, t.t) || (t.t.done.host_flag && !t.t.done.per_wg)) return hipErrorInvalidValue;
+    F32SmallTailArgs a;
+    a.p = p; a.t = t;
+    a.t.t.ni = t.t.IH * t.t.s;                        // one band of all output rows
+    const dim3 grid((p.M + 15) / 16, (p.Cout + 15) / 16, 1);
+    const bool deep = f32_small_deep(tapgemm_f32_small_tiles(p), deep_mode, false), xch = (p.chain_io & 1) != 0;
+    if (deep && xch) pnn_launch(tapgemm_f32_small_tail_kernel<kF32SmallLADeep, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+    else if (deep) pnn_launch(tapgemm_f32_small_tail_kernel<kF32SmallLADeep, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);
+    else if (xch) pnn_launch(tapgemm_f32_small_tail_kernel<kF32SmallLA, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
+    else pnn_launch(tapgemm_f32_small_tail_kernel<kF32SmallLA, false>, grid, dim3(256), tapgemm_f32_small_lds_bytes(false), s, a);
+    return hipGetLastError();
+}
+
+// The branches' last layers + the merger per (block, channel group) (SmallTail kind 1).
+bool f32_small_merger_tail_ok(const TapGemmParams& a, const TapGemmParams& b, const MergerParams& m)
+{
+    if (!f32_small_tail_layer_ok(a) || !f32_small_tail_layer_ok(b) || a.Cout != b.Cout || a.Cout != m.C || m.split || m.nout != 16) return false;
+    if (a.SH * a.SW != m.na || b.SH * b.SW != m.nl || m.na + m.nl != 80 || a.os != 1 || b.os != 1) return false;
+    return a.M == m.B * m.na && b.M == m.B * m.nl && sizeof(f32x4) * 3 * 16 * 64 <= tapgemm_f32_small_lds_bytes(false);
+}
+hipError_t launch_tapgemm_f32_small_pair_tail(const TapGemmParams& a, const TapGemmParams& b, const SmallTail& t, hipStream_t s, int deep_mode)
+{
+    hipError_t e = f32_small_tail_attrs();
+    if (e != hipSuccess) return e;
+    if (t.kind != 1 || !t.cnt || !f32_small_merger_tail_ok(a, b, t.m) || (a.chain_io & 1) != (b.chain_io & 1)) return hipErrorInvalidValue;
+    F32SmallTail2Args args;
+    args.a = a; args.b = b; args.t = t;
+    args.na = (int)tapgemm_f32_small_tiles(a);
+    const long total = args.na + tapgemm_f32_small_tiles(b);
+    const bool xch = (a.chain_io & 1) != 0, deep = f32_small_deep(total, deep_mode, false);
+    if (deep && xch) pnn_launch(tapgemm_f32_small_pair_tail_kernel<kF32SmallLADeep, true>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
+    else if (deep) pnn_launch(tapgemm_f32_small_pair_tail_kernel<kF32SmallLADeep, false>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(true), s, args);
+    else if (xch) pnn_launch(tapgemm_f32_small_pair_tail_kernel<kF32SmallLA, true>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
+    else pnn_launch(tapgemm_f32_small_pair_tail_kernel<kF32SmallLA, false>, dim3((unsigned)total), dim3(256), tapgemm_f32_small_lds_bytes(false), s, args);
     return hipGetLastError();
 }
 

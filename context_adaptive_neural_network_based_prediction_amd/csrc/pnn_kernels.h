@@ -228,6 +228,16 @@ struct MergerParams {
 };
 hipError_t launch_merger(const MergerParams& p, hipStream_t s);
 
+// A small layer run as the TAIL of the small exact-f32 GEMM launch in front of it (pnn_gemm_f32_small.hip, round 6): kind 1 = the
+// merger per (block, channel group) behind the pair launch of the branches' last layers, kind 2 = the last transposed convolution
+// (with the HM epilogue and one completion flag per block, DoneSignal::per_wg) per block behind the last GEMM of the transposed
+// stack.  cnt: one zeroed counter per instance (kind 1: blocks x C / 16, kind 2: blocks); the launch leaves them zero.
+struct SmallTail { int kind; unsigned* cnt; MergerParams m; TConv1Params t; };
+bool f32_small_cout1_tail_ok(const TapGemmParams& p, const TConv1Params& t);
+bool f32_small_merger_tail_ok(const TapGemmParams& a, const TapGemmParams& b, const MergerParams& m);
+hipError_t launch_tapgemm_f32_small_tail(const TapGemmParams& p, const SmallTail& t, hipStream_t s, int deep_mode = 1);
+hipError_t launch_tapgemm_f32_small_pair_tail(const TapGemmParams& a, const TapGemmParams& b, const SmallTail& t, hipStream_t s, int deep_mode = 1);
+
 // L-shaped context gather (extraction_context.cpp:3-208) over a descriptor array.
 struct TbDev {           // mirrors pnn_tb_dev of include/pnn_hip.h
     int64_t origin;      // element index of the TB's top-left pixel from the plane base

@@ -60,7 +60,8 @@ bool f32_small_chain_out_ok(const pnn_ctx* c, const GemmLayer& L, long nb)
 // chain_io: bit 0 = X is in chain order, bit 1 = write Y in chain order (TapGemmParams::chain_io) -- only for a layer that
 // f32_small_applies() sends to the small kernels; anything else is the caller's mistake and refused.
 int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* Yi, long nblocks, hipStream_t s,
-             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr, const float* host_rows = nullptr, int chain_io = 0)
+             const GemmLayer* next = nullptr, float* part = nullptr, int* tiles_out = nullptr, const float* host_rows = nullptr, int chain_io = 0,
+             const SmallTail* tail = nullptr, bool* tail_ran = nullptr)
 {
     TapGemmParams p = L.proto;
     p.X = X; p.Wp = L.d_w; p.bias = L.d_bias; p.Y = Y; p.Yi = Yi; p.mean = c->mean;
@@ -150,7 +151,7 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
         const bool fold = nseg > 1 && c->opt_seg_fold && c->d_seg_cnt && seg_tiles <= pnn_ctx::kSegCntTiles && !c->opt_time_launches;
         if (fold) {
             if (c->seg_cnt_dirty) {                   // see pnn_ctx::seg_cnt_dirty
-                HIPCHK(c, hipMemsetAsync(c->d_seg_cnt, 0, 2 * pnn_ctx::kSegCntTiles * 4, s));
+                HIPCHK(c, hipMemsetAsync(c->d_seg_cnt, 0, pnn_ctx::kCntWords * 4, s));
                 if (c->side_stream && s != c->side_stream) HIPCHK(c, hipStreamSynchronize(s));   // (the other branch's launches use the second half on the side stream)
                 c->seg_cnt_dirty = false;
             }
@@ -183,6 +184,11 @@ int run_gemm(pnn_ctx* c, const GemmLayer& L, const float* X, float* Y, int32_t* 
             } else {
                 c->launch_recs.push_back(r);
             }
+        } else if (tail && tail_ran && nseg == 1 && !(chain_io & 2) && f32_small_cout1_tail_ok(ps, tail->t)) {
+            // the net's last layer as this launch's tail (SmallTail kind 2): per block, by the last of the block's tiles to arrive
+            if (debug) fprintf(stderr, "[pnn]   ... with the last transposed convolution as its tail\n");
+            HIPCHK(c, launch_tapgemm_f32_small_tail(ps, *tail, s, (int)c->opt_f32_small_deep));
+            *tail_ran = true;
         } else {
             HIPCHK(c, launch_tapgemm_f32_small(ps, s, host_rows, (int)c->opt_f32_small_deep));
         }
@@ -836,6 +842,8 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     // The same on the exact-f32 arithmetic (round 5): conv_cin1_pair_kernel with f32 output (the context gather inside when the pass
     // reads the picture plane itself), then tapgemm_f32_small_pair_kernel per layer; K-segmented layers (32x32 / 64x64 nets) leave
     // their planes and get one seg_reduce launch per branch.
+    bool merger_done = false, merger_chain_done = false;   // the merger ran as the tail of the branches' last pair launch (below)
+    int merged_in = 0;                                // ... and left the merged map in P[merged_in]
     bool pair32 = !sp && !pair && c->opt_pair && c->opt_f32_small && c->opt_f32_cfg < 0 &&
                   !c->opt_time_launches && !env_profile && !env_sdiag && m->branch[0].size() == m->branch[1].size() && !m->branch[0].empty();
     for (size_t i = 0; pair32 && i < m->branch[0].size(); i++) {
@@ -906,6 +914,26 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             }
             static const bool dbg = getenv("PNN_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[pnn] f32 gemm pair: branch layer %zu, M = %d / %d -> one f32 small-kernel launch\n", i + 1, q[0].M, q[1].M);
+            // the merger as the tail of the branches' LAST pair launch (SmallTail kind 1): per (block, channel group), by the last of its
+            // five tiles to arrive -- where the launch is at most one workgroup per CU (the tail kernel's registers allow one)
+            bool mtail = false;
+            SmallTail mt;
+            if (last && c->opt_tails && c->d_seg_cnt && nb * (m->C / 16) <= pnn_ctx::kTailCnt &&
+                tapgemm_f32_small_tiles(q[0]) + tapgemm_f32_small_tiles(q[1]) <= (long)device_info().cus) {
+                mt.kind = 1; mt.cnt = c->d_seg_cnt + 2 * pnn_ctx::kSegCntTiles;
+                mt.m = m->merger.proto;
+                mt.m.A = F[0]; mt.m.L = F[1]; mt.m.Wp = m->merger.d_w; mt.m.bias = m->merger.d_bias; mt.m.Y = P[cur ^ 1]; mt.m.B = (int)nb;   // (P[cur] is what this launch's above branch still reads)
+                mt.m.split = 0; mt.m.range_flag = c->h_range;
+                mt.m.chain = (m->tconv.size() > 0 && c->opt_chain_io && mt.m.C % 16 == 0 && f32_small_applies(c, m->tconv[0], nb, false, false)) ? 1 : 0;
+                mt.t = TConv1Params{};
+                mtail = f32_small_merger_tail_ok(q[0], q[1], mt.m);
+            }
+            if (mtail) {
+                if (c->seg_cnt_dirty) { HIPCHK(c, hipMemsetAsync(c->d_seg_cnt, 0, pnn_ctx::kCntWords * 4, s)); c->seg_cnt_dirty = false; }
+                if (dbg) fprintf(stderr, "[pnn]   ... with the merger as its tail\n");
+                HIPCHK(c, launch_tapgemm_f32_small_pair_tail(q[0], q[1], mt, s, (int)c->opt_f32_small_deep));
+                merger_done = true; merger_chain_done = mt.m.chain != 0; merged_in = cur ^ 1;
+            } else
             HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s, (int)c->opt_f32_small_deep));
             c->stat_gemm_launches++; c->stat_launches++;
             for (int br = 0; br < 2; br++) {
@@ -973,12 +1001,31 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
     // exact f32, small passes: the merged map in chain order when the first transposed convolution runs on the small kernels
     const bool merger_chain = !sp && nt > 0 && c->opt_chain_io && mp.C % 16 == 0 && f32_small_applies(c, m->tconv[0], nb, false, false);
     mp.chain = merger_chain ? 1 : 0;
-    HIPCHK(c, launch_merger(mp, s));
-    c->stat_launches++;
-    int cur = 0;
+    if (merger_done && merger_chain_done != merger_chain) return fail(c, PNN_E_ARG, "internal: the merger's tail and its consumer disagree on the tensor's order");
+    if (!merger_done) {
+        HIPCHK(c, launch_merger(mp, s));
+        c->stat_launches++;
+    }
+    int cur = merger_done ? merged_in : 0;
     TConv1Params tp = m->last.proto;
     tp.W = m->last.d_w; tp.Y = d_out; tp.Yi = d_dst; tp.B = (int)nb; tp.mean = c->mean;
-    tp.done = take_done_signal(c);
+    // the last layer as the tail of the last GEMM of the transposed stack (SmallTail kind 2; run_gemm takes it where that GEMM runs on
+    // the small kernels and the shapes fit): one completion flag per block instead of the counter form
+    const bool want_ctail = !sp && nt > 0 && c->opt_tails && c->d_seg_cnt && nb <= pnn_ctx::kTailCnt && nb <= 64 && !c->opt_time_launches && !env_profile && !env_sdiag &&
+                            f32_small_applies(c, m->tconv[nt - 1], nb, false, false);
+    SmallTail ct;
+    if (want_ctail) {
+        if (c->seg_cnt_dirty) { HIPCHK(c, hipMemsetAsync(c->d_seg_cnt, 0, pnn_ctx::kCntWords * 4, s)); c->seg_cnt_dirty = false; }
+        TapGemmParams probe = m->tconv[nt - 1].proto;
+        probe.M = (int)(nb * probe.SH * probe.SW); probe.Y = P[0]; probe.Yi = nullptr; probe.nseg = m->tconv[nt - 1].nseg; probe.chain_io = 0;
+        TConv1Params tq = tp;
+        tq.X = P[0];
+        if (!f32_small_cout1_tail_ok(probe, tq)) { tp.done = take_done_signal(c); ct.kind = 0; }
+        else { tp.done = take_done_signal_per_wg(c, (int)nb); ct.kind = 2; }
+    } else {
+        tp.done = take_done_signal(c);
+        ct.kind = 0;
+    }
     bool last_done = false;                          // the last layer went out with (or inside) the GEMM in front of it
     bool t_in_chain = merger_chain;                  // exact f32, small passes: the transposed convolutions hand their maps on in chain order (see fc_pass)
     for (size_t i = 0; i < nt; i++) {
@@ -990,6 +1037,14 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
             rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, P[cur ^ 1], nullptr, nullptr, nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, false, 0, nullptr, &tp);
             last_done = true;
         } else if (sp) rc = run_gemm_sp(c, m->tconv[i], P[cur], nullptr, nullptr, P[cur ^ 1], nullptr, nullptr, nb, s);
+        else if (last && ct.kind == 2) {
+            ct.cnt = c->d_seg_cnt + 2 * pnn_ctx::kSegCntTiles;
+            ct.m = MergerParams{};
+            ct.t = tp;
+            ct.t.X = P[cur ^ 1];
+            rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, (t_in_chain ? 1 : 0), &ct, &last_done);
+            if (!rc && !last_done) return fail(c, PNN_E_ARG, "internal: the last layer's tail was planned and not taken");
+        }
         else rc = run_gemm(c, m->tconv[i], P[cur], P[cur ^ 1], nullptr, nb, s, nullptr, nullptr, nullptr, nullptr, (t_in_chain ? 1 : 0) | (t_out_chain ? 2 : 0));
         if (rc) return rc;
         t_in_chain = t_out_chain;

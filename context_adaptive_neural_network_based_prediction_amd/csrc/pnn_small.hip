@@ -10,6 +10,7 @@
 #include "pnn_kernels.h"
 #include <time.h>
 #include "pnn_device_common.h"
+#include "pnn_small_bodies.h"
 
 namespace pnn {
 
@@ -382,77 +383,12 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
 // (1.6 KB of ds_read per output, 26 us for the 16x16 net at batch 1024); here x goes global -> registers -> MFMA once.
 // The K order inside the MFMA is a fixed permutation of the channels (lane half h, step 4q+i <-> channel 8q+4h+i), the
 // same for every batch size.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kTcTP = 33;                            // LDS pitch of a T row (32 taps + 1)
 template <int s, int K>                              // compile-time stride and kernel size: the parity tests of phase 2 fold
 __global__ __launch_bounds__(256) void tconv_cout1_mfma_kernel(const TConv1Params p)
 {
     touch_kernargs<sizeof(TConv1Params)>();
     extern __shared__ __attribute__((aligned(16))) float T[];        // [pixels of the band, padded to 32][kTcTP]
-    constexpr int KK = K * K;
-    const int OH = p.IH * s, OW = p.IW * s;
-    const int TOH = p.ni;                             // output rows per band (set by the launcher)
-    const long b = blockIdx.x;
-    const int oy0 = blockIdx.y * TOH;
-    const int lo_y = oy0 + p.pad - (K - 1);
-    int iy0 = lo_y >= 0 ? lo_y / s : -((-lo_y + s - 1) / s);
-    int iy1 = (oy0 + TOH - 1 + p.pad) / s;
-    if (iy0 < 0) iy0 = 0;
-    if (iy1 > p.IH - 1) iy1 = p.IH - 1;
-    const int npx = (iy1 - iy0 + 1) * p.IW;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int col = lane & 31, h = lane >> 5;
-    const int tiles = (npx + 31) >> 5;
-    if (wave < tiles) {
-        f32x4 wv[8];                                  // B operand: w[tap = col][channels 8q + 4h .. +3]
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            wv[q] = col < KK ? *reinterpret_cast<const f32x4*>(p.W + col * 64 + 8 * q + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* xb = p.X + ((b * p.IH + iy0) * (long)p.IW) * 64;
-        for (int t = wave; t < tiles; t += 4) {
-            int px = t * 32 + col;
-            if (px >= npx) px = npx - 1;              // padding rows of the last tile: recomputed, never read
-            const float* xr = xb + (long)px * 64 + 4 * h;
-            f32x4 xv[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) xv[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q][i], wv[q][i], acc, 0, 0, 0);
-            // acc[r]: pixel row 8 * (r / 4) + 4 * h + r % 4 of the tile, tap = col
-#pragma unroll
-            for (int r = 0; r < 16; r++) T[(t * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * kTcTP + col] = acc[r];
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < TOH * OW; idx += 256) {
-        const int oyl = idx / OW, ox = idx - oyl * OW;
-        const int oy = oy0 + oyl;
-        if (oy >= OH) break;
-        float v = 0.f;
-        // taps of this pixel's parity class: ky = ky0, ky0 + s, ... with (oy + pad - ky) % s == 0; the numerators are
-        // kept non-negative (+ s * K) so that / and % are shifts
-        const int ky0 = (oy + p.pad) % s, kx0 = (ox + p.pad) % s;
-#pragma unroll
-        for (int a = 0; a < (K + s - 1) / s; a++) {
-            const int ky = ky0 + a * s;
-            const int iy = (oy + p.pad - ky + s * K) / s - K;
-            if (ky >= K || iy < iy0 || iy > iy1) continue;   // band rows are clipped to the image: outside = zero input
-#pragma unroll
-            for (int c = 0; c < (K + s - 1) / s; c++) {
-                const int kx = kx0 + c * s;
-                const int ix = (ox + p.pad - kx + s * K) / s - K;
-                if (kx >= K || (unsigned)ix >= (unsigned)p.IW) continue;
-                v += T[((iy - iy0) * p.IW + ix) * kTcTP + ky * K + kx];
-            }
-        }
-        v += p.bias;
-        const size_t o = ((size_t)b * OH + oy) * OW + ox;
-        if (p.Y) p.Y[o] = v;
-        if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
-    }
+    tconv_cout1_mfma_band<s, K, false>(p, T, blockIdx.x, blockIdx.y);   // pnn_small_bodies.h
     signal_done(p.done);
 }
 
@@ -569,68 +505,12 @@ __global__ __launch_bounds__(256) void merger_mfma_kernel(const MergerParams p)
 {
     touch_kernargs<sizeof(MergerParams)>();
     __shared__ f32x4 red[3][16][64];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ngc = p.C >> 4;
     const long rest = blockIdx.x >> 3;
     const int c0 = (int)(rest % ngc) * 16;
     const long bg = (rest / ngc) * 8 + (blockIdx.x & 7);
     if (bg * 16 >= p.B) return;
-    const int li = lane & 15, lk = lane >> 4;
-    long brow = bg * 16 + li;
-    if (brow >= p.B) brow = p.B - 1;
-    f32x4 xv[5][4], wv[5][4];
-#pragma unroll
-    for (int t = 0; t < 5; t++) {
-        const int p0 = 4 * (wave + 4 * t);            // first position of this step (wave-uniform): above part or left part
-        const float* xr = p0 < p.na ? p.A + ((size_t)brow * p.na + p0 + lk) * p.C + c0
-                                    : p.L + ((size_t)brow * p.nl + (p0 - p.na) + lk) * p.C + c0;
-        const float* wr = p.Wp + ((size_t)(p0 + lk) * 16 + li) * p.C + c0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            xv[t][q] = *reinterpret_cast<const f32x4*>(xr + 4 * q);
-            wv[t][q] = *reinterpret_cast<const f32x4*>(wr + 4 * q);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);               // every load is in flight before the first MFMA waits
-    f32x4 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 5; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                acc[4 * q + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][q][i], wv[t][q][i], acc[4 * q + i], 0, 0, 0);
-    if (wave) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) red[wave - 1][i][lane] = acc[i];
-    }
-    __syncthreads();
-    if (wave) return;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = (acc[i] + red[0][i][lane]) + (red[1][i][lane] + red[2][i][lane]);
-    // acc[i][r]: block bg * 16 + 4 * lk + r, output j = li, channel c0 + i
-    f32x4 bv[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + (size_t)li * p.C + c0 + 4 * q);
-    float amax = 0.f;                                // range guard of the split output (pnn_device_common.h)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const long b = bg * 16 + 4 * lk + r;
-        const size_t pix = (size_t)b * 16 + li;
-        if (b < p.B) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = leaky(acc[4 * q + i][r] + bv[q][i]);
-                if (SPLIT) store_split4(p.Y, pix * p.C, c0 + 4 * q, v, amax);
-                else store4_chain(p.Y + pix * p.C + c0, q, v, p.chain != 0);
-            }
-        }
-    }
-    if (SPLIT) report_range(p.range_flag, amax);
+    merger_mfma_tile<SPLIT, false>(p, red, c0, bg * 16);               // pnn_small_bodies.h
 }
 
 hipError_t launch_merger(const MergerParams& p, hipStream_t s)

@@ -81,6 +81,9 @@ float pnn_mean(const pnn_ctx* ctx);
  *   "fc_out_f32"           1   FC passes of <= 512 blocks: output layer's K segments + their reduction in one launch
  *   "chain_io"             1   tensors between two launches of the small kernels travel with every 16-channel group in the order the 16x16x4
  *                              chain consumes it (one 16-byte LDS-DMA instruction per chunk of activations instead of four 4-byte ones); 0: never
+ *   "tails"                1   small exact-f32 conv passes: the merger runs inside the branches' last pair launch (per block and channel group, by the
+ *                              last of its five tiles to arrive) and the last transposed convolution inside the launch of the GEMM in front of it (per
+ *                              block) -- two launches less per single-block call, the same bits; 0: every layer its own launch
  *   "f32_cfg"             -1   >= 0: force tile code [0, pnn_num_f32_configs()) of tapgemm_f32_kernel on every layer it is legal for
  *   "f32_seg_mode"         0   K segments of the deep convolution layers (> 2304 per output: summed in segments of <= 1600, whole taps,
  *                              added in order): 0 separate workgroups + a reduction launch, 1 in sequence inside the workgroups, -1 by model

@@ -448,6 +448,48 @@ def test_f32_small_kernel_bit_identical(pnn, oracle, precision, w, is_fc, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_small_conv_passes_run_merger_and_last_layer_as_tails(pnn, precision, w):
+    """Small exact-f32 conv passes (round 6): the merger runs as the TAIL of the branches' last pair launch -- per (block, channel group),
+    by the last of its five tiles to arrive -- and the last transposed convolution as the tail of the GEMM in front of it, per block
+    (option "tails", pnn_gemm_f32_small.hip).  Same bodies, same bits: float and Pel predictions of 1 ... 9 blocks equal those of the
+    layer-by-layer launches and of a large batch; two launches less per call where the shapes allow it; call after call (the
+    counters go back to zero); from the picture plane too (pnn_predict_tbs_device's small passes)."""
+    if precision != "f32":
+        pytest.skip("exact-f32 kernels only")
+    params = util.make_params(w, False, 71, out_gain=util.out_gain(w, False))
+    big = {4: 400, 8: 300, 16: 150, 32: 40}[w]
+    above, left = util.make_contexts(w, big, 72)
+    net = pnn.PredictionNeuralNetwork(big, w, False, params=params)
+    want_f, want_p = net.predict(above, left), net.predict_pel(above, left)
+    saved = {}
+    for n in (1, 2, 3, 6, 9):
+        res = {}
+        for tails in (0, 1):
+            net.set_option("tails", tails)
+            for rep in range(3 if tails else 1):
+                f = net.predict(above[:n], left[:n])
+                launches = net.last_call_stats()["launches"]
+                q = net.predict_pel(above[:n], left[:n])
+                assert np.array_equal(f, want_f[:n]), "tails = %d, %d blocks, call %d: float predictions differ from the large batch's" % (tails, n, rep)
+                assert np.array_equal(q, want_p[:n]), "tails = %d, %d blocks, call %d: Pel blocks differ" % (tails, n, rep)
+            res[tails] = launches
+        saved[n] = res[0] - res[1]
+        assert saved[n] in (0, 1, 2), saved
+    if w in (8, 16):
+        assert saved[1] == 2 and saved[3] == 2, saved                # both tails (the 4x4 net's last layer has 32 input maps: its own kernel; 32x32: K segments in front of the merger)
+    # ... and with other options that move the small kernels' data around
+    for opts in ({"chain_io": 0}, {"f32_small_deep": 2}, {"pair": 0}, {"flag_wait": 0}):
+        for k, v in opts.items():
+            net.set_option(k, v)
+        assert np.array_equal(net.predict(above[:2], left[:2]), want_f[:2]), opts
+        assert np.array_equal(net.predict_pel(above[:1], left[:1]), want_p[:1]), opts
+        for k in opts:
+            net.set_option(k, {"chain_io": 1, "f32_small_deep": 1, "pair": 1, "flag_wait": 1}[k])
+    net.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w,is_fc,slice_blocks,n", [(8, True, 512, 2300), (4, True, 1024, 5000), (16, False, 128, 700), (32, False, 32, 100)])
 def test_host_calls_of_several_slices_overlap_and_keep_the_bits(pnn, precision, w, is_fc, slice_blocks, n):
     """Host-array calls of several passes' worth of blocks (the reference's batched driver, pnn/batching.py:7-88) run slice
