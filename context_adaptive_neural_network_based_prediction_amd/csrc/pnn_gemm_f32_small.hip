@@ -74,8 +74,8 @@ __device__ __forceinline__ void f32s_dma16(const __amdgpu_buffer_rsrc_t& r, unsi
 // (ablation build) a single 16x16 block took 73.7 us instead of 86.9 (profiles/r06_b1_chain_order.txt).  The PRODUCER of such a tensor
 // is the epilogue below (p.chain_io bit 1: two 8-byte stores per lane instead of one 16-byte); the pass decides which tensors travel
 // that way (both ends on these kernels: pnn_passes.cpp).  Same values in another place: not a bit of any sum changes.
-// WT (round 6): the tile is written THROUGH to memory (store16_through) -- its reader is a tail of this same launch, on another XCD
-// whose L2 does not see this one's (small_tail_* below); channel order, no K segments.
+// WT (round 6): the tile is written THROUGH to memory (store16_through) as 1 KiB of its own (tile-major, pnn_small_bodies.h) -- its
+// reader is a tail of this same launch, on another XCD whose L2 does not see this one's (small_tail_* below); no K segments.
 template <bool INL, int LA, bool XCH = false, bool WT = false>
 __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const int bx, const int by, const int bz, const int gy)
 {
@@ -315,7 +315,7 @@ __device__ __forceinline__ void tapgemm_f32_small_body(CF32SmallParams& p, const
     float* const Yo = (nseg > 1 && p.Y) ? p.Y + (size_t)seg * p.seg_stride : p.Y;
     f32x4 v = acc + *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.act) { v[0] = leaky(v[0]); v[1] = leaky(v[1]); v[2] = leaky(v[2]); v[3] = leaky(v[3]); }
-    if (WT) store16_through(reinterpret_cast<f32x4*>(Yo + obase + n), v);
+    if (WT) store16_through(reinterpret_cast<f32x4*>(Yo) + ((size_t)(by * ((p.M + 15) >> 4) + bx) * 64 + lane), v);   // tile-major: tile_major_piece, pnn_small_bodies.h
     else if (Yo) store4_chain(Yo + obase + n0, q, v, (p.chain_io & 2) != 0 && !(nseg > 1));   // (raw K-segment planes: as they are; the fold writes the layer's output)
     if (p.Yi) *reinterpret_cast<int4*>(p.Yi + obase + n) = make_int4(hm_round(v[0], p.mean), hm_round(v[1], p.mean), hm_round(v[2], p.mean), hm_round(v[3], p.mean));
     F32S_DIAG_EXIT();

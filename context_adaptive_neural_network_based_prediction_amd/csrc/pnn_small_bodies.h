@@ -7,8 +7,18 @@
 
 namespace pnn {
 
-// cache-policy bits of a raw buffer load on gfx950: sc0 | sc1 = system scope, past the XCD's L2 (what another XCD wrote through)
+// cache-policy bits of a raw buffer load on gfx950: sc0 | sc1 = system scope (what another XCD wrote through)
 constexpr int kAuxThrough = 1 | 16;
+// A [M][C] tensor that workgroups of ONE launch write through and other workgroups of the same launch read (the tails of
+// pnn_gemm_f32_small.hip) is TILE-MAJOR: the 16 x 16 tile (rows 16 R .., channels 16 G ..) is 1 KiB of its own, [G][R][piece g = channels
+// 4 g .. 4 g + 3][row][4 floats] -- the producing wave's lanes side by side.  In [row][channel] order two 16-channel tiles share every
+// 128-byte line; the L2 of the XCD that wrote one half keeps the line WITH the other half as it was, and a reader on that XCD is served
+// from it, system-scope load or not (tools/tails_stress.py: 1 call in 10 000 wrong beside four other contexts).  A line that ONE
+// workgroup writes whole is right wherever it is cached.  Byte offset of the piece (row m, channels 16 G + 4 g ..), gx = M / 16:
+__device__ __forceinline__ unsigned tile_major_piece(unsigned m, unsigned G, unsigned g, unsigned gx)
+{
+    return (((G * gx + (m >> 4)) * 64u + g * 16u + (m & 15u)) * 4u) << 2;
+}
 
 // One 16-block x 16-channel tile of the merger (see merger_mfma_kernel, pnn_small.hip): rows = blocks first .. first + 15 (clamped to
 // B - 1), channels c0 .. c0 + 15; `red` = 48 KiB of LDS.  ONE: every row is block `first` -- the tail of a small pass, where the tile's
@@ -31,12 +41,13 @@ __device__ __forceinline__ void merger_mfma_tile(const MergerParams& p, f32x4 (*
     for (int t = 0; t < 5; t++) {
         const int p0 = 4 * (wave + 4 * t);            // first position of this step (wave-uniform): above part or left part
         const float* wr = p.Wp + ((size_t)(p0 + lk) * 16 + li) * p.C + c0;
-        if (ONE) {
+        if (ONE) {                                    // the branch maps are tile-major here (tile_major_piece)
             const bool ab = p0 < p.na;
-            const unsigned off = (unsigned)(((size_t)brow * (ab ? p.na : p.nl) + (ab ? p0 : p0 - p.na) + lk) * p.C + c0) * 4u;
+            const unsigned np = ab ? p.na : p.nl;
+            const unsigned m = (unsigned)brow * np + (unsigned)(ab ? p0 : p0 - p.na) + lk;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                xv[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab ? arsrc : lrsrc, off + 16u * q, 0, kAuxThrough));
+                xv[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab ? arsrc : lrsrc, tile_major_piece(m, c0 >> 4, q, ((unsigned)p.B * np) >> 4), 0, kAuxThrough));
         } else {
             const float* xr = p0 < p.na ? p.A + ((size_t)brow * p.na + p0 + lk) * p.C + c0
                                         : p.L + ((size_t)brow * p.nl + (p0 - p.na) + lk) * p.C + c0;
@@ -116,15 +127,16 @@ __device__ __forceinline__ void tconv_cout1_mfma_band(const TConv1Params& p, flo
             wv[q] = col < KK ? *reinterpret_cast<const f32x4*>(p.W + col * 64 + 8 * q + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* xb = p.X + ((b * p.IH + iy0) * (long)p.IW) * 64;
         __amdgpu_buffer_rsrc_t xrsrc;
-        if (THROUGH) xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7fffffff, 0x00020000);
+        if (THROUGH) xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0x7fffffff, 0x00020000);   // tile-major (tile_major_piece)
         for (int t = wave; t < tiles; t += 4) {
             int px = t * 32 + col;
             if (px >= npx) px = npx - 1;              // padding rows of the last tile: recomputed, never read
             f32x4 xv[8];
             if (THROUGH) {
+                const unsigned m = (unsigned)((b * p.IH + iy0) * (long)p.IW) + (unsigned)px, gx = ((unsigned)p.B * p.IH * p.IW) >> 4;
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    xv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)(px * 64 + 4 * h + 8 * q) * 4u, 0, kAuxThrough));
+                for (int q = 0; q < 8; q++)       // channels 8 q + 4 h ..: 16-channel group q / 2, piece 2 (q & 1) + h
+                    xv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, tile_major_piece(m, q >> 1, 2 * (q & 1) + h, gx), 0, kAuxThrough));
             } else {
                 const float* xr = xb + (long)px * 64 + 4 * h;
 #pragma unroll

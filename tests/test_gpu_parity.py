@@ -490,6 +490,23 @@ def test_small_conv_passes_run_merger_and_last_layer_as_tails(pnn, precision, w)
 
 
 @pytest.mark.gpu
+def test_small_passes_of_five_contexts_side_by_side_keep_their_bits(precision):
+    """tools/tails_stress.py: five host threads, one context each (the batching service's layout), random small batches back to back
+    for 8 s -- every call equals the large batch's bits.  The first form of the tails failed this 1 call in 10 000 (tiles of two
+    workgroups sharing 128-byte lines between XCDs) and passed every single-context test."""
+    if precision != "f32":
+        pytest.skip("exact-f32 kernels only")
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tails_stress.py"), "8", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("tails =")][-1]
+    import re
+    counts = re.findall(r"'(\w+)': \((\d+), (\d+)", line)
+    assert len(counts) == 5 and all(int(bad) == 0 and int(calls) > 1000 for _, bad, calls in counts), line
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w,is_fc,slice_blocks,n", [(8, True, 512, 2300), (4, True, 1024, 5000), (16, False, 128, 700), (32, False, 32, 100)])
 def test_host_calls_of_several_slices_overlap_and_keep_the_bits(pnn, precision, w, is_fc, slice_blocks, n):
     """Host-array calls of several passes' worth of blocks (the reference's batched driver, pnn/batching.py:7-88) run slice
