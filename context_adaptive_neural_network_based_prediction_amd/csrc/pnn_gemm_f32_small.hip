@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void tapgemm_f32_small_tail_kernel(const F32Sm
     const long b = ((long)blockIdx.x * 16) / SP;
     if (!small_tail_arrive(k->t.cnt + b, (unsigned)(SP >> 4) * gridDim.y, reinterpret_cast<unsigned*>(ring))) return;
     const TConv1Params& tp = args.t.t;
-    tconv_cout1_mfma_band<2, 5, true>(tp, reinterpret_cast<float*>(ring), b, 0);
+    if (tp.Cin == 64) tconv_cout1_mfma_band<2, 5, true>(tp, reinterpret_cast<float*>(ring), b, 0);   // (launch-uniform)
+    else tconv_cout1_lds_tile<true>(tp, ring, (int)b, 0);
     if (tp.done.host_flag) {                         // one flag word per block (DoneSignal::per_wg)
         __threadfence_system();
         __syncthreads();
@@ -874,10 +875,19 @@ static hipError_t f32_small_tail_attrs()
 // The last GEMM of the transposed stack + the net's last layer per block (SmallTail kind 2).  hipErrorInvalidValue: not this shape.
 bool f32_small_cout1_tail_ok(const TapGemmParams& p, const TConv1Params& t)
 {
-    if (!f32_small_tail_layer_ok(p) || p.Cout != 64 || t.Cin != 64 || t.s != 2 || t.k != 5 || t.pad > t.k - 1) return false;
+    if (!f32_small_tail_layer_ok(p) || p.Cout != t.Cin) return false;
     if (t.IH != p.OH || t.IW != p.OW || p.os != 1 || t.B * p.SH * p.SW != p.M) return false;   // the GEMM's output map is the last layer's input
-    const int npx = t.IH * t.IW;                      // one band: the whole input map in T
-    return (size_t)((npx + 31) / 32) * 32 * kTcTP * sizeof(float) <= tapgemm_f32_small_lds_bytes(false);
+    if (t.Cin == 64) {                                // tconv_cout1_mfma_kernel's form: one band, the whole input map in T
+        if (t.s != 2 || t.k != 5 || t.pad > t.k - 1) return false;
+        const int npx = t.IH * t.IW;
+        return (size_t)((npx + 31) / 32) * 32 * kTcTP * sizeof(float) <= tapgemm_f32_small_lds_bytes(false);
+    }
+    // tconv_cout1_kernel's form (the 4x4 net: 32 maps, 3x3, stride 1): one output tile, one image per workgroup
+    if ((t.s != 1 && t.s != 2) || t.Cin % 4 || t.IH != t.IW || t.IH * t.s > 16 || (t.s == 2 && ((t.IH * t.s) & 1))) return false;
+    const int TO = t.IH * t.s, lo = t.pad - (t.k - 1);
+    const int i0 = lo >= 0 ? lo / t.s : -((-lo + t.s - 1) / t.s);
+    const int TI = (TO - 1 + t.pad) / t.s - i0 + 1;
+    return (size_t)(TI * TI + t.k * t.k) * t.Cin * sizeof(float) <= tapgemm_f32_small_lds_bytes(false);
 }
 hipError_t launch_tapgemm_f32_small_tail(const TapGemmParams& p, const SmallTail& t, hipStream_t s, int deep_mode)
 {
@@ -886,7 +896,7 @@ hipError_t launch_tapgemm_f32_small_tail(const TapGemmParams& p, const SmallTail
     if (t.kind != 2 || !t.cnt || !f32_small_cout1_tail_ok(p, t.t) || (t.t.done.host_flag && !t.t.done.per_wg)) return hipErrorInvalidValue;
     F32SmallTailArgs a;
     a.p = p; a.t = t;
-    a.t.t.ni = t.t.IH * t.t.s;                        // one band of all output rows
+    a.t.t.ni = t.t.Cin == 64 ? t.t.IH * t.t.s : 1;    // one band of all output rows / one image per workgroup
     const dim3 grid((p.M + 15) / 16, (p.Cout + 15) / 16, 1);
     const bool deep = f32_small_deep(tapgemm_f32_small_tiles(p), deep_mode, false), xch = (p.chain_io & 1) != 0;
     if (deep && xch) pnn_launch(tapgemm_f32_small_tail_kernel<kF32SmallLADeep, true>, grid, dim3(256), tapgemm_f32_small_lds_bytes(true), s, a);

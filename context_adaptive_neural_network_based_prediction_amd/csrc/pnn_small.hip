@@ -299,79 +299,7 @@ __global__ __launch_bounds__(256) void tconv_cout1_kernel(const TConv1Params p)
 {
     touch_kernargs<sizeof(TConv1Params)>();
     extern __shared__ __attribute__((aligned(16))) f32x4 xt[];       // [image in WG][Cin/4][TI*TI]
-    const int s = p.s, K = p.k;
-    const int OH = p.IH * s, OW = p.IW * s;
-    const int TO = OH < 16 ? OH : 16;                 // output tile edge (square images: OH == OW)
-    const int tiles_x = (OW + TO - 1) / TO;
-    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
-    const int oy0 = ty * TO, ox0 = tx * TO;
-    // input rows/cols that can reach this output tile: iy in [floor((oy0 + pad - (K-1)) / s), (oy0 + TO-1 + pad) / s]
-    const int lo_y = oy0 + p.pad - (K - 1), lo_x = ox0 + p.pad - (K - 1);
-    const int iy0 = lo_y >= 0 ? lo_y / s : -((-lo_y + s - 1) / s);
-    const int ix0 = lo_x >= 0 ? lo_x / s : -((-lo_x + s - 1) / s);
-    const int TI = (oy0 + TO - 1 + p.pad) / s - iy0 + 1;
-    const int NP = TI * TI, C4 = p.Cin >> 2;
-    const int NI = p.ni;                              // images per workgroup (small outputs share a workgroup)
-    const long bbase = (long)blockIdx.x * NI;
-    for (int idx = threadIdx.x; idx < NI * NP * C4; idx += 256) {
-        const int li = idx / (NP * C4), r0 = idx - li * NP * C4;
-        const int pix = r0 / C4, c4 = r0 - pix * C4;
-        const int r = pix / TI, c = pix - r * TI;
-        const int iy = iy0 + r, ix = ix0 + c;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bbase + li < p.B && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
-            v = *reinterpret_cast<const f32x4*>(p.X + (((bbase + li) * p.IH + iy) * p.IW + ix) * p.Cin + 4 * c4);
-        xt[(li * C4 + c4) * NP + pix] = v;
-    }
-    // the k x k x Cin weights behind the tiles: read per (tap, channel quad) as one broadcast ds_read_b128 in the inner
-    // loop (as wave-uniform scalar loads they cost a ~200-cycle round trip per iteration: 26 us for the 16x16 net at
-    // batch 1024, most of it waiting)
-    f32x4* wl = xt + NI * C4 * NP;
-    for (int idx = threadIdx.x; idx < K * K * C4; idx += 256) wl[idx] = reinterpret_cast<const f32x4*>(p.W)[idx];
-    __syncthreads();
-
-    // Thread -> (image, output pixel).  Stride 2: wave = parity class (py, px), lanes = NI images x (TO/2)^2
-    // pixels of that class, so the tap set is wave-uniform.  Stride 1: plain row-major pixels, every tap valid.
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int li, oy, ox, py, px;
-    bool live;
-    if (s == 2) {
-        const int SG = TO >> 1, SGP = SG * SG;
-        py = wave >> 1; px = wave & 1;
-        li = lane / SGP;
-        const int sub = lane - li * SGP;
-        oy = oy0 + 2 * (sub / SG) + py; ox = ox0 + 2 * (sub % SG) + px;
-        live = li < NI;
-    } else {
-        const int PT = TO * TO;
-        py = 0; px = 0;
-        li = threadIdx.x / PT;
-        const int sub = threadIdx.x - li * PT;
-        oy = oy0 + sub / TO; ox = ox0 + sub % TO;
-        live = li < NI;
-    }
-    if (!live) li = 0;
-    float acc = 0.f;
-    for (int ky = 0; ky < K; ky++) {
-        if ((py + p.pad - ky) % s) continue;          // wave-uniform: parity class (s = 2) or always taken (s = 1)
-        const int ry = (oy + p.pad - ky) / s - iy0;   // exact division for this class; inside the staged tile
-        for (int kx = 0; kx < K; kx++) {
-            if ((px + p.pad - kx) % s) continue;
-            const int rx = (ox + p.pad - kx) / s - ix0;
-            const f32x4* xp = xt + (size_t)li * C4 * NP + ry * TI + rx;
-            const f32x4* wp = wl + (ky * K + kx) * C4;
-            for (int c4 = 0; c4 < C4; c4++) {
-                const f32x4 xv = xp[c4 * NP], wv = wp[c4];
-                acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
-            }
-        }
-    }
-    if (live && bbase + li < p.B && oy < OH && ox < OW) {
-        const float v = acc + p.bias;
-        const size_t o = ((size_t)(bbase + li) * OH + oy) * OW + ox;
-        if (p.Y) p.Y[o] = v;
-        if (p.Yi) p.Yi[o] = hm_round(v, p.mean);
-    }
+    tconv_cout1_lds_tile<false>(p, xt, blockIdx.x, blockIdx.y);        // pnn_small_bodies.h
     signal_done(p.done);
 }
 

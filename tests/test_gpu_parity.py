@@ -476,8 +476,8 @@ def test_small_conv_passes_run_merger_and_last_layer_as_tails(pnn, precision, w)
             res[tails] = launches
         saved[n] = res[0] - res[1]
         assert saved[n] in (0, 1, 2), saved
-    if w in (8, 16):
-        assert saved[1] == 2 and saved[3] == 2, saved                # both tails (the 4x4 net's last layer has 32 input maps: its own kernel; 32x32: K segments in front of the merger)
+    if w in (4, 8, 16):
+        assert saved[1] == 2 and saved[3] == 2, saved                # both tails (32x32: K segments in front of the merger, four classes in front of the last layer)
     # ... and with other options that move the small kernels' data around
     for opts in ({"chain_io": 0}, {"f32_small_deep": 2}, {"pair": 0}, {"flag_wait": 0}):
         for k, v in opts.items():
