@@ -933,8 +933,9 @@ int conv_pass(pnn_ctx* c, Model* m, const float* d_above, const float* d_left, l
                 if (dbg) fprintf(stderr, "[pnn]   ... with the merger as its tail\n");
                 HIPCHK(c, launch_tapgemm_f32_small_pair_tail(q[0], q[1], mt, s, (int)c->opt_f32_small_deep));
                 merger_done = true; merger_chain_done = mt.m.chain != 0; merged_in = cur ^ 1;
-            } else
-            HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s, (int)c->opt_f32_small_deep));
+            } else {
+                HIPCHK(c, launch_tapgemm_f32_small_pair(q[0], q[1], s, (int)c->opt_f32_small_deep));
+            }
             c->stat_gemm_launches++; c->stat_launches++;
             for (int br = 0; br < 2; br++) {
                 const GemmLayer& L = m->branch[br][i];
