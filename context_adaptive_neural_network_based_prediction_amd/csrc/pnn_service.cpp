@@ -78,7 +78,11 @@ struct ShmDoor { alignas(64) std::atomic<uint32_t> bell; std::atomic<uint32_t> s
 // 100-encoder campaign holds 500 slots); the slot's state word stays the truth: a stale bit costs one look, a bit that was never set
 // belongs to a client that died.
 constexpr int kShmMaxSlots = 1024;
-struct ShmDoors { ShmDoor door[5]; alignas(64) std::atomic<uint64_t> posted[5][kShmMaxSlots / 64]; };
+// spin_us: the server's hint to both sides of a request -- with FEW clients connected (a couple of encoders: their waits are what their
+// wall clock is made of, and CPUs are idle) a client polls its slot, and an idle worker its posted bits, for that long before going to
+// sleep on the futex: a wake-up through the kernel is 5-10 us on each side of a 35-45 us call.  0 with many clients (a campaign: every CPU
+// is taken, and a polling client would take one from an encoder that has work).
+struct ShmDoors { ShmDoor door[5]; alignas(64) std::atomic<uint64_t> posted[5][kShmMaxSlots / 64]; alignas(64) std::atomic<uint32_t> spin_us; };
 constexpr size_t kSlotBytes = (sizeof(ShmSlot) + 4095) / 4096 * 4096, kDoorBytes = (sizeof(ShmDoors) + 4095) / 4096 * 4096;
 static_assert(std::atomic<uint32_t>::is_always_lock_free && std::atomic<uint64_t>::is_always_lock_free, "futex words and flags in shared memory");
 
@@ -255,6 +259,9 @@ struct Server {
     std::shared_ptr<ShmClient> shm_table[kShmMaxSlots];
     std::atomic<int> shm_hi{0};                       // indices >= this were never handed out
     std::atomic<long> shm_clients{0}, shm_requests{0};
+    long shm_live = 0;                                // slots listed now (under shm_mu)
+    long spin_slots = 20, spin_cfg_us = 200;         // ShmDoors::spin_us = spin_cfg_us while at most spin_slots are listed (an encoder holds five)
+    void publish_spin() { doors->spin_us.store(shm_live <= spin_slots ? (uint32_t)spin_cfg_us : 0u, std::memory_order_relaxed); }
     // The wake-ups of a batch's clients are NOT the worker's job: one futex_wake per client is 2-4 us of system call, in front of the
     // worker's next batch (first form of round 6: configs[3] 4.88 -> 5.11 s, the 4x4 / 8x8 workers being what its encoders wait for;
     // profiles/r06_service_transport.txt).  The worker writes the replies and flips the states -- a client that is not asleep yet sees
@@ -494,6 +501,12 @@ struct Server {
                 }
                 return true;
             }
+            if (const uint32_t spin = doors->spin_us.load(std::memory_order_relaxed)) {   // few clients: poll for the next request before sleeping
+                const uint64_t t0 = now_ns();
+                bool found = false;
+                while (!(found = has_pending(k)) && !quit_flag.load(std::memory_order_relaxed) && now_ns() - t0 < (uint64_t)spin * 1000u) __builtin_ia32_pause();
+                if (found) continue;
+            }
             const uint32_t seen = d.bell.load(std::memory_order_seq_cst);
             d.sleeping.store(1, std::memory_order_seq_cst);
             if (!has_pending(k) && !quit_flag.load()) futex_wait(&d.bell, seen, 50000);   // (bounded: a lost wake-up costs 50 ms, not the server)
@@ -575,6 +588,8 @@ struct Server {
                 for (int k = 0; k < 5; k++) doors->posted[k][sc->index >> 6].fetch_and(~(1ull << (sc->index & 63)), std::memory_order_seq_cst);   // a bit its previous owner left
                 std::atomic_store(&shm_table[sc->index], sc);
                 if (sc->index >= shm_hi.load()) shm_hi.store(sc->index + 1, std::memory_order_release);
+                ++shm_live;
+                publish_spin();
             }
         }
         struct { RspHeader rh; int32_t worker[5]; int32_t index; } body;
@@ -609,7 +624,11 @@ struct Server {
     {
         sc->dead.store(true);
         std::lock_guard<std::mutex> lk(shm_mu);
-        if (sc->index >= 0 && std::atomic_load(&shm_table[sc->index]) == sc) std::atomic_store(&shm_table[sc->index], std::shared_ptr<ShmClient>());
+        if (sc->index >= 0 && std::atomic_load(&shm_table[sc->index]) == sc) {
+            std::atomic_store(&shm_table[sc->index], std::shared_ptr<ShmClient>());
+            --shm_live;
+            publish_spin();
+        }
     }
 
     // One I/O thread: its share of the connections (receive, queue for the workers, reply); thread 0 also owns the listener.
@@ -834,6 +853,9 @@ struct Server {
         void* dm = (door_fd >= 0 && ftruncate(door_fd, (off_t)kDoorBytes) == 0) ? mmap(nullptr, kDoorBytes, PROT_READ | PROT_WRITE, MAP_SHARED, door_fd, 0) : MAP_FAILED;
         if (dm == MAP_FAILED) { if (door_fd >= 0) close(door_fd); return PNN_E_IO; }
         doors = new (dm) ShmDoors;
+        if (const char* e = getenv("PNN_SERVICE_SPIN_SLOTS")) spin_slots = atol(e);        // poll instead of sleeping while at most this many slots are listed (0: never)
+        if (const char* e = getenv("PNN_SERVICE_SPIN_US")) spin_cfg_us = std::max(0L, std::min(atol(e), 1000L));
+        { std::lock_guard<std::mutex> lk(shm_mu); publish_spin(); }
         struct DoorGuard { Server* sv; ~DoorGuard() { munmap(sv->doors, kDoorBytes); close(sv->door_fd); sv->doors = nullptr; } } door_guard{this};
         const int lfd = socket(AF_UNIX, SOCK_STREAM, 0);
         if (lfd < 0) return PNN_E_IO;
@@ -1147,6 +1169,10 @@ static int client_call(pnn_client* c, int width, const float* above, const float
         door.bell.fetch_add(1, std::memory_order_seq_cst);
         if (door.sleeping.load(std::memory_order_seq_cst)) futex_wake(&door.bell, 1);
         int idle_rounds = 0;
+        if (const uint32_t spin = static_cast<ShmDoors*>(c->doors)->spin_us.load(std::memory_order_relaxed)) {   // few clients: see ShmDoors::spin_us
+            const uint64_t t0 = sl->posted_ns;
+            while (sl->state.load(std::memory_order_acquire) != kSlotReady && now_ns() - t0 < (uint64_t)spin * 1000u) __builtin_ia32_pause();
+        }
         for (;;) {
             uint32_t st = sl->state.load(std::memory_order_acquire);
             if (st == kSlotReady) break;

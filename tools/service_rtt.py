@@ -18,7 +18,6 @@ params = util.make_params(w, fc, 1, out_gain=util.out_gain(w, fc))
 above, left = util.make_contexts(w, n, 2)
 rows = util.flatten_fc(above, left) if fc else None
 net = PredictionNeuralNetwork(1, w, fc, params=params)
-net.set_option("canonical_order", 1)
 net.set_option("cache_mb", 0)
 dst = np.empty((w, w), np.int32)
 
